@@ -1,0 +1,710 @@
+/*
+ * tfhe_oracle.c -- CPU restatement of the TFHE programmable-bootstrap path (see tfhe_oracle.h for
+ * what it restates, what pins it and what stays unpinned).  TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain C11, integers only.  Polynomial products are exact in Z[X]/(X^N+1) and then wrapped to
+ * 2^64, which is the semantics of tfhe-rs polynomial_wrapping_mul used by the reference at
+ * ml/extensions/rust/src/computations.rs:50-54.  Two routes are kept: schoolbook (the definition)
+ * and a two-prime NTT + CRT route (the fast one); tests check them against each other.
+ */
+#include "tfhe_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+typedef unsigned __int128 u128;
+typedef __int128 i128;
+typedef uint64_t u64;
+typedef int64_t i64;
+typedef uint32_t u32;
+
+/* ------------------------------------------------------------------------------------------- */
+/* ChaCha20 keystream (RFC 8439 quarter round / block function), 64-bit block counter.          */
+/* ------------------------------------------------------------------------------------------- */
+static inline u32 rotl32(u32 x, int n) { return (x << n) | (x >> (32 - n)); }
+#define QR(a, b, c, d)                                                                             \
+    do {                                                                                           \
+        a += b; d ^= a; d = rotl32(d, 16);                                                         \
+        c += d; b ^= c; b = rotl32(b, 12);                                                         \
+        a += b; d ^= a; d = rotl32(d, 8);                                                          \
+        c += d; b ^= c; b = rotl32(b, 7);                                                          \
+    } while (0)
+
+static void chacha_block(orc_rng* r) {
+    u32 s[16], x[16];
+    s[0] = 0x61707865u; s[1] = 0x3320646eu; s[2] = 0x79622d32u; s[3] = 0x6b206574u;
+    for (int i = 0; i < 8; ++i) s[4 + i] = r->key[i];
+    s[12] = (u32)r->counter; s[13] = (u32)(r->counter >> 32);
+    s[14] = (u32)r->stream;  s[15] = (u32)(r->stream >> 32);
+    memcpy(x, s, sizeof x);
+    for (int i = 0; i < 10; ++i) {
+        QR(x[0], x[4], x[8], x[12]); QR(x[1], x[5], x[9], x[13]);
+        QR(x[2], x[6], x[10], x[14]); QR(x[3], x[7], x[11], x[15]);
+        QR(x[0], x[5], x[10], x[15]); QR(x[1], x[6], x[11], x[12]);
+        QR(x[2], x[7], x[8], x[13]); QR(x[3], x[4], x[9], x[14]);
+    }
+    for (int i = 0; i < 16; ++i) r->buf[i] = x[i] + s[i];
+    r->counter++;
+    r->pos = 0;
+}
+
+void orc_rng_init(orc_rng* r, const uint8_t seed[32], uint64_t stream) {
+    for (int i = 0; i < 8; ++i)
+        r->key[i] = (u32)seed[4 * i] | ((u32)seed[4 * i + 1] << 8) | ((u32)seed[4 * i + 2] << 16) |
+                    ((u32)seed[4 * i + 3] << 24);
+    r->counter = 0;
+    r->stream = stream;
+    r->pos = 16;
+}
+
+uint64_t orc_rng_u64(orc_rng* r) {
+    if (r->pos >= 16) chacha_block(r);
+    u64 lo = r->buf[r->pos], hi = r->buf[r->pos + 1];
+    r->pos += 2;
+    return lo | (hi << 32);
+}
+
+/* TUniform(b): uniform over the 2^(b+1)+1 integers of [-2^b, 2^b] (rejection sampling on b+2
+ * bits).  tfhe-rs weights the two end points by one half instead; the support is the same and no
+ * reference fixture depends on the sampler. */
+uint64_t orc_rng_tuniform(orc_rng* r, uint32_t b) {
+    const u64 span = ((u64)1 << (b + 1)) + 1;
+    const u64 mask = ((u64)1 << (b + 2)) - 1;
+    for (;;) {
+        u64 v = orc_rng_u64(r) & mask;
+        if (v < span) return v - ((u64)1 << b);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* modular arithmetic                                                                          */
+/* ------------------------------------------------------------------------------------------- */
+uint64_t orc_mulmod(uint64_t a, uint64_t b, uint64_t p) { return (u64)(((u128)a * b) % p); }
+
+uint64_t orc_powmod(uint64_t a, uint64_t e, uint64_t p) {
+    u64 r = 1 % p;
+    a %= p;
+    while (e) {
+        if (e & 1) r = orc_mulmod(r, a, p);
+        a = orc_mulmod(a, a, p);
+        e >>= 1;
+    }
+    return r;
+}
+
+static int is_prime_u64(u64 n) {
+    if (n < 2) return 0;
+    static const u64 small[] = {2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37};
+    for (size_t i = 0; i < sizeof small / sizeof small[0]; ++i) {
+        if (n == small[i]) return 1;
+        if (n % small[i] == 0) return 0;
+    }
+    u64 d = n - 1;
+    int s = 0;
+    while ((d & 1) == 0) { d >>= 1; ++s; }
+    /* these 12 bases are a deterministic Miller-Rabin certificate below 2^64 */
+    for (size_t i = 0; i < sizeof small / sizeof small[0]; ++i) {
+        u64 x = orc_powmod(small[i], d, n);
+        if (x == 1 || x == n - 1) continue;
+        int comp = 1;
+        for (int k = 1; k < s; ++k) {
+            x = orc_mulmod(x, x, n);
+            if (x == n - 1) { comp = 0; break; }
+        }
+        if (comp) return 0;
+    }
+    return 1;
+}
+
+/* Montgomery arithmetic mod an odd p < 2^63, R = 2^64 */
+typedef struct {
+    u64 p, pinv_neg, r2; /* -p^-1 mod 2^64, R^2 mod p */
+} mont_t;
+
+static inline u64 mont_redc(const mont_t* m, u128 t) {
+    u64 q = (u64)t * m->pinv_neg;
+    u128 u = t + (u128)q * m->p;
+    u64 r = (u64)(u >> 64);
+    return r >= m->p ? r - m->p : r;
+}
+static inline u64 mont_mul(const mont_t* m, u64 a, u64 b) { return mont_redc(m, (u128)a * b); }
+static inline u64 to_mont(const mont_t* m, u64 a) { return mont_mul(m, a, m->r2); }
+static void mont_init(mont_t* m, u64 p) {
+    m->p = p;
+    u64 inv = p; /* Newton: inv = p^-1 mod 2^64 */
+    for (int i = 0; i < 6; ++i) inv *= 2 - p * inv;
+    m->pinv_neg = (u64)0 - inv;
+    u64 r = (u64)(((u128)1 << 64) % p);
+    m->r2 = orc_mulmod(r, r, p);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* negacyclic NTT over one prime (tables in Montgomery form, data in plain form)               */
+/* ------------------------------------------------------------------------------------------- */
+typedef struct {
+    mont_t m;
+    u64 psi;          /* primitive 2N-th root of unity (plain) */
+    u64* w_fwd;       /* psi^bitrev(i), Montgomery form, i < N */
+    u64* w_inv;       /* psi^-bitrev(i), Montgomery form */
+    u64 ninv_mont;    /* N^-1, Montgomery form */
+} ntt_prime;
+
+static u32 bitrev(u32 x, u32 bits) {
+    u32 r = 0;
+    for (u32 i = 0; i < bits; ++i) r |= ((x >> i) & 1u) << (bits - 1 - i);
+    return r;
+}
+
+static u64 find_psi(u64 p, u32 N) {
+    /* smallest g whose (p-1)/2N power has order exactly 2N (its N-th power is -1) */
+    for (u64 g = 2;; ++g) {
+        u64 c = orc_powmod(g, (p - 1) / (2 * (u64)N), p);
+        if (orc_powmod(c, N, p) == p - 1) return c;
+    }
+}
+
+static void ntt_prime_init(ntt_prime* t, u64 p, u32 N) {
+    u32 logn = 0;
+    while ((1u << logn) < N) ++logn;
+    mont_init(&t->m, p);
+    t->psi = find_psi(p, N);
+    u64 psi_inv = orc_powmod(t->psi, p - 2, p);
+    t->w_fwd = (u64*)malloc(sizeof(u64) * N);
+    t->w_inv = (u64*)malloc(sizeof(u64) * N);
+    for (u32 i = 0; i < N; ++i) {
+        u32 e = bitrev(i, logn);
+        t->w_fwd[i] = to_mont(&t->m, orc_powmod(t->psi, e, p));
+        t->w_inv[i] = to_mont(&t->m, orc_powmod(psi_inv, e, p));
+    }
+    t->ninv_mont = to_mont(&t->m, orc_powmod(N, p - 2, p));
+}
+
+/* forward: natural order in, bit-reversed order out (Cooley-Tukey, twist merged) */
+static void ntt_fwd(const ntt_prime* t, u64* a, u32 N) {
+    const u64 p = t->m.p;
+    u32 len = N;
+    for (u32 m = 1; m < N; m <<= 1) {
+        len >>= 1;
+        for (u32 i = 0; i < m; ++i) {
+            const u64 w = t->w_fwd[m + i];
+            u64* x = a + 2 * i * len;
+            for (u32 j = 0; j < len; ++j) {
+                u64 u = x[j], v = mont_mul(&t->m, x[j + len], w);
+                u64 s = u + v; if (s >= p) s -= p;
+                u64 d = u >= v ? u - v : u + p - v;
+                x[j] = s; x[j + len] = d;
+            }
+        }
+    }
+}
+
+/* inverse: bit-reversed order in, natural order out (Gentleman-Sande), scaled by 1/N */
+static void ntt_inv(const ntt_prime* t, u64* a, u32 N) {
+    const u64 p = t->m.p;
+    u32 len = 1;
+    for (u32 m = N >> 1; m >= 1; m >>= 1) {
+        for (u32 i = 0; i < m; ++i) {
+            const u64 w = t->w_inv[m + i];
+            u64* x = a + 2 * i * len;
+            for (u32 j = 0; j < len; ++j) {
+                u64 u = x[j], v = x[j + len];
+                u64 s = u + v; if (s >= p) s -= p;
+                u64 d = u >= v ? u - v : u + p - v;
+                x[j] = s; x[j + len] = mont_mul(&t->m, d, w);
+            }
+        }
+        len <<= 1;
+    }
+    for (u32 j = 0; j < N; ++j) a[j] = mont_mul(&t->m, a[j], t->ninv_mont);
+}
+
+void orc_ntt_definition(uint64_t p, uint64_t psi, const uint64_t* in, uint64_t* out, uint32_t N) {
+    for (u32 j = 0; j < N; ++j) {
+        const u64 step = orc_powmod(psi, 2 * (u64)j + 1, p);
+        u64 acc = 0, w = 1;
+        for (u32 i = 0; i < N; ++i) {
+            acc = (u64)(((u128)acc + (u128)orc_mulmod(in[i] % p, w, p)) % p);
+            w = orc_mulmod(w, step, p);
+        }
+        out[j] = acc;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* context                                                                                     */
+/* ------------------------------------------------------------------------------------------- */
+struct orc_ctx {
+    orc_params prm;
+    u32 logN;
+    ntt_prime pr[2];
+    u64 p0_inv_mod_p1; /* plain */
+};
+
+void orc_default_params(orc_params* p) {
+    /* decoded from the reference fixture sdk/relayer/src/test/keys/privateKey.bin (offsets
+     * 23867-24007): PARAM_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128 */
+    p->lwe_dim = 918; p->glwe_dim = 1; p->poly_size = 2048;
+    p->pbs_base_log = 23; p->pbs_level = 1;
+    p->ks_base_log = 4; p->ks_level = 4;
+    p->message_modulus = 4; p->carry_modulus = 4;
+    p->lwe_noise_log2 = 45; p->glwe_noise_log2 = 17;
+}
+
+orc_ctx* orc_ctx_new(const orc_params* p) {
+    orc_ctx* c = (orc_ctx*)calloc(1, sizeof *c);
+    c->prm = *p;
+    while ((1u << c->logN) < p->poly_size) ++c->logN;
+    /* the two largest primes below 2^62 that are 1 mod 2^16 */
+    u64 cand = ((u64)1 << 62) + 1;
+    int found = 0;
+    while (found < 2) {
+        cand -= (u64)1 << 16;
+        if (is_prime_u64(cand)) ntt_prime_init(&c->pr[found++], cand, p->poly_size);
+    }
+    c->p0_inv_mod_p1 = orc_powmod(c->pr[0].m.p % c->pr[1].m.p, c->pr[1].m.p - 2, c->pr[1].m.p);
+    return c;
+}
+
+void orc_ctx_free(orc_ctx* c) {
+    if (!c) return;
+    for (int i = 0; i < 2; ++i) { free(c->pr[i].w_fwd); free(c->pr[i].w_inv); }
+    free(c);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* polynomial products                                                                         */
+/* ------------------------------------------------------------------------------------------- */
+void orc_negacyclic_mul_schoolbook(uint64_t* out, const int64_t* small, const uint64_t* b, uint32_t N) {
+    memset(out, 0, sizeof(u64) * N);
+    for (u32 i = 0; i < N; ++i) {
+        const u64 s = (u64)small[i];
+        if (!s) continue;
+        for (u32 j = 0; j < N; ++j) {
+            u32 k = i + j;
+            u64 t = s * b[j];
+            if (k < N) out[k] += t; else out[k - N] -= t;
+        }
+    }
+}
+
+static inline u64 reduce_signed(i64 v, u64 p) {
+    i64 r = v % (i64)p;
+    return r < 0 ? (u64)(r + (i64)p) : (u64)r;
+}
+
+/* residues (mod p0, mod p1) of an integer known to lie in (-P/2, P/2), P = p0*p1 -> that integer
+ * wrapped to 2^64 */
+static inline u64 crt_wrap(const orc_ctx* c, u64 y0, u64 y1) {
+    const u64 p0 = c->pr[0].m.p, p1 = c->pr[1].m.p;
+    u64 d = (y1 + p1 - y0 % p1) % p1;
+    u64 k = orc_mulmod(d, c->p0_inv_mod_p1, p1);
+    u128 x = (u128)y0 + (u128)p0 * k;          /* in [0, P) */
+    const u128 P = (u128)p0 * p1;
+    if (x > P / 2) return (u64)x - (u64)P;     /* x - P, wrapped */
+    return (u64)x;
+}
+
+typedef struct {
+    u64* v[2]; /* NTT-domain, Montgomery form, one array per prime */
+} poly_hat;
+
+static void torus_poly_to_hat(const orc_ctx* c, const u64* b, u64* h0, u64* h1) {
+    const u32 N = c->prm.poly_size;
+    for (u32 i = 0; i < N; ++i) {
+        i64 s = (i64)b[i]; /* centred representative in [-2^63, 2^63) */
+        h0[i] = reduce_signed(s, c->pr[0].m.p);
+        h1[i] = reduce_signed(s, c->pr[1].m.p);
+    }
+    ntt_fwd(&c->pr[0], h0, N);
+    ntt_fwd(&c->pr[1], h1, N);
+    for (u32 i = 0; i < N; ++i) { h0[i] = to_mont(&c->pr[0].m, h0[i]); h1[i] = to_mont(&c->pr[1].m, h1[i]); }
+}
+
+void orc_negacyclic_mul_ntt(const orc_ctx* c, uint64_t* out, const int64_t* small, const uint64_t* b) {
+    const u32 N = c->prm.poly_size;
+    u64* buf = (u64*)malloc(sizeof(u64) * N * 4);
+    u64 *a0 = buf, *a1 = buf + N, *b0 = buf + 2 * N, *b1 = buf + 3 * N;
+    for (u32 i = 0; i < N; ++i) {
+        a0[i] = reduce_signed(small[i], c->pr[0].m.p);
+        a1[i] = reduce_signed(small[i], c->pr[1].m.p);
+    }
+    ntt_fwd(&c->pr[0], a0, N); ntt_fwd(&c->pr[1], a1, N);
+    torus_poly_to_hat(c, b, b0, b1);
+    for (u32 i = 0; i < N; ++i) {
+        a0[i] = mont_mul(&c->pr[0].m, a0[i], b0[i]);
+        a1[i] = mont_mul(&c->pr[1].m, a1[i], b1[i]);
+    }
+    ntt_inv(&c->pr[0], a0, N); ntt_inv(&c->pr[1], a1, N);
+    for (u32 i = 0; i < N; ++i) out[i] = crt_wrap(c, a0[i], a1[i]);
+    free(buf);
+}
+
+void orc_monomial_mul(uint64_t* out, const uint64_t* in, uint32_t rot, uint32_t N) {
+    rot %= 2 * N;
+    for (u32 j = 0; j < N; ++j) {
+        u32 k = j + rot;
+        if (k >= 2 * N) k -= 2 * N;
+        if (k < N) out[k] = in[j]; else out[k - N] = (u64)0 - in[j];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* decomposition (tfhe-rs SignedDecomposer: closest representable, balanced digits)             */
+/* ------------------------------------------------------------------------------------------- */
+void orc_decompose(uint64_t x, uint32_t base_log, uint32_t levels, int64_t* digits) {
+    const u32 rep_bits = base_log * levels;
+    const u32 shift = 64 - rep_bits;
+    /* closest representable: keep the top rep_bits bits, rounding half up */
+    u64 state = (x >> (shift - 1));
+    state = (state + 1) >> 1;
+    state &= (rep_bits == 64) ? ~(u64)0 : (((u64)1 << rep_bits) - 1);
+    const u64 mask = ((u64)1 << base_log) - 1;
+    for (u32 j = levels; j-- > 0;) { /* least significant digit (highest level) first */
+        u64 outp = state & mask;
+        state >>= base_log;
+        u64 carry = ((outp - 1) | state) & outp;
+        carry >>= base_log - 1;
+        state += carry;
+        digits[j] = (i64)outp - (i64)(carry << base_log);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* keys and encryption                                                                         */
+/* ------------------------------------------------------------------------------------------- */
+void orc_gen_binary_key(orc_rng* r, uint64_t* key, size_t len) {
+    for (size_t i = 0; i < len; i += 64) {
+        u64 bits = orc_rng_u64(r);
+        for (size_t j = 0; j < 64 && i + j < len; ++j) key[i + j] = (bits >> j) & 1;
+    }
+}
+
+void orc_lwe_encrypt(const uint64_t* sk, size_t dim, uint64_t plaintext, uint32_t noise_log2,
+                     orc_rng* r, uint64_t* ct) {
+    u64 b = plaintext + orc_rng_tuniform(r, noise_log2);
+    for (size_t i = 0; i < dim; ++i) {
+        ct[i] = orc_rng_u64(r);
+        b += ct[i] * sk[i];
+    }
+    ct[dim] = b;
+}
+
+uint64_t orc_lwe_phase(const uint64_t* sk, size_t dim, const uint64_t* ct) {
+    u64 b = ct[dim];
+    for (size_t i = 0; i < dim; ++i) b -= ct[i] * sk[i];
+    return b;
+}
+
+void orc_lwe_trivial(size_t dim, uint64_t plaintext, uint64_t* ct) {
+    memset(ct, 0, sizeof(u64) * dim);
+    ct[dim] = plaintext;
+}
+
+void orc_glwe_encrypt(const orc_ctx* c, const uint64_t* glwe_sk, const uint64_t* pt, orc_rng* r,
+                      uint64_t* ct) {
+    const u32 N = c->prm.poly_size, k = c->prm.glwe_dim;
+    u64* body = ct + (size_t)k * N;
+    u64* tmp = (u64*)malloc(sizeof(u64) * N);
+    i64* s = (i64*)malloc(sizeof(i64) * N);
+    for (u32 j = 0; j < N; ++j) body[j] = (pt ? pt[j] : 0) + orc_rng_tuniform(r, c->prm.glwe_noise_log2);
+    for (u32 i = 0; i < k; ++i) {
+        u64* a = ct + (size_t)i * N;
+        for (u32 j = 0; j < N; ++j) { a[j] = orc_rng_u64(r); s[j] = (i64)glwe_sk[(size_t)i * N + j]; }
+        orc_negacyclic_mul_ntt(c, tmp, s, a);
+        for (u32 j = 0; j < N; ++j) body[j] += tmp[j];
+    }
+    free(tmp); free(s);
+}
+
+void orc_glwe_phase(const orc_ctx* c, const uint64_t* glwe_sk, const uint64_t* ct, uint64_t* phase) {
+    const u32 N = c->prm.poly_size, k = c->prm.glwe_dim;
+    u64* tmp = (u64*)malloc(sizeof(u64) * N);
+    i64* s = (i64*)malloc(sizeof(i64) * N);
+    memcpy(phase, ct + (size_t)k * N, sizeof(u64) * N);
+    for (u32 i = 0; i < k; ++i) {
+        for (u32 j = 0; j < N; ++j) s[j] = (i64)glwe_sk[(size_t)i * N + j];
+        orc_negacyclic_mul_ntt(c, tmp, s, ct + (size_t)i * N);
+        for (u32 j = 0; j < N; ++j) phase[j] -= tmp[j];
+    }
+    free(tmp); free(s);
+}
+
+size_t orc_bsk_len(const orc_params* p) {
+    return (size_t)p->lwe_dim * p->pbs_level * (p->glwe_dim + 1) * (p->glwe_dim + 1) * p->poly_size;
+}
+
+void orc_gen_bsk(const orc_ctx* c, const uint64_t* lwe_sk, const uint64_t* glwe_sk, orc_rng* r,
+                 uint64_t* bsk) {
+    const orc_params* P = &c->prm;
+    const u32 N = P->poly_size, k = P->glwe_dim;
+    const size_t row_len = (size_t)(k + 1) * N;
+    u64* row = bsk;
+    for (u32 i = 0; i < P->lwe_dim; ++i)
+        for (u32 lv = 0; lv < P->pbs_level; ++lv)
+            for (u32 rr = 0; rr <= k; ++rr, row += row_len) {
+                orc_glwe_encrypt(c, glwe_sk, NULL, r, row);
+                /* Z + s_i * G: gadget value on the constant coefficient of polynomial rr */
+                row[(size_t)rr * N] += lwe_sk[i] << (64 - P->pbs_base_log * (lv + 1));
+            }
+}
+
+size_t orc_ksk_len(const orc_params* p) {
+    return (size_t)p->glwe_dim * p->poly_size * p->ks_level * (p->lwe_dim + 1);
+}
+
+void orc_gen_ksk(const orc_ctx* c, const uint64_t* big_sk, const uint64_t* lwe_sk, orc_rng* r,
+                 uint64_t* ksk) {
+    const orc_params* P = &c->prm;
+    const size_t big = (size_t)P->glwe_dim * P->poly_size;
+    u64* ct = ksk;
+    for (size_t i = 0; i < big; ++i)
+        for (u32 lv = 0; lv < P->ks_level; ++lv, ct += P->lwe_dim + 1)
+            orc_lwe_encrypt(lwe_sk, P->lwe_dim, big_sk[i] << (64 - P->ks_base_log * (lv + 1)),
+                            P->lwe_noise_log2, r, ct);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* external product / cmux                                                                     */
+/* ------------------------------------------------------------------------------------------- */
+/* NTT-domain image of one GGSW: hat[level][row][poly][prime][N] (Montgomery form) */
+static void ggsw_to_hat(const orc_ctx* c, const u64* ggsw, u64* hat) {
+    const orc_params* P = &c->prm;
+    const u32 N = P->poly_size, k1 = P->glwe_dim + 1;
+    const size_t polys = (size_t)P->pbs_level * k1 * k1;
+    for (size_t q = 0; q < polys; ++q)
+        torus_poly_to_hat(c, ggsw + q * N, hat + q * 2 * N, hat + q * 2 * N + N);
+}
+
+static void external_product_hat(const orc_ctx* c, const u64* hat, const u64* glwe, u64* out) {
+    const orc_params* P = &c->prm;
+    const u32 N = P->poly_size, k1 = P->glwe_dim + 1, L = P->pbs_level;
+    u64* acc = (u64*)calloc((size_t)k1 * 2 * N, sizeof(u64)); /* [poly][prime][N] */
+    u64* d0 = (u64*)malloc(sizeof(u64) * 2 * N);
+    u64* d1 = d0 + N;
+    i64* digs = (i64*)malloc(sizeof(i64) * L);
+    i64* dpoly = (i64*)malloc(sizeof(i64) * (size_t)L * N);
+    for (u32 rr = 0; rr < k1; ++rr) {
+        for (u32 j = 0; j < N; ++j) {
+            orc_decompose(glwe[(size_t)rr * N + j], P->pbs_base_log, L, digs);
+            for (u32 lv = 0; lv < L; ++lv) dpoly[(size_t)lv * N + j] = digs[lv];
+        }
+        for (u32 lv = 0; lv < L; ++lv) {
+            for (u32 j = 0; j < N; ++j) {
+                d0[j] = reduce_signed(dpoly[(size_t)lv * N + j], c->pr[0].m.p);
+                d1[j] = reduce_signed(dpoly[(size_t)lv * N + j], c->pr[1].m.p);
+            }
+            ntt_fwd(&c->pr[0], d0, N); ntt_fwd(&c->pr[1], d1, N);
+            for (u32 cc = 0; cc < k1; ++cc) {
+                const u64* h = hat + (((size_t)lv * k1 + rr) * k1 + cc) * 2 * N;
+                u64* a0 = acc + (size_t)cc * 2 * N;
+                u64* a1 = a0 + N;
+                const u64 p0 = c->pr[0].m.p, p1 = c->pr[1].m.p;
+                for (u32 j = 0; j < N; ++j) {
+                    u64 t0 = a0[j] + mont_mul(&c->pr[0].m, d0[j], h[j]);
+                    a0[j] = t0 >= p0 ? t0 - p0 : t0;
+                    u64 t1 = a1[j] + mont_mul(&c->pr[1].m, d1[j], h[N + j]);
+                    a1[j] = t1 >= p1 ? t1 - p1 : t1;
+                }
+            }
+        }
+    }
+    for (u32 cc = 0; cc < k1; ++cc) {
+        u64* a0 = acc + (size_t)cc * 2 * N;
+        u64* a1 = a0 + N;
+        ntt_inv(&c->pr[0], a0, N); ntt_inv(&c->pr[1], a1, N);
+        for (u32 j = 0; j < N; ++j) out[(size_t)cc * N + j] = crt_wrap(c, a0[j], a1[j]);
+    }
+    free(acc); free(d0); free(digs); free(dpoly);
+}
+
+void orc_external_product(const orc_ctx* c, const uint64_t* ggsw, const uint64_t* glwe, uint64_t* out) {
+    const orc_params* P = &c->prm;
+    const size_t polys = (size_t)P->pbs_level * (P->glwe_dim + 1) * (P->glwe_dim + 1);
+    u64* hat = (u64*)malloc(sizeof(u64) * polys * 2 * P->poly_size);
+    ggsw_to_hat(c, ggsw, hat);
+    external_product_hat(c, hat, glwe, out);
+    free(hat);
+}
+
+static void cmux_rotate_hat(const orc_ctx* c, const u64* hat, u32 rot, u64* acc) {
+    const u32 N = c->prm.poly_size, k1 = c->prm.glwe_dim + 1;
+    u64* diff = (u64*)malloc(sizeof(u64) * (size_t)k1 * N * 2);
+    u64* prod = diff + (size_t)k1 * N;
+    for (u32 q = 0; q < k1; ++q) {
+        orc_monomial_mul(diff + (size_t)q * N, acc + (size_t)q * N, rot, N);
+        for (u32 j = 0; j < N; ++j) diff[(size_t)q * N + j] -= acc[(size_t)q * N + j];
+    }
+    external_product_hat(c, hat, diff, prod);
+    for (size_t j = 0; j < (size_t)k1 * N; ++j) acc[j] += prod[j];
+    free(diff);
+}
+
+void orc_cmux_rotate(const orc_ctx* c, const uint64_t* ggsw, uint32_t rot, uint64_t* acc) {
+    const orc_params* P = &c->prm;
+    const size_t polys = (size_t)P->pbs_level * (P->glwe_dim + 1) * (P->glwe_dim + 1);
+    u64* hat = (u64*)malloc(sizeof(u64) * polys * 2 * P->poly_size);
+    ggsw_to_hat(c, ggsw, hat);
+    cmux_rotate_hat(c, hat, rot, acc);
+    free(hat);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* mod switch, key switch, blind rotation, sample extraction, PBS                              */
+/* ------------------------------------------------------------------------------------------- */
+uint32_t orc_modswitch(uint64_t x, uint32_t log2_2N) {
+    u64 t = x >> (64 - log2_2N - 1);
+    t = (t + 1) >> 1;
+    return (u32)(t & (((u64)1 << log2_2N) - 1));
+}
+
+void orc_keyswitch(const orc_ctx* c, const uint64_t* ksk, const uint64_t* in, uint64_t* out) {
+    const orc_params* P = &c->prm;
+    const size_t big = (size_t)P->glwe_dim * P->poly_size;
+    const u32 n = P->lwe_dim, L = P->ks_level;
+    i64 digs[64];
+    memset(out, 0, sizeof(u64) * n);
+    out[n] = in[big];
+    for (size_t i = 0; i < big; ++i) {
+        orc_decompose(in[i], P->ks_base_log, L, digs);
+        for (u32 lv = 0; lv < L; ++lv) {
+            const u64 d = (u64)digs[lv];
+            if (!d) continue;
+            const u64* row = ksk + (i * L + lv) * (n + 1);
+            for (u32 j = 0; j <= n; ++j) out[j] -= d * row[j];
+        }
+    }
+}
+
+void orc_sample_extract(const orc_ctx* c, const uint64_t* glwe, uint64_t* lwe_big) {
+    const u32 N = c->prm.poly_size, k = c->prm.glwe_dim;
+    for (u32 i = 0; i < k; ++i) {
+        const u64* a = glwe + (size_t)i * N;
+        u64* o = lwe_big + (size_t)i * N;
+        o[0] = a[0];
+        for (u32 j = 1; j < N; ++j) o[j] = (u64)0 - a[N - j];
+    }
+    lwe_big[(size_t)k * N] = glwe[(size_t)k * N];
+}
+
+/* prepared (NTT-domain) bootstrapping key */
+struct orc_prepared_bsk {
+    u64* hat;        /* [i][level][row][poly][prime][N] */
+    size_t per_ggsw; /* words per GGSW image */
+};
+
+orc_prepared_bsk* orc_bsk_prepare(const orc_ctx* c, const uint64_t* bsk) {
+    const orc_params* P = &c->prm;
+    const size_t polys = (size_t)P->pbs_level * (P->glwe_dim + 1) * (P->glwe_dim + 1);
+    orc_prepared_bsk* b = (orc_prepared_bsk*)malloc(sizeof *b);
+    b->per_ggsw = polys * 2 * P->poly_size;
+    b->hat = (u64*)malloc(sizeof(u64) * b->per_ggsw * P->lwe_dim);
+    for (u32 i = 0; i < P->lwe_dim; ++i)
+        ggsw_to_hat(c, bsk + (size_t)i * polys * P->poly_size, b->hat + (size_t)i * b->per_ggsw);
+    return b;
+}
+
+void orc_bsk_prepared_free(orc_prepared_bsk* b) {
+    if (!b) return;
+    free(b->hat);
+    free(b);
+}
+
+static void blind_rotate_hat(const orc_ctx* c, const orc_prepared_bsk* pb, const u64* lwe_small,
+                             const u64* lut, u64* acc) {
+    const orc_params* P = &c->prm;
+    const u32 N = P->poly_size, k1 = P->glwe_dim + 1, n = P->lwe_dim;
+    const u32 log2n = c->logN + 1;
+    const u32 bt = orc_modswitch(lwe_small[n], log2n);
+    /* acc = X^{-b~} * lut */
+    for (u32 q = 0; q < k1; ++q)
+        orc_monomial_mul(acc + (size_t)q * N, lut + (size_t)q * N, (2 * N - bt) % (2 * N), N);
+    for (u32 i = 0; i < n; ++i) {
+        const u32 at = orc_modswitch(lwe_small[i], log2n);
+        if (at == 0) continue; /* X^0 - 1 = 0: the external product of zero is zero */
+        cmux_rotate_hat(c, pb->hat + (size_t)i * pb->per_ggsw, at, acc);
+    }
+}
+
+void orc_blind_rotate(const orc_ctx* c, const uint64_t* bsk, const uint64_t* lwe_small,
+                      const uint64_t* lut, uint64_t* acc_out) {
+    orc_prepared_bsk* pb = orc_bsk_prepare(c, bsk);
+    blind_rotate_hat(c, pb, lwe_small, lut, acc_out);
+    orc_bsk_prepared_free(pb);
+}
+
+void orc_blind_rotate_prepared(const orc_ctx* c, const orc_prepared_bsk* pb, const uint64_t* lwe_small,
+                               const uint64_t* lut, uint64_t* acc_out) {
+    blind_rotate_hat(c, pb, lwe_small, lut, acc_out);
+}
+
+void orc_pbs_prepared(const orc_ctx* c, const uint64_t* ksk, const orc_prepared_bsk* pb,
+                      const uint64_t* lwe_big, const uint64_t* lut, uint64_t* out_big) {
+    const orc_params* P = &c->prm;
+    u64* small = (u64*)malloc(sizeof(u64) * (P->lwe_dim + 1));
+    u64* acc = (u64*)malloc(sizeof(u64) * (size_t)(P->glwe_dim + 1) * P->poly_size);
+    orc_keyswitch(c, ksk, lwe_big, small);
+    blind_rotate_hat(c, pb, small, lut, acc);
+    orc_sample_extract(c, acc, out_big);
+    free(small); free(acc);
+}
+
+void orc_pbs(const orc_ctx* c, const uint64_t* ksk, const uint64_t* bsk, const uint64_t* lwe_big,
+             const uint64_t* lut, uint64_t* out_big) {
+    orc_prepared_bsk* pb = orc_bsk_prepare(c, bsk);
+    orc_pbs_prepared(c, ksk, pb, lwe_big, lut, out_big);
+    orc_bsk_prepared_free(pb);
+}
+
+void orc_pbs_batch_prepared(const orc_ctx* c, const uint64_t* ksk, const orc_prepared_bsk* pb,
+                            const uint64_t* in, const uint64_t* luts, const uint32_t* lut_index,
+                            uint64_t* out, size_t count, int nthreads) {
+    const orc_params* P = &c->prm;
+    const size_t big1 = (size_t)P->glwe_dim * P->poly_size + 1;
+    const size_t lut_len = (size_t)(P->glwe_dim + 1) * P->poly_size;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+    for (long i = 0; i < (long)count; ++i)
+        orc_pbs_prepared(c, ksk, pb, in + (size_t)i * big1,
+                         luts + (size_t)(lut_index ? lut_index[i] : 0) * lut_len, out + (size_t)i * big1);
+}
+
+void orc_pbs_batch(const orc_ctx* c, const uint64_t* ksk, const uint64_t* bsk, const uint64_t* in,
+                   const uint64_t* luts, const uint32_t* lut_index, uint64_t* out, size_t count,
+                   int nthreads) {
+    orc_prepared_bsk* pb = orc_bsk_prepare(c, bsk);
+    orc_pbs_batch_prepared(c, ksk, pb, in, luts, lut_index, out, count, nthreads);
+    orc_bsk_prepared_free(pb);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* shortint encoding                                                                           */
+/* ------------------------------------------------------------------------------------------- */
+static u64 delta_of(const orc_ctx* c) {
+    /* one padding bit above message and carry (the pattern of encryption_delta,
+     * ml/extensions/rust/src/encryption.rs:5-22) */
+    return ((u64)1 << 63) / ((u64)c->prm.message_modulus * c->prm.carry_modulus);
+}
+
+uint64_t orc_encode(const orc_ctx* c, uint64_t m) { return m * delta_of(c); }
+
+uint64_t orc_decode(const orc_ctx* c, uint64_t phase) {
+    const u64 delta = delta_of(c);
+    const u64 space = (u64)c->prm.message_modulus * c->prm.carry_modulus;
+    u64 r = (phase + delta / 2) / delta; /* includes the padding bit */
+    return r % space;
+}
+
+void orc_make_lut(const orc_ctx* c, const uint64_t* table, uint64_t* lut) {
+    const u32 N = c->prm.poly_size, k = c->prm.glwe_dim;
+    const u32 space = c->prm.message_modulus * c->prm.carry_modulus;
+    const u32 box = N / space, half = box / 2;
+    const u64 delta = delta_of(c);
+    u64* body = lut + (size_t)k * N;
+    u64* tmp = (u64*)malloc(sizeof(u64) * N);
+    memset(lut, 0, sizeof(u64) * (size_t)k * N);
+    for (u32 i = 0; i < space; ++i)
+        for (u32 j = 0; j < box; ++j) tmp[i * box + j] = table[i] * delta;
+    for (u32 j = 0; j < half; ++j) tmp[j] = (u64)0 - tmp[j];
+    for (u32 j = 0; j < N; ++j) body[j] = tmp[(j + half) % N]; /* rotate left by half a box */
+    free(tmp);
+}

@@ -1,0 +1,161 @@
+"""The CPU oracle against the reference's own fixtures and against its own definitions."""
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle, Params, Rng, load_reference_cpk_fixture, seed_bytes, lib
+
+M64 = (1 << 64) - 1
+SMALL = Params(lwe_dim=24, poly_size=256, lwe_noise_log2=30, glwe_noise_log2=10)
+
+
+def centered(x):
+    return x.astype(np.int64)
+
+
+def test_reference_fixture_parameters(golden_dir):
+    """privateKey.bin carries the numeric parameter set the oracle defaults to
+    (reference: sdk/relayer/src/tfhe.ts:14-19 names it; the blob holds the values)."""
+    blob = open(golden_dir + "/privateKey.bin", "rb").read()
+    u64 = lambda off: int.from_bytes(blob[off:off + 8], "little")
+    p = Params()
+    assert u64(23867) == p.lwe_dim
+    assert u64(23879) == p.glwe_dim
+    assert u64(23891) == p.poly_size
+    assert int.from_bytes(blob[23911:23915], "little") == p.lwe_noise_log2
+    assert int.from_bytes(blob[23927:23931], "little") == p.glwe_noise_log2
+    assert u64(23935) == p.pbs_base_log and u64(23947) == p.pbs_level
+    assert u64(23959) == p.ks_base_log and u64(23971) == p.ks_level
+    assert u64(23983) == p.message_modulus and u64(23995) == p.carry_modulus
+
+
+def test_negacyclic_product_pinned_by_reference_public_key(golden_dir):
+    """Known answer from the reference's key fixtures: body = mask (*) rev(s) + e, |e| <= 2^17.
+    Any error in the sign convention, the wrap or the CRT lift gives a full-range residual."""
+    s, mask, body = load_reference_cpk_fixture(golden_dir)
+    assert set(np.unique(s)) <= {0, 1} and int(s.sum()) == 975
+    orc = Oracle()
+    rev = np.ascontiguousarray(s[::-1])
+    for mul in (orc.mul_ntt, orc.mul_schoolbook):
+        e = centered(body - mul(rev, mask))
+        assert np.abs(e).max() <= 1 << 17
+        assert 1000 < np.abs(e).mean() < (1 << 17)
+    # and the wrong conventions really are detected
+    bad = centered(body - orc.mul_ntt(s, mask))
+    assert np.abs(bad).max() > 1 << 60
+
+
+@pytest.mark.parametrize("N", [256, 2048])
+def test_ntt_route_equals_schoolbook(N):
+    orc = Oracle(Params(poly_size=N))
+    r = Rng(seed_bytes(3))
+    b = r.u64s(N)
+    small = np.array([(r.u64() % (1 << 23)) - (1 << 22) for _ in range(N)], dtype=np.int64)
+    assert np.array_equal(orc.mul_ntt(small, b), orc.mul_schoolbook(small, b))
+    # extreme magnitudes: the integer result reaches the 2^96 bound the CRT modulus must cover
+    small[:] = 1 << 22
+    b[:] = 1 << 63
+    assert np.array_equal(orc.mul_ntt(small, b), orc.mul_schoolbook(small, b))
+    small[::2] = -(1 << 22)
+    b[:] = (1 << 63) - 1
+    assert np.array_equal(orc.mul_ntt(small, b), orc.mul_schoolbook(small, b))
+
+
+def test_decompose_matches_definition():
+    r = Rng(seed_bytes(5))
+    for base_log, levels in ((23, 1), (4, 4), (8, 3)):
+        for _ in range(2000):
+            x = r.u64()
+            d = Oracle.decompose(x, base_log, levels)
+            B = 1 << base_log
+            assert all(-B // 2 <= int(v) <= B // 2 for v in d)
+            rec = sum(int(v) << (64 - base_log * (j + 1)) for j, v in enumerate(d)) & M64
+            err = (x - rec) & M64
+            err = err - (1 << 64) if err >= 1 << 63 else err
+            assert abs(err) <= 1 << (64 - base_log * levels - 1)
+    # the tie case keeps +B/2 (tfhe-rs balanced rule), it does not wrap to -B/2
+    assert int(Oracle.decompose(1 << 63, 23, 1)[0]) == 1 << 22
+    assert int(Oracle.decompose((1 << 63) + (1 << 41), 23, 1)[0]) == -(1 << 22) + 1
+
+
+def test_lwe_and_glwe_round_trip():
+    orc = Oracle(SMALL)
+    lwe_sk, glwe_sk, _, _ = orc.gen_keys(seed_bytes(1))
+    r = Rng(seed_bytes(2))
+    for m in range(16):
+        ct = orc.encrypt_block(glwe_sk, m, r)
+        assert orc.decrypt_block(glwe_sk, ct) == m
+    pt = np.array([orc.encode(i % 16) for i in range(orc.N)], dtype=np.uint64)
+    ct = orc.glwe_encrypt(glwe_sk, pt, r)
+    ph = orc.glwe_phase(glwe_sk, ct)
+    assert np.abs(centered(ph - pt)).max() <= 1 << SMALL.glwe_noise_log2
+
+
+def test_external_product_and_cmux():
+    orc = Oracle(SMALL)
+    lwe_sk, glwe_sk, bsk, _ = orc.gen_keys(seed_bytes(7))
+    r = Rng(seed_bytes(8))
+    pt = np.array([orc.encode(i % 16) for i in range(orc.N)], dtype=np.uint64)
+    glwe = orc.glwe_encrypt(glwe_sk, pt, r)
+    W = orc.ggsw_words()
+    for i in range(6):
+        ggsw = bsk[i * W:(i + 1) * W]
+        out = orc.external_product(ggsw, glwe)
+        ph = orc.glwe_phase(glwe_sk, out)
+        want = pt * lwe_sk[i]
+        assert np.abs(centered(ph - want)).max() < 1 << 52
+        rot = 37 + i
+        acc = orc.cmux_rotate(ggsw, rot, glwe)
+        ph = orc.glwe_phase(glwe_sk, acc)
+        want = orc.monomial_mul(pt, rot) if lwe_sk[i] else pt
+        assert np.abs(centered(ph - want)).max() < 1 << 53
+
+
+def test_keyswitch_and_pbs_small_params():
+    orc = Oracle(SMALL)
+    lwe_sk, glwe_sk, bsk, ksk = orc.gen_keys(seed_bytes(9))
+    pb = orc.prepare_bsk(bsk)
+    r = Rng(seed_bytes(10))
+    ident = orc.make_lut(lambda x: x)
+    sq = orc.make_lut(lambda x: (x * x + 1) % 16)
+    for m in range(16):
+        ct = orc.encrypt_block(glwe_sk, m, r)
+        small = orc.keyswitch(ksk, ct)
+        assert orc.decode(orc.lwe_phase(lwe_sk, small)) == m
+        assert orc.decrypt_block(glwe_sk, orc.pbs(ksk, pb, ct, ident)) == m
+        assert orc.decrypt_block(glwe_sk, orc.pbs(ksk, pb, ct, sq)) == (m * m + 1) % 16
+    cts = np.stack([orc.encrypt_block(glwe_sk, m, r) for m in range(8)])
+    luts = np.stack([ident, sq])
+    idx = np.array([0, 1] * 4, dtype=np.uint32)
+    out = orc.pbs_batch(ksk, pb, cts, luts, idx, nthreads=2)
+    for m in range(8):
+        want = m if m % 2 == 0 else (m * m + 1) % 16
+        assert orc.decrypt_block(glwe_sk, out[m]) == want
+        assert np.array_equal(out[m], orc.pbs(ksk, pb, cts[m], luts[idx[m]]))
+
+
+def test_ntt_definition_is_the_transform_the_product_uses():
+    """out = INTT(NTT(a) . NTT(b)) with the O(N^2) definition equals the negacyclic product mod p."""
+    N, p = 64, 7681  # 7681 = 60*128 + 1
+    L = lib()
+    psi = next(c for c in (L.orc_powmod(g, (p - 1) // (2 * N), p) for g in range(2, 50))
+               if L.orc_powmod(c, N, p) == p - 1)
+    r = Rng(seed_bytes(11))
+    a = r.u64s(N) % p
+    b = r.u64s(N) % p
+    A, B = Oracle.ntt_definition(p, psi, a), Oracle.ntt_definition(p, psi, b)
+    Cc = (A.astype(object) * B.astype(object)) % p
+    want = np.zeros(N, dtype=object)
+    for i in range(N):
+        for j in range(N):
+            k = i + j
+            t = int(a[i]) * int(b[j])
+            if k < N:
+                want[k] += t
+            else:
+                want[k - N] -= t
+    want %= p
+    # inverse by definition: a_n = N^-1 sum_j C_j psi^-(2j+1)n
+    ninv = pow(N, p - 2, p)
+    psi_inv = pow(int(psi), p - 2, p)
+    got = [(ninv * sum(int(Cc[j]) * pow(psi_inv, (2 * j + 1) * n, p) for j in range(N))) % p for n in range(N)]
+    assert got == list(want)
