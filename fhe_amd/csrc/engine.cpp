@@ -1,0 +1,164 @@
+#include "engine.h"
+
+#include <stdexcept>
+#include <vector>
+
+#include "tables.h"
+
+namespace lfhe {
+
+void hip_check(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HC(x) hip_check((x), #x)
+
+Engine::Engine(int device, const EngineParams& p) : device_(device), prm_(p) {
+    if (p.poly_size != (uint32_t)N || p.glwe_dim != 1 || p.pbs_level != 1 || p.pbs_base_log != 23)
+        throw std::runtime_error(
+            "unsupported parameters: the kernels are built for N=2048, k=1, one PBS level of base 2^23");
+    if (p.ks_level < 1 || p.ks_level > 4 || p.ks_base_log < 1 || p.ks_base_log > 7 ||
+        p.ks_base_log * p.ks_level > 32)
+        throw std::runtime_error("unsupported key-switch decomposition");
+    if (p.lwe_dim < 1 || p.lwe_dim > 4096) throw std::runtime_error("unsupported LWE dimension");
+    int ndev = 0;
+    HC(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) throw std::runtime_error("no HIP device: the HIP path is the only path");
+    if (device < 0 || device >= ndev) throw std::runtime_error("device index out of range");
+    HC(hipSetDevice(device_));
+    HC(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+
+    HostTables H;
+    build_host_tables(H);
+    HC(hipMalloc(&d_tw_, sizeof(double) * 4 * N));
+    for (int r = 0; r < 2; ++r) {
+        HC(hipMemcpy(d_tw_ + (2 * r) * N, H.tw_fwd[r].data(), sizeof(double) * N, hipMemcpyHostToDevice));
+        HC(hipMemcpy(d_tw_ + (2 * r + 1) * N, H.tw_inv[r].data(), sizeof(double) * N, hipMemcpyHostToDevice));
+        T_.tw_fwd[r] = d_tw_ + (2 * r) * N;
+        T_.tw_inv[r] = d_tw_ + (2 * r + 1) * N;
+        T_.pr[r].p = (double)H.p[r];
+        T_.pr[r].pinv = 1.0 / (double)H.p[r];
+        T_.two32[r] = H.two32[r];
+        T_.ninv[r] = H.ninv[r];
+    }
+    T_.p0inv_mod_p1 = H.p0inv_mod_p1;
+}
+
+Engine::~Engine() {
+    (void)hipSetDevice(device_);
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    if (own_keys_) { (void)hipFree(d_bsk_); (void)hipFree(d_ksk_); }
+    (void)hipFree(d_tw_);
+    (void)hipFree(d_small_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void Engine::sync() {
+    HC(hipSetDevice(device_));
+    HC(hipStreamSynchronize(stream_));
+}
+
+void Engine::load_bsk(const u64* host_bsk) {
+    HC(hipSetDevice(device_));
+    if (!own_keys_ || !d_bsk_) {
+        if (d_bsk_ && !own_keys_) throw std::runtime_error("keys are attached, not owned");
+        HC(hipMalloc(&d_bsk_, bsk_dev_bytes()));
+        own_keys_ = true;
+    }
+    // upload and transform in slabs of 64 GGSWs to bound the staging buffer
+    const size_t slab = 64;
+    u64* d_raw = nullptr;
+    HC(hipMalloc(&d_raw, slab * 4 * N * sizeof(u64)));
+    for (size_t i0 = 0; i0 < prm_.lwe_dim; i0 += slab) {
+        const size_t cnt = (prm_.lwe_dim - i0) < slab ? (prm_.lwe_dim - i0) : slab;
+        HC(hipMemcpyAsync(d_raw, host_bsk + i0 * 4 * N, cnt * 4 * N * sizeof(u64), hipMemcpyHostToDevice, stream_));
+        launch_ntt_forward(T_, d_raw, d_bsk_ + i0 * BSK_ROW, cnt * 4, 1, stream_);
+        HC(hipGetLastError());
+        HC(hipStreamSynchronize(stream_));
+    }
+    HC(hipFree(d_raw));
+}
+
+void Engine::load_ksk(const u64* host_ksk) {
+    HC(hipSetDevice(device_));
+    if (!d_ksk_) {
+        if (d_bsk_ && !own_keys_) throw std::runtime_error("keys are attached, not owned");
+        HC(hipMalloc(&d_ksk_, ksk_dev_bytes()));
+        own_keys_ = true;
+    }
+    HC(hipMemcpyAsync(d_ksk_, host_ksk, ksk_words() * sizeof(u64), hipMemcpyHostToDevice, stream_));
+    launch_ksk_colsum(d_ksk_, N * (int)prm_.ks_level, (int)prm_.lwe_dim + 1, 1 << (prm_.ks_base_log - 1),
+                      d_ksk_ + ksk_words(), stream_);
+    HC(hipGetLastError());
+    HC(hipStreamSynchronize(stream_));
+}
+
+void Engine::attach_device_keys(double* bsk_dev, u64* ksk_dev_with_colsum) {
+    if (own_keys_) {
+        (void)hipFree(d_bsk_);
+        (void)hipFree(d_ksk_);
+        own_keys_ = false;
+    }
+    d_bsk_ = bsk_dev;
+    d_ksk_ = ksk_dev_with_colsum;
+}
+
+u64* Engine::small_scratch(size_t count) {
+    if (count > small_cap_) {
+        HC(hipSetDevice(device_));
+        HC(hipStreamSynchronize(stream_));
+        (void)hipFree(d_small_);
+        d_small_ = nullptr;
+        HC(hipMalloc(&d_small_, count * (prm_.lwe_dim + 1) * sizeof(u64)));
+        small_cap_ = count;
+    }
+    return d_small_;
+}
+
+void Engine::keyswitch(const u64* lwe_in, u64* lwe_small_out, size_t count) {
+    if (!d_ksk_) throw std::runtime_error("no key-switching key loaded");
+    if (!count) return;
+    HC(hipSetDevice(device_));
+    launch_keyswitch(d_ksk_, d_ksk_ + ksk_words(), lwe_in, lwe_small_out, count, N, (int)prm_.lwe_dim,
+                     (int)prm_.ks_base_log, (int)prm_.ks_level, stream_);
+    HC(hipGetLastError());
+}
+
+void Engine::blind_rotate(const u64* lwe_small, const u64* luts, const u32* lut_index, u64* glwe_out, u64* lwe_out,
+                          size_t count) {
+    if (!d_bsk_) throw std::runtime_error("no bootstrapping key loaded");
+    if (!count) return;
+    HC(hipSetDevice(device_));
+    launch_blind_rotate(T_, d_bsk_, lwe_small, (int)prm_.lwe_dim, luts, lut_index, glwe_out, lwe_out, count, stream_);
+    HC(hipGetLastError());
+}
+
+void Engine::pbs_batch(const u64* lwe_in, const u64* luts, const u32* lut_index, u64* lwe_out, size_t count) {
+    if (!count) return;
+    u64* small = small_scratch(count);
+    keyswitch(lwe_in, small, count);
+    blind_rotate(small, luts, lut_index, nullptr, lwe_out, count);
+}
+
+void Engine::external_product(const u32* ggsw_index, const u64* glwe, u64* out, size_t count) {
+    if (!d_bsk_) throw std::runtime_error("no bootstrapping key loaded");
+    if (!count) return;
+    HC(hipSetDevice(device_));
+    launch_external_product(T_, d_bsk_, ggsw_index, glwe, out, count, stream_);
+    HC(hipGetLastError());
+}
+
+void Engine::ntt_forward(const u64* polys, double* out, size_t count) {
+    if (!count) return;
+    HC(hipSetDevice(device_));
+    launch_ntt_forward(T_, polys, out, count, 0, stream_);
+    HC(hipGetLastError());
+}
+
+void Engine::ntt_inverse(const double* in, u64* out, size_t count) {
+    if (!count) return;
+    HC(hipSetDevice(device_));
+    launch_ntt_inverse(T_, in, out, count, stream_);
+    HC(hipGetLastError());
+}
+
+}  // namespace lfhe

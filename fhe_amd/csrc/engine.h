@@ -1,0 +1,93 @@
+// Device-side engine: transform tables, key material in HBM, kernel launchers and the batched
+// bootstrap pipeline (key switch -> modulus switch + blind rotation + sample extraction).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "pbs_phases.h"
+
+namespace lfhe {
+
+struct EngineParams {
+    uint32_t lwe_dim = 918;
+    uint32_t glwe_dim = 1;
+    uint32_t poly_size = 2048;
+    uint32_t pbs_base_log = 23, pbs_level = 1;
+    uint32_t ks_base_log = 4, ks_level = 4;
+    uint32_t message_modulus = 4, carry_modulus = 4;
+    uint32_t lwe_noise_log2 = 45, glwe_noise_log2 = 17;
+};
+
+// kernel launchers (kernels.hip)
+void launch_ntt_forward(const Tables& T, const u64* in, double* out, size_t polys, int mode, hipStream_t st);
+void launch_ntt_inverse(const Tables& T, const double* in, u64* out, size_t polys, hipStream_t st);
+void launch_external_product(const Tables& T, const double* bsk, const u32* idx, const u64* glwe, u64* out,
+                             size_t count, hipStream_t st);
+void launch_blind_rotate(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
+                         const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count, hipStream_t st);
+void launch_ksk_colsum(const u64* ksk, int rows, int cols, int half_base, u64* colsum, hipStream_t st);
+void launch_keyswitch(const u64* ksk, const u64* colsum, const u64* in, u64* out, size_t count, int big, int n,
+                      int base_log, int levels, hipStream_t st);
+void launch_lwe_linear(const u64* a, const u64* b, u64* out, size_t count, int dim1, u64 ca, u64 cb, u64 add_body,
+                       hipStream_t st);
+
+class Engine {
+public:
+    // throws std::runtime_error on unsupported parameters or HIP failure
+    Engine(int device, const EngineParams& p);
+    ~Engine();
+    Engine(const Engine&) = delete;
+    Engine& operator=(const Engine&) = delete;
+
+    const EngineParams& params() const { return prm_; }
+    int device() const { return device_; }
+    hipStream_t stream() const { return stream_; }
+    const Tables& tables() const { return T_; }
+    bool has_keys() const { return d_bsk_ && d_ksk_; }
+
+    size_t bsk_raw_words() const { return (size_t)prm_.lwe_dim * 4 * N; }
+    size_t ksk_words() const { return (size_t)N * prm_.ks_level * (prm_.lwe_dim + 1); }
+    size_t bsk_dev_bytes() const { return (size_t)prm_.lwe_dim * BSK_ROW * sizeof(double); }
+    size_t ksk_dev_bytes() const { return (ksk_words() + prm_.lwe_dim + 1) * sizeof(u64); }
+
+    // key material: host coefficient-domain keys in, device images built here
+    void load_bsk(const u64* host_bsk);   // [n][row][poly][N]
+    void load_ksk(const u64* host_ksk);   // [N][level][n+1]
+    // or attach images that already sit in device memory (e.g. received by a broadcast);
+    // the engine does not take ownership
+    void attach_device_keys(double* bsk_dev, u64* ksk_dev_with_colsum);
+    double* bsk_dev() const { return d_bsk_; }
+    u64* ksk_dev() const { return d_ksk_; }   // ksk words followed by the n+1 column sums
+
+    // ---- device-pointer operations, asynchronous on stream()
+    // count bootstraps: lwe_in [count][N+1], luts [nluts][N] body polynomials, lut_index [count] or null
+    void pbs_batch(const u64* lwe_in, const u64* luts, const u32* lut_index, u64* lwe_out, size_t count);
+    void keyswitch(const u64* lwe_in, u64* lwe_small_out, size_t count);
+    void blind_rotate(const u64* lwe_small, const u64* luts, const u32* lut_index, u64* glwe_out, u64* lwe_out,
+                      size_t count);
+    void external_product(const u32* ggsw_index, const u64* glwe, u64* out, size_t count);
+    void ntt_forward(const u64* polys, double* out, size_t count);
+    void ntt_inverse(const double* in, u64* out, size_t count);
+    void sync();
+
+    // scratch owned by the engine (grow-only), for the small-LWE intermediate of pbs_batch
+    u64* small_scratch(size_t count);
+
+private:
+    int device_;
+    EngineParams prm_;
+    hipStream_t stream_ = nullptr;
+    Tables T_{};
+    double* d_tw_ = nullptr;
+    double* d_bsk_ = nullptr;
+    u64* d_ksk_ = nullptr;
+    bool own_keys_ = false;
+    u64* d_small_ = nullptr;
+    size_t small_cap_ = 0;
+};
+
+void hip_check(hipError_t e, const char* what);
+
+}  // namespace lfhe

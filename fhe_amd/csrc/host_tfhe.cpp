@@ -1,0 +1,137 @@
+#include "host_tfhe.h"
+
+#include <cstring>
+#include <thread>
+
+namespace lfhe {
+
+static inline uint32_t rotl32(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+
+void ChaCha::init(const uint8_t seed[32], uint64_t stream) {
+    for (int i = 0; i < 8; ++i)
+        key_[i] = (uint32_t)seed[4 * i] | ((uint32_t)seed[4 * i + 1] << 8) | ((uint32_t)seed[4 * i + 2] << 16) |
+                  ((uint32_t)seed[4 * i + 3] << 24);
+    counter_ = 0;
+    stream_ = stream;
+    pos_ = 16;
+}
+
+void ChaCha::refill() {
+    uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
+    for (int i = 0; i < 8; ++i) s[4 + i] = key_[i];
+    s[12] = (uint32_t)counter_;
+    s[13] = (uint32_t)(counter_ >> 32);
+    s[14] = (uint32_t)stream_;
+    s[15] = (uint32_t)(stream_ >> 32);
+    uint32_t x[16];
+    std::memcpy(x, s, sizeof x);
+    auto qr = [&](int a, int b, int c, int d) {
+        x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 16);
+        x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 12);
+        x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 8);
+        x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 7);
+    };
+    for (int i = 0; i < 10; ++i) {
+        qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15);
+        qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14);
+    }
+    for (int i = 0; i < 16; ++i) buf_[i] = x[i] + s[i];
+    ++counter_;
+    pos_ = 0;
+}
+
+uint64_t ChaCha::next() {
+    if (pos_ >= 16) refill();
+    uint64_t lo = buf_[pos_], hi = buf_[pos_ + 1];
+    pos_ += 2;
+    return lo | (hi << 32);
+}
+
+uint64_t ChaCha::tuniform(uint32_t b) {
+    const uint64_t span = (1ull << (b + 1)) + 1, mask = (1ull << (b + 2)) - 1;
+    for (;;) {
+        uint64_t v = next() & mask;
+        if (v < span) return v - (1ull << b);
+    }
+}
+
+void gen_binary_key(ChaCha& r, uint64_t* key, size_t len) {
+    for (size_t i = 0; i < len; i += 64) {
+        uint64_t bits = r.next();
+        for (size_t j = 0; j < 64 && i + j < len; ++j) key[i + j] = (bits >> j) & 1;
+    }
+}
+
+void lwe_encrypt(const uint64_t* sk, size_t dim, uint64_t plaintext, uint32_t noise_log2, ChaCha& r, uint64_t* ct) {
+    uint64_t b = plaintext + r.tuniform(noise_log2);
+    for (size_t i = 0; i < dim; ++i) {
+        ct[i] = r.next();
+        b += ct[i] & (0 - sk[i]);
+    }
+    ct[dim] = b;
+}
+
+uint64_t lwe_phase(const uint64_t* sk, size_t dim, const uint64_t* ct) {
+    uint64_t b = ct[dim];
+    for (size_t i = 0; i < dim; ++i) b -= ct[i] & (0 - sk[i]);
+    return b;
+}
+
+// body += a (*) s for a binary s: sum of negacyclic rotations of a
+static void add_mask_times_binary_key(const uint64_t* a, const uint64_t* s, uint64_t* body) {
+    for (int i = 0; i < N; ++i) {
+        if (!s[i]) continue;
+        // X^i * a: coefficient j of a lands on j + i, negated past N
+        for (int j = 0; j < N - i; ++j) body[j + i] += a[j];
+        for (int j = N - i; j < N; ++j) body[j + i - N] -= a[j];
+    }
+}
+
+template <class F>
+static void parallel_for(size_t n, int threads, F&& fn) {
+    if (threads < 1) threads = 1;
+    std::vector<std::thread> pool;
+    for (int w = 0; w < threads; ++w)
+        pool.emplace_back([&, w]() {
+            for (size_t i = w; i < n; i += threads) fn(i);
+        });
+    for (auto& th : pool) th.join();
+}
+
+void gen_bsk(const EngineParams& p, const uint64_t* lwe_sk, const uint64_t* glwe_sk, const uint8_t seed[32],
+             uint64_t* bsk, int threads) {
+    const size_t rows = (size_t)p.lwe_dim * 2;  // one level, k + 1 = 2 rows per GGSW
+    parallel_for(rows, threads, [&](size_t row) {
+        ChaCha r(seed, 0x100000000ull + row);  // one stream per GLWE row: order-independent
+        uint64_t* mask = bsk + row * 2 * N;
+        uint64_t* body = mask + N;
+        for (int j = 0; j < N; ++j) mask[j] = r.next();
+        for (int j = 0; j < N; ++j) body[j] = r.tuniform(p.glwe_noise_log2);
+        add_mask_times_binary_key(mask, glwe_sk, body);
+        const size_t i = row >> 1;
+        const int rr = (int)(row & 1);
+        (rr == 0 ? mask : body)[0] += lwe_sk[i] << (64 - p.pbs_base_log);
+    });
+}
+
+void gen_ksk(const EngineParams& p, const uint64_t* glwe_sk, const uint64_t* lwe_sk, const uint8_t seed[32],
+             uint64_t* ksk, int threads) {
+    const size_t n1 = (size_t)p.lwe_dim + 1;
+    parallel_for((size_t)N, threads, [&](size_t i) {
+        ChaCha r(seed, 0x200000000ull + i);
+        for (uint32_t lv = 0; lv < p.ks_level; ++lv)
+            lwe_encrypt(lwe_sk, p.lwe_dim, glwe_sk[i] << (64 - p.ks_base_log * (lv + 1)), p.lwe_noise_log2, r,
+                        ksk + (i * p.ks_level + lv) * n1);
+    });
+}
+
+void make_lut_body(uint32_t space, uint64_t delta, const uint64_t* table, uint64_t* body) {
+    const uint32_t box = N / space, half = box / 2;
+    std::vector<uint64_t> tmp(N);
+    for (uint32_t i = 0; i < space; ++i)
+        for (uint32_t j = 0; j < box; ++j) tmp[i * box + j] = table[i] * delta;
+    for (uint32_t j = 0; j < half; ++j) tmp[j] = 0 - tmp[j];
+    for (uint32_t j = 0; j < (uint32_t)N; ++j) body[j] = tmp[(j + half) % N];
+}
+
+}  // namespace lfhe

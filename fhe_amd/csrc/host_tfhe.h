@@ -1,0 +1,46 @@
+// Host-side TFHE pieces that are not on the throughput path: the deterministic generator, key
+// generation, LWE encryption / decryption of radix blocks, accumulator (LUT) construction.
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+#include "engine.h"
+
+namespace lfhe {
+
+// ChaCha20 keystream generator (RFC 8439 block function, 64-bit block counter, 64-bit stream id)
+class ChaCha {
+public:
+    ChaCha() = default;
+    ChaCha(const uint8_t seed[32], uint64_t stream) { init(seed, stream); }
+    void init(const uint8_t seed[32], uint64_t stream);
+    uint64_t next();
+    // uniform integer in [-2^b, 2^b] as a torus element
+    uint64_t tuniform(uint32_t b);
+
+private:
+    void refill();
+    uint32_t key_[8] = {0};
+    uint64_t counter_ = 0, stream_ = 0;
+    uint32_t buf_[16] = {0};
+    uint32_t pos_ = 16;
+};
+
+void gen_binary_key(ChaCha& r, uint64_t* key, size_t len);
+// b = <a, s> + plaintext + e
+void lwe_encrypt(const uint64_t* sk, size_t dim, uint64_t plaintext, uint32_t noise_log2, ChaCha& r, uint64_t* ct);
+uint64_t lwe_phase(const uint64_t* sk, size_t dim, const uint64_t* ct);
+
+// bootstrapping key bsk[n][row][poly][N] (GGSW(s_i) = Z + s_i G, one level of base 2^base_log) and
+// key-switching key ksk[N][level][n+1]; `threads` host threads
+void gen_bsk(const EngineParams& p, const uint64_t* lwe_sk, const uint64_t* glwe_sk, const uint8_t seed[32],
+             uint64_t* bsk, int threads);
+void gen_ksk(const EngineParams& p, const uint64_t* glwe_sk, const uint64_t* lwe_sk, const uint8_t seed[32],
+             uint64_t* ksk, int threads);
+
+// body polynomial of the accumulator of f given as a table over [0, space): box-encoded, rotated
+// left by half a box with the wrapped part negated
+void make_lut_body(uint32_t space, uint64_t delta, const uint64_t* table, uint64_t* body /* [N] */);
+
+}  // namespace lfhe

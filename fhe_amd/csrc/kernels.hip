@@ -1,0 +1,336 @@
+// HIP kernels of the bootstrap path for gfx950 (MI355X): bootstrapping-key preparation (forward
+// negacyclic NTT), inverse NTT, GGSW external product, blind rotation with fused modulus switch
+// and sample extraction, LWE key switch, and the small linear LWE kernels the radix layer needs.
+//
+// One 256-thread workgroup owns one ciphertext; its accumulator lives in registers, its
+// decomposed polynomials go through four register passes with LDS exchanges in between
+// (pbs_device.h / pbs_phases.h), and the NTT-domain key row of the current iteration is streamed
+// from L2/HBM with contiguous 16-byte loads.  Workgroups of different ciphertexts walk the key in
+// near lock-step, so each row is fetched from HBM about once per XCD and served from L2 to the
+// rest.
+#include <hip/hip_runtime.h>
+
+#include <utility>
+
+#include "engine.h"
+#include "pbs_phases.h"
+
+namespace lfhe {
+
+extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
+
+template <int... PH>
+__device__ __forceinline__ void ep_run_seq(EpState& s, double* lds, int t, const Tables& T,
+                                           const double* __restrict__ bsk_i,
+                                           std::integer_sequence<int, PH...>) {
+    ((ep_phase<PH>(s, lds, t, T, bsk_i), __syncthreads()), ...);
+}
+
+__device__ __forceinline__ void ep_run(EpState& s, double* lds, int t, const Tables& T,
+                                       const double* __restrict__ bsk_i) {
+    ep_run_seq(s, lds, t, T, bsk_i, std::make_integer_sequence<int, EP_PHASES>{});
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward transform of torus polynomials, both primes.
+//   mode 0: out[(poly*2 + r)*N + e]  centred residues in transform order (for parity checks)
+//   mode 1: bootstrapping-key layout with N^-1 folded in; poly = i*4 + q
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NT) k_ntt_forward(Tables T, const u64* __restrict__ in,
+                                                    double* __restrict__ out, int mode) {
+    double* buf = lds_dyn;
+    const int t = threadIdx.x;
+    const size_t poly = blockIdx.x;
+    u64 v[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) v[j] = in[poly * N + own1(t, j)];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const Prime P = T.pr[r];
+        const double* __restrict__ tw = T.tw_fwd[r];
+        double x[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) x[j] = torus_to_res(v[j], T.two32[r], P);
+        ct_radix8(x, tw, 1, P);
+        st_o1p12(buf, t, x); __syncthreads(); ld_o2p12(buf, t, x); __syncthreads();
+        ct_radix8(x, tw, base2(t), P);
+        st_o2p23(buf, t, x); __syncthreads(); ld_o3p23(buf, t, x); __syncthreads();
+        ct_radix8(x, tw, base3(t), P);
+        st_o3p34(buf, t, x); __syncthreads(); ld_o4p34(buf, t, x); __syncthreads();
+        ct_radix4x2(x, tw, t, P);
+        if (mode == 0) {
+#pragma unroll
+            for (int j = 0; j < E; ++j) out[(poly * 2 + r) * N + own4(t, j)] = mnorm(x[j], P);
+        } else {
+            const size_t i = poly >> 2;
+            const int q = (int)(poly & 3);
+            double* row = out + i * BSK_ROW;
+#pragma unroll
+            for (int j = 0; j < E; ++j)
+                row[bsk_off(r, q, j >> 1, t) + (j & 1)] = mnorm(mmul(x[j], T.ninv[r], P), P);
+        }
+    }
+}
+
+// inverse transform + CRT lift: in[(poly*2 + r)*N + e] residues in transform order -> torus
+__global__ void __launch_bounds__(NT) k_ntt_inverse(Tables T, const double* __restrict__ in,
+                                                    u64* __restrict__ out) {
+    double* buf = lds_dyn;
+    const int t = threadIdx.x;
+    const size_t poly = blockIdx.x;
+    double y0[E];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const Prime P = T.pr[r];
+        const double* __restrict__ tw = T.tw_inv[r];
+        double x[E];
+#pragma unroll
+        for (int j = 0; j < E; ++j) x[j] = mmul(in[(poly * 2 + r) * N + own4(t, j)], T.ninv[r], P);
+        gs_radix4x2(x, tw, t, P); norm8(x, P);
+        st_o4p34(buf, t, x); __syncthreads(); ld_o3p34(buf, t, x); __syncthreads();
+        gs_radix8(x, tw, base3(t), P); norm8(x, P);
+        st_o3p23(buf, t, x); __syncthreads(); ld_o2p23(buf, t, x); __syncthreads();
+        gs_radix8(x, tw, base2(t), P); norm8(x, P);
+        st_o2p12(buf, t, x); __syncthreads(); ld_o1p12(buf, t, x); __syncthreads();
+        gs_radix8(x, tw, 1, P); norm8(x, P);
+        if (r == 0) {
+#pragma unroll
+            for (int j = 0; j < E; ++j) y0[j] = x[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < E; ++j)
+                out[poly * N + own1(t, j)] = crt_wrap(y0[j], x[j], T.p0inv_mod_p1, T.pr[1]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// out = BSK[ggsw_index[ct]] [.] glwe[ct]    (one workgroup per ciphertext)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NT, 2) k_external_product(Tables T, const double* __restrict__ bsk,
+                                                            const u32* __restrict__ ggsw_index,
+                                                            const u64* __restrict__ glwe,
+                                                            u64* __restrict__ out) {
+    const int t = threadIdx.x;
+    const size_t ct = blockIdx.x;
+    EpState s;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < E; ++j) s.dig[q][j] = decomp23(glwe[(ct * 2 + q) * N + own1(t, j)]);
+    ep_run(s, lds_dyn, t, T, bsk + (size_t)ggsw_index[ct] * BSK_ROW);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < E; ++j) out[(ct * 2 + q) * N + own1(t, j)] = s.out[q][j];
+}
+
+// ------------------------------------------------------------------------------------------------
+// blind rotation: modulus switch of the small ciphertext, acc = X^-b~ * lut, n CMux steps,
+// then either the whole accumulator (glwe_out) or its sample-extracted LWE (lwe_out).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NT, 2) k_blind_rotate(Tables T, const double* __restrict__ bsk,
+                                                        const u64* __restrict__ lwe_small, int n,
+                                                        const u64* __restrict__ luts,
+                                                        const u32* __restrict__ lut_index,
+                                                        u64* __restrict__ glwe_out,
+                                                        u64* __restrict__ lwe_out) {
+    const int t = threadIdx.x;
+    const size_t ct = blockIdx.x;
+    const u64* __restrict__ lwe = lwe_small + ct * (size_t)(n + 1);
+    const u64* __restrict__ lut = luts + (size_t)(lut_index ? lut_index[ct] : 0) * N;
+    u64* pub = reinterpret_cast<u64*>(lds_dyn);
+
+    u64 acc[2][E];
+    {
+        const int bt = (int)modswitch_2n(lwe[n]);
+        const int a = (2 * N - bt) & (2 * N - 1);  // multiply by X^-b~
+        const int ar = a & (N - 1);
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const int e = own1(t, j);
+            int idx = e - ar;
+            bool neg = (a & N) != 0;
+            if (idx < 0) { idx += N; neg = !neg; }
+            const u64 v = lut[idx];
+            acc[0][j] = 0;
+            acc[1][j] = neg ? (u64)0 - v : v;
+        }
+    }
+
+    EpState s;
+    for (int i = 0; i < n; ++i) {
+        const int a = (int)modswitch_2n(lwe[i]);
+        if (a == 0) continue;  // X^0 - 1 = 0: this CMux adds exactly zero
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < E; ++j) pub[q * POLY_STRIDE + own1(t, j)] = acc[q][j];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < E; ++j)
+                s.dig[q][j] = decomp23(rot_minus_self(pub + q * POLY_STRIDE, own1(t, j), a, acc[q][j]));
+        __syncthreads();
+        ep_run(s, lds_dyn, t, T, bsk + (size_t)i * BSK_ROW);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < E; ++j) acc[q][j] += s.out[q][j];
+    }
+
+    if (glwe_out) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < E; ++j) glwe_out[(ct * 2 + q) * N + own1(t, j)] = acc[q][j];
+    }
+    if (lwe_out) {  // sample extraction of coefficient 0
+        u64* o = lwe_out + ct * (size_t)(N + 1);
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const int e = own1(t, j);
+            if (e == 0) { o[0] = acc[0][j]; o[N] = acc[1][j]; }
+            else o[N - e] = (u64)0 - acc[0][j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LWE key switch, big (N) -> small (n):  out = (0,...,0,b) - sum_i sum_lv d[i][lv] * KSK[i][lv].
+// Digits are shifted to u = d + B/2 >= 0 so the inner product is unsigned; the constant
+// (B/2) * sum KSK is precomputed per column (colsum).  One thread per output column (coalesced
+// key reads), KS_CT ciphertexts per workgroup share every key word read.
+// ------------------------------------------------------------------------------------------------
+constexpr int KS_CT = 16;      // ciphertexts per workgroup
+constexpr int KS_CHUNK = 64;   // input coefficients whose digits are staged in LDS at a time
+
+__device__ __forceinline__ u32 ks_digits_packed(u64 x, int base_log, int levels) {
+    // shifted digits u = d + B/2, one per byte, level lv in byte lv (lv = 0 most significant)
+    const int rep = base_log * levels;
+    u64 state = ((x >> (64 - rep - 1)) + 1) >> 1;
+    state &= (1ull << rep) - 1;
+    const u64 mask = (1ull << base_log) - 1;
+    u32 packed = 0;
+    for (int lv = levels - 1; lv >= 0; --lv) {
+        u64 o = state & mask;
+        state >>= base_log;
+        u64 carry = (((o - 1) | state) & o) >> (base_log - 1);
+        state += carry;
+        const int d = (int)o - (int)(carry << base_log);
+        packed |= (u32)(d + (1 << (base_log - 1))) << (8 * lv);
+    }
+    return packed;
+}
+
+__global__ void __launch_bounds__(256) k_ksk_colsum(const u64* __restrict__ ksk, int rows, int cols,
+                                                    int half_base, u64* __restrict__ colsum) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= cols) return;
+    u64 s = 0;
+    for (int r = 0; r < rows; ++r) s += ksk[(size_t)r * cols + col];
+    colsum[col] = s * (u64)half_base;
+}
+
+__global__ void __launch_bounds__(256) k_keyswitch(const u64* __restrict__ ksk,
+                                                   const u64* __restrict__ colsum,
+                                                   const u64* __restrict__ in, u64* __restrict__ out,
+                                                   int count, int big, int n, int base_log, int levels) {
+    __shared__ u32 dig[KS_CT][KS_CHUNK];
+    const int cols = n + 1;
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ct0 = blockIdx.y * KS_CT;
+    u64 acc[KS_CT];
+#pragma unroll
+    for (int c = 0; c < KS_CT; ++c) acc[c] = 0;
+    for (int i0 = 0; i0 < big; i0 += KS_CHUNK) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < KS_CT * KS_CHUNK; k += blockDim.x) {
+            const int c = k / KS_CHUNK, ii = k % KS_CHUNK;
+            const int ct = ct0 + c;
+            u32 pk = 0;
+            if (ct < count && i0 + ii < big) pk = ks_digits_packed(in[(size_t)ct * (big + 1) + i0 + ii], base_log, levels);
+            dig[c][ii] = pk;
+        }
+        __syncthreads();
+        if (col < cols) {
+            const int lim = (big - i0) < KS_CHUNK ? (big - i0) : KS_CHUNK;
+            for (int ii = 0; ii < lim; ++ii) {
+                for (int lv = 0; lv < levels; ++lv) {
+                    const u64 k = ksk[((size_t)(i0 + ii) * levels + lv) * cols + col];
+#pragma unroll
+                    for (int c = 0; c < KS_CT; ++c) {
+                        const u32 u = (dig[c][ii] >> (8 * lv)) & 0xffu;
+                        acc[c] += (u64)u * k;
+                    }
+                }
+            }
+        }
+    }
+    if (col < cols) {
+        const u64 cs = colsum[col];
+#pragma unroll
+        for (int c = 0; c < KS_CT; ++c) {
+            const int ct = ct0 + c;
+            if (ct < count) {
+                const u64 b = (col == n) ? in[(size_t)ct * (big + 1) + big] : 0;
+                out[(size_t)ct * cols + col] = b - acc[c] + cs;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// out = ca * a + cb * b + (add_body on the body word), count ciphertexts of dim1 words each.
+// b may be null.  Everything wraps mod 2^64.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_lwe_linear(const u64* __restrict__ a, const u64* __restrict__ b,
+                                                    u64* __restrict__ out, size_t total, int dim1, u64 ca, u64 cb,
+                                                    u64 add_body) {
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (size_t)gridDim.x * blockDim.x) {
+        u64 v = ca * a[k];
+        if (b) v += cb * b[k];
+        if ((int)(k % (size_t)dim1) == dim1 - 1) v += add_body;
+        out[k] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static constexpr size_t LDS_BYTES = (size_t)LDS_WORDS * sizeof(double);
+
+void launch_ntt_forward(const Tables& T, const u64* in, double* out, size_t polys, int mode, hipStream_t st) {
+    hipLaunchKernelGGL(k_ntt_forward, dim3((unsigned)polys), dim3(NT), POLY_STRIDE * sizeof(double), st, T, in, out, mode);
+}
+void launch_ntt_inverse(const Tables& T, const double* in, u64* out, size_t polys, hipStream_t st) {
+    hipLaunchKernelGGL(k_ntt_inverse, dim3((unsigned)polys), dim3(NT), POLY_STRIDE * sizeof(double), st, T, in, out);
+}
+void launch_external_product(const Tables& T, const double* bsk, const u32* idx, const u64* glwe, u64* out,
+                             size_t count, hipStream_t st) {
+    hipLaunchKernelGGL(k_external_product, dim3((unsigned)count), dim3(NT), LDS_BYTES, st, T, bsk, idx, glwe, out);
+}
+void launch_blind_rotate(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
+                         const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count, hipStream_t st) {
+    hipLaunchKernelGGL(k_blind_rotate, dim3((unsigned)count), dim3(NT), LDS_BYTES, st, T, bsk, lwe_small, n, luts,
+                       lut_index, glwe_out, lwe_out);
+}
+void launch_ksk_colsum(const u64* ksk, int rows, int cols, int half_base, u64* colsum, hipStream_t st) {
+    hipLaunchKernelGGL(k_ksk_colsum, dim3((cols + 255) / 256), dim3(256), 0, st, ksk, rows, cols, half_base, colsum);
+}
+void launch_keyswitch(const u64* ksk, const u64* colsum, const u64* in, u64* out, size_t count, int big, int n,
+                      int base_log, int levels, hipStream_t st) {
+    dim3 grid((n + 1 + 255) / 256, (unsigned)((count + KS_CT - 1) / KS_CT));
+    hipLaunchKernelGGL(k_keyswitch, grid, dim3(256), 0, st, ksk, colsum, in, out, (int)count, big, n, base_log, levels);
+}
+
+void launch_lwe_linear(const u64* a, const u64* b, u64* out, size_t count, int dim1, u64 ca, u64 cb, u64 add_body,
+                       hipStream_t st) {
+    const size_t total = count * (size_t)dim1;
+    unsigned blocks = (unsigned)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_lwe_linear, dim3(blocks), dim3(256), 0, st, a, b, out, total, dim1, ca, cb, add_body);
+}
+
+}  // namespace lfhe

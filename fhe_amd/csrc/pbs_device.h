@@ -1,0 +1,204 @@
+// Per-thread building blocks of the bootstrap kernels (gfx950), written so the same code also
+// compiles for the host: the host build runs the identical index maps and arithmetic thread by
+// thread, which is how the LDS layouts are checked without a GPU.
+//
+// Arithmetic.  The negacyclic transform runs over two primes p0, p1 just under 5*2^47 (both
+// 1 mod 8192, p0*p1 > 2^98.6).  Residues are exact integers carried in f64 registers and kept
+// lazily reduced (|x| < 13 p < 2^53).  A modular product is a Barrett reduction whose quotient
+// estimate comes from the FP64 pipe and whose remainder is recovered exactly with two FMAs:
+//     h = b*w; l = fma(b,w,-h); q = rint(h/p); r = fma(-q,p,h) + l        (b*w = h + l exactly)
+// On gfx950 v_fma_f64 / v_mul_f64 / v_add_f64 issue at the same (half) rate as v_mul_lo_u32 and
+// v_mad_u64_u32, so this 6-instruction product is several times cheaper than a 64-bit Montgomery
+// product (about 11 multiplier instructions plus carries); see csrc/microbench/valu_rates.hip.
+//
+// Work split for one polynomial pair (N = 2048, 256 threads, 8 coefficients per thread and
+// polynomial): four register passes (radix 8, 8, 8, 4) with an LDS exchange between passes.
+//   pass 1 owns e = t + 256 j           (strides 1024, 512, 256)
+//   pass 2 owns e = 256 (t>>5) + (t&31) + 32 j   (strides 128, 64, 32)
+//   pass 3 owns e = 32 (t>>2) + (t&3) + 4 j      (strides 16, 8, 4)
+//   pass 4 owns e = 8 t + j             (strides 2, 1)
+// The forward transform is Cooley-Tukey with the twist merged (natural in, bit-reversed out);
+// the inverse is Gentleman-Sande through the same passes backwards.  Each exchange has its own
+// padding so that both its write and its read are bank-conflict free for 8-byte LDS accesses.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#include <hip/hip_runtime.h>
+#define LFHE_HD __host__ __device__ __forceinline__
+#else
+#define LFHE_HD inline
+#endif
+
+#pragma clang fp contract(off)
+
+namespace lfhe {
+
+typedef uint64_t u64;
+typedef int64_t i64;
+typedef uint32_t u32;
+
+constexpr int N = 2048;
+constexpr int LOGN = 11;
+constexpr int NT = 256;          // threads per ciphertext
+constexpr int E = 8;             // coefficients per thread and polynomial
+constexpr int POLY_STRIDE = 2304;  // padded polynomial in LDS, in 8-byte words
+constexpr int LDS_WORDS = 2 * POLY_STRIDE;
+
+constexpr double P0 = 703687441727489.0;
+constexpr double P1 = 703687441702913.0;
+constexpr u64 P0_U = 703687441727489ull;
+constexpr u64 P1_U = 703687441702913ull;
+
+struct Prime {
+    double p, pinv;
+};
+
+// b * w mod p, b any integer with |b| < 13 p, |w| <= p/2.  Result within (0.5 + 0.08 |b|/p) p.
+LFHE_HD double mmul(double b, double w, const Prime& P) {
+    double h = b * w;
+    double l = __builtin_fma(b, w, -h);
+    double q = __builtin_rint(h * P.pinv);
+    double c = __builtin_fma(-q, P.p, h);
+    return c + l;
+}
+
+// centred representative of x, |x| < 2^53
+LFHE_HD double mnorm(double x, const Prime& P) {
+    return __builtin_fma(-__builtin_rint(x * P.pinv), P.p, x);
+}
+
+// Host-only instrumentation (the phase emulation defines LFHE_TRACK_MAX): largest magnitude any
+// butterfly or product operand reaches, to check the lazy-reduction bound |x| < 2^53.
+#if defined(LFHE_TRACK_MAX) && !defined(__HIP_DEVICE_COMPILE__)
+inline double& track_max_ref() { static double m = 0; return m; }
+inline void track_max(double v) { double a = v < 0 ? -v : v; if (a > track_max_ref()) track_max_ref() = a; }
+#else
+LFHE_HD void track_max(double) {}
+#endif
+
+LFHE_HD void ct_bfly(double& a, double& b, double w, const Prime& P) {
+    track_max(b);
+    double t = mmul(b, w, P);
+    b = a - t;
+    a = a + t;
+    track_max(a); track_max(b);
+}
+
+LFHE_HD void gs_bfly(double& a, double& b, double w, const Prime& P) {
+    double u = a, v = b;
+    a = u + v;
+    track_max(a); track_max(u - v);
+    b = mmul(u - v, w, P);
+}
+
+// ---- element ownership per pass
+LFHE_HD int own1(int t, int j) { return t + 256 * j; }
+LFHE_HD int own2(int t, int j) { return ((t >> 5) << 8) + (t & 31) + 32 * j; }
+LFHE_HD int own3(int t, int j) { return ((t >> 2) << 5) + (t & 3) + 4 * j; }
+LFHE_HD int own4(int t, int j) { return 8 * t + j; }
+// ---- paddings per exchange
+LFHE_HD int pad12(int e) { return e; }
+LFHE_HD int pad23(int e) { return e + 4 * (e >> 5); }
+LFHE_HD int pad34(int e) { return e + (e >> 3); }
+
+// Radix-8 Cooley-Tukey on the 8 registers of one pass.  tw is the bit-reversed table
+// (tw[m + i] = psi^bitrev(m + i)), b the table index of the pass's first stage.
+LFHE_HD void ct_radix8(double (&x)[8], const double* __restrict__ tw, int b, const Prime& P) {
+    const double w1 = tw[b];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ct_bfly(x[j], x[j + 4], w1, P);
+    const double w2a = tw[2 * b], w2b = tw[2 * b + 1];
+    ct_bfly(x[0], x[2], w2a, P); ct_bfly(x[1], x[3], w2a, P);
+    ct_bfly(x[4], x[6], w2b, P); ct_bfly(x[5], x[7], w2b, P);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ct_bfly(x[2 * k], x[2 * k + 1], tw[4 * b + k], P);
+}
+
+// last forward pass: strides 2 and 1 on 8 consecutive coefficients
+LFHE_HD void ct_radix4x2(double (&x)[8], const double* __restrict__ tw, int t, const Prime& P) {
+    const double wa = tw[512 + 2 * t], wb = tw[512 + 2 * t + 1];
+    ct_bfly(x[0], x[2], wa, P); ct_bfly(x[1], x[3], wa, P);
+    ct_bfly(x[4], x[6], wb, P); ct_bfly(x[5], x[7], wb, P);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ct_bfly(x[2 * k], x[2 * k + 1], tw[1024 + 4 * t + k], P);
+}
+
+LFHE_HD void gs_radix4x2(double (&x)[8], const double* __restrict__ tw, int t, const Prime& P) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gs_bfly(x[2 * k], x[2 * k + 1], tw[1024 + 4 * t + k], P);
+    const double wa = tw[512 + 2 * t], wb = tw[512 + 2 * t + 1];
+    gs_bfly(x[0], x[2], wa, P); gs_bfly(x[1], x[3], wa, P);
+    gs_bfly(x[4], x[6], wb, P); gs_bfly(x[5], x[7], wb, P);
+}
+
+LFHE_HD void gs_radix8(double (&x)[8], const double* __restrict__ tw, int b, const Prime& P) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gs_bfly(x[2 * k], x[2 * k + 1], tw[4 * b + k], P);
+    const double w2a = tw[2 * b], w2b = tw[2 * b + 1];
+    gs_bfly(x[0], x[2], w2a, P); gs_bfly(x[1], x[3], w2a, P);
+    gs_bfly(x[4], x[6], w2b, P); gs_bfly(x[5], x[7], w2b, P);
+    const double w1 = tw[b];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gs_bfly(x[j], x[j + 4], w1, P);
+}
+
+LFHE_HD void norm8(double (&x)[8], const Prime& P) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = mnorm(x[j], P);
+}
+
+// table index of the first stage of each radix-8 pass
+LFHE_HD int base1(int) { return 1; }
+LFHE_HD int base2(int t) { return 8 + (t >> 5); }
+LFHE_HD int base3(int t) { return 64 + (t >> 2); }
+
+// ---- LDS exchange halves.  `buf` is one polynomial's region (POLY_STRIDE words).
+#define LFHE_XCHG(NAME, OWN, PAD)                                                         \
+    LFHE_HD void st_##NAME(double* buf, int t, const double (&x)[8]) {                    \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) buf[PAD(OWN(t, j))] = x[j];         \
+    }                                                                                     \
+    LFHE_HD void ld_##NAME(const double* buf, int t, double (&x)[8]) {                    \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) x[j] = buf[PAD(OWN(t, j))];         \
+    }
+LFHE_XCHG(o1p12, own1, pad12)
+LFHE_XCHG(o2p12, own2, pad12)
+LFHE_XCHG(o2p23, own2, pad23)
+LFHE_XCHG(o3p23, own3, pad23)
+LFHE_XCHG(o3p34, own3, pad34)
+LFHE_XCHG(o4p34, own4, pad34)
+#undef LFHE_XCHG
+
+// ---- conversions
+// exact integer |v| < 2^51 held in f64 -> two's complement 64-bit
+LFHE_HD i64 f64_to_i64(double v) {
+    const double magic = 6755399441055744.0;  // 2^52 + 2^51
+    double s = v + magic;
+    i64 bits;
+    __builtin_memcpy(&bits, &s, 8);
+    return bits - 0x4338000000000000ll;
+}
+
+// signed digit of the one-level base-2^23 decomposition (closest representative; the tie keeps
+// +2^22, matching tfhe-rs SignedDecomposer)
+LFHE_HD int decomp23(u64 v) {
+    u32 hi = (u32)((v + (1ull << 40)) >> 32);
+    u32 u = hi >> 9;
+    return (int)u - (int)((u > (1u << 22)) ? (1u << 23) : 0u);
+}
+
+// torus value (centred) -> residue mod p as an exact f64, |result| <= p/2 (+1 ulp of slack)
+LFHE_HD double torus_to_res(u64 v, double two32_mod_p, const Prime& P) {
+    i64 s = (i64)v;
+    double hi = (double)(int)(s >> 32);          // signed high word
+    double lo = (double)(u32)(u64)s;             // unsigned low word
+    return mnorm(mmul(hi, two32_mod_p, P) + lo, P);
+}
+
+// CRT lift of (y0 mod p0, y1 mod p1), both centred, to the integer in (-P/2, P/2), wrapped to 2^64
+LFHE_HD u64 crt_wrap(double y0, double y1, double p0inv_mod_p1, const Prime& Q1) {
+    double k = mnorm(mmul(y1 - y0, p0inv_mod_p1, Q1), Q1);
+    return (u64)f64_to_i64(y0) + P0_U * (u64)f64_to_i64(k);
+}
+
+}  // namespace lfhe

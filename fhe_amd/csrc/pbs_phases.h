@@ -1,0 +1,135 @@
+// The external product  out_c = sum_j dig_j (*) BSK_i[j][c]  (mod X^N+1, mod 2^64)  for one
+// ciphertext, cut into barrier-delimited phases.  Every phase is a per-thread function; the GPU
+// kernels run phase, __syncthreads(), phase, ...; the host build runs each phase for all 256
+// threads in turn.  Same code, same LDS image.
+#pragma once
+#include "pbs_device.h"
+
+namespace lfhe {
+
+// Everything a kernel needs besides its operands; passed by value as a kernel argument.
+struct Tables {
+    const double* tw_fwd[2];   // [N] psi^bitrev(i), centred, per prime
+    const double* tw_inv[2];   // [N] psi^-bitrev(i), centred
+    Prime pr[2];
+    double two32[2];           // 2^32 mod p, centred
+    double ninv[2];            // N^-1 mod p, centred
+    double p0inv_mod_p1;       // centred
+};
+
+// Bootstrapping key on the device: f64 residues, N^-1 folded in, transform (bit-reversed) order,
+// laid out so that each 16-byte load of the point-wise stage is contiguous across a wavefront:
+//   [i][prime][q = j_in*2 + c_out][chunk c4][thread t][2]   holds position e = 8 t + 2 c4 + h.
+constexpr int BSK_POLY = N;                 // doubles per (i, prime, q)
+constexpr int BSK_ROW = 2 * 4 * BSK_POLY;   // doubles per i
+LFHE_HD int bsk_off(int r, int q, int c4, int t) { return ((r * 4 + q) * 4 + c4) * (NT * 2) + t * 2; }
+
+struct EpState {
+    int dig[2][E];     // in: decomposition digits, pass-1 ownership
+    double x[2][E];    // working residues
+    double y0[2][E];   // prime-0 result, pass-1 ownership
+    u64 out[2][E];     // result, pass-1 ownership
+};
+
+constexpr int EP_PHASES = 24;  // 12 per prime
+
+// phase p of the external product.  `lds` holds two padded polynomials.
+template <int PH>
+LFHE_HD void ep_phase(EpState& s, double* lds, int t, const Tables& T, const double* __restrict__ bsk_i) {
+    constexpr int r = PH / 12;
+    constexpr int ph = PH % 12;
+    const Prime P = T.pr[r];
+    const double* __restrict__ twf = T.tw_fwd[r];
+    const double* __restrict__ twi = T.tw_inv[r];
+    double* b0 = lds;
+    double* b1 = lds + POLY_STRIDE;
+
+    if constexpr (ph == 0) {  // digits -> residues, forward pass 1, publish
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int j = 0; j < E; ++j) s.x[q][j] = (double)s.dig[q][j];
+            ct_radix8(s.x[q], twf, 1, P);
+        }
+        st_o1p12(b0, t, s.x[0]); st_o1p12(b1, t, s.x[1]);
+    } else if constexpr (ph == 1) {
+        ld_o2p12(b0, t, s.x[0]); ld_o2p12(b1, t, s.x[1]);
+        ct_radix8(s.x[0], twf, base2(t), P); ct_radix8(s.x[1], twf, base2(t), P);
+    } else if constexpr (ph == 2) {
+        st_o2p23(b0, t, s.x[0]); st_o2p23(b1, t, s.x[1]);
+    } else if constexpr (ph == 3) {
+        ld_o3p23(b0, t, s.x[0]); ld_o3p23(b1, t, s.x[1]);
+        ct_radix8(s.x[0], twf, base3(t), P); ct_radix8(s.x[1], twf, base3(t), P);
+    } else if constexpr (ph == 4) {
+        st_o3p34(b0, t, s.x[0]); st_o3p34(b1, t, s.x[1]);
+    } else if constexpr (ph == 5) {  // forward pass 4, point-wise with the key row, inverse pass 4
+        ld_o4p34(b0, t, s.x[0]); ld_o4p34(b1, t, s.x[1]);
+        ct_radix4x2(s.x[0], twf, t, P); ct_radix4x2(s.x[1], twf, t, P);
+        double o0[E], o1[E];
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const double* k00 = bsk_i + bsk_off(r, 0, c4, t);
+            const double* k01 = bsk_i + bsk_off(r, 1, c4, t);
+            const double* k10 = bsk_i + bsk_off(r, 2, c4, t);
+            const double* k11 = bsk_i + bsk_off(r, 3, c4, t);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int j = 2 * c4 + h;
+                o0[j] = mmul(s.x[0][j], k00[h], P) + mmul(s.x[1][j], k10[h], P);
+                o1[j] = mmul(s.x[0][j], k01[h], P) + mmul(s.x[1][j], k11[h], P);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < E; ++j) { s.x[0][j] = o0[j]; s.x[1][j] = o1[j]; }
+        gs_radix4x2(s.x[0], twi, t, P); gs_radix4x2(s.x[1], twi, t, P);
+        norm8(s.x[0], P); norm8(s.x[1], P);
+    } else if constexpr (ph == 6) {
+        st_o4p34(b0, t, s.x[0]); st_o4p34(b1, t, s.x[1]);
+    } else if constexpr (ph == 7) {
+        ld_o3p34(b0, t, s.x[0]); ld_o3p34(b1, t, s.x[1]);
+        gs_radix8(s.x[0], twi, base3(t), P); gs_radix8(s.x[1], twi, base3(t), P);
+        norm8(s.x[0], P); norm8(s.x[1], P);
+    } else if constexpr (ph == 8) {
+        st_o3p23(b0, t, s.x[0]); st_o3p23(b1, t, s.x[1]);
+    } else if constexpr (ph == 9) {
+        ld_o2p23(b0, t, s.x[0]); ld_o2p23(b1, t, s.x[1]);
+        gs_radix8(s.x[0], twi, base2(t), P); gs_radix8(s.x[1], twi, base2(t), P);
+        norm8(s.x[0], P); norm8(s.x[1], P);
+    } else if constexpr (ph == 10) {
+        st_o2p12(b0, t, s.x[0]); st_o2p12(b1, t, s.x[1]);
+    } else {  // ph == 11: inverse pass 1, then keep (prime 0) or lift (prime 1)
+        static_assert(ph == 11, "phase out of range");
+        ld_o1p12(b0, t, s.x[0]); ld_o1p12(b1, t, s.x[1]);
+        gs_radix8(s.x[0], twi, 1, P); gs_radix8(s.x[1], twi, 1, P);
+        norm8(s.x[0], P); norm8(s.x[1], P);
+        if constexpr (r == 0) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < E; ++j) s.y0[q][j] = s.x[q][j];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < E; ++j)
+                    s.out[q][j] = crt_wrap(s.y0[q][j], s.x[q][j], T.p0inv_mod_p1, T.pr[1]);
+        }
+    }
+}
+
+// X^a * acc - acc at coefficient e, reading the rotated term from the published copy
+LFHE_HD u64 rot_minus_self(const u64* pub, int e, int a, u64 self) {
+    const int ar = a & (N - 1);
+    int idx = e - ar;
+    bool neg = (a & N) != 0;
+    if (idx < 0) { idx += N; neg = !neg; }
+    u64 v = pub[idx];
+    return (neg ? (u64)0 - v : v) - self;
+}
+
+LFHE_HD u32 modswitch_2n(u64 x) {  // round to Z_{2N}
+    u64 t = x >> (64 - (LOGN + 1) - 1);
+    return (u32)(((t + 1) >> 1) & (2 * N - 1));
+}
+
+}  // namespace lfhe

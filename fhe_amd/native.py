@@ -1,0 +1,323 @@
+"""ctypes binding of liblfhe.so (include/lfhe.h).  The HIP library is the only compute path:
+loading fails loudly when it has not been built, and creating a context fails without a GPU."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblfhe.so")
+
+LFHE_OK = 0
+ERR_NAMES = {-1: "LFHE_ERR_ARG", -2: "LFHE_ERR_STATE", -3: "LFHE_ERR_DEVICE", -4: "LFHE_ERR_SIZE",
+             -5: "LFHE_ERR_UNSUPPORTED", -6: "LFHE_ERR_FORMAT"}
+KEY_CLIENT, KEY_SERVER = 1, 2
+PARAMS_DEFAULT = 1
+
+OPS = {"add": 0, "sub": 1, "mul": 2, "eq": 3, "ne": 4, "ge": 5, "gt": 6, "le": 7, "lt": 8, "min": 9, "max": 10,
+       "and": 11, "or": 12, "xor": 13, "not": 14, "neg": 15, "select": 16, "shl": 17, "shr": 18, "rotl": 19,
+       "rotr": 20, "div": 21, "rem": 22, "cast": 23}
+COMPARISONS = {"eq", "ne", "ge", "gt", "le", "lt"}
+
+
+class LfheError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in (
+        "lwe_dim", "glwe_dim", "poly_size", "pbs_base_log", "pbs_level", "ks_base_log", "ks_level",
+        "message_modulus", "carry_modulus", "lwe_noise_log2", "glwe_noise_log2")]
+
+
+_lib = None
+
+
+def load():
+    """Load liblfhe.so.  Raises if the library was not built (python fhe_amd/build.py)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python fhe_amd/build.py` "
+                          "(there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32
+    pu64, pu32 = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+    sig = {
+        "lfhe_version": (C.c_char_p, []),
+        "lfhe_default_params": (None, [C.POINTER(Params)]),
+        "lfhe_ctx_create": (i32, [C.POINTER(vp), u32, i32, C.c_char_p]),
+        "lfhe_ctx_create_custom": (i32, [C.POINTER(vp), C.POINTER(Params), i32, C.c_char_p]),
+        "lfhe_ctx_destroy": (None, [vp]),
+        "lfhe_last_error": (C.c_char_p, [vp]),
+        "lfhe_get_params": (i32, [vp, C.POINTER(Params)]),
+        "lfhe_health": (i32, [vp, C.c_char_p, pu64]),
+        "lfhe_keygen": (i32, [vp]),
+        "lfhe_keys_export": (i32, [vp, u32, vp, pu64]),
+        "lfhe_keys_import": (i32, [vp, u32, vp, u64]),
+        "lfhe_server_keys_import_raw": (i32, [vp, vp, u64, vp, u64]),
+        "lfhe_client_keys_import_raw": (i32, [vp, vp, vp]),
+        "lfhe_public_key": (i32, [vp, vp, pu64]),
+        "lfhe_device_keys_size": (i32, [vp, pu64, pu64]),
+        "lfhe_device_keys_ptr": (i32, [vp, C.POINTER(vp), C.POINTER(vp)]),
+        "lfhe_device_keys_attach": (i32, [vp, vp, vp]),
+        "lfhe_encrypt": (i32, [vp, C.c_char_p, u32, vp, pu64]),
+        "lfhe_trivial_encrypt": (i32, [vp, C.c_char_p, u32, vp, pu64]),
+        "lfhe_decrypt": (i32, [vp, vp, u64, vp, pu32]),
+        "lfhe_ciphertext_size": (i32, [vp, u32, pu64]),
+        "lfhe_op_from_name": (i32, [C.c_char_p]),
+        "lfhe_evaluate": (i32, [vp, u32, u32, vp, u64, vp, u64, i32, vp, u64, vp, pu64]),
+        "lfhe_evaluate_batch": (i32, [vp, u32, u32, u64, vp, vp, i32, vp, vp]),
+        "lfhe_pbs_count": (i32, [vp, pu64]),
+        "lfhe_make_lut": (i32, [vp, vp, vp]),
+        "lfhe_pbs_batch": (i32, [vp, u64, vp, vp, u32, vp, vp]),
+        "lfhe_pbs_batch_device": (i32, [vp, u64, vp, vp, vp, vp]),
+        "lfhe_sync": (i32, [vp]),
+        "lfhe_pbs_batch_device_timed": (i32, [vp, u64, vp, vp, vp, vp, u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "lfhe_ntt_info": (i32, [vp, pu64, pu64]),
+        "lfhe_ntt_forward": (i32, [vp, u64, vp, vp]),
+        "lfhe_ntt_inverse": (i32, [vp, u64, vp, vp]),
+        "lfhe_external_product": (i32, [vp, u64, vp, vp, vp]),
+        "lfhe_keyswitch": (i32, [vp, u64, vp, vp]),
+        "lfhe_blind_rotate": (i32, [vp, u64, vp, vp, u32, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype, f.argtypes = res, args
+    L._declared = sorted(sig)
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def le32(value: int) -> bytes:
+    return int(value).to_bytes(32, "little", signed=False)
+
+
+class Context:
+    """One GPU, one key set.  Mirrors the engine surface the reference's clients call."""
+
+    N = 2048
+
+    def __init__(self, seed: bytes = bytes(32), device: int = 0, params: Params | None = None):
+        self._L = load()
+        self._h = C.c_void_p()
+        if params is None:
+            rc = self._L.lfhe_ctx_create(C.byref(self._h), PARAMS_DEFAULT, device, seed)
+        else:
+            rc = self._L.lfhe_ctx_create_custom(C.byref(self._h), C.byref(params), device, seed)
+        if rc != LFHE_OK:
+            raise LfheError(rc, "context creation failed (see stderr)")
+        p = Params()
+        self._L.lfhe_get_params(self._h, C.byref(p))
+        self.params = p
+        self.n = p.lwe_dim
+
+    def close(self):
+        if self._h:
+            self._L.lfhe_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def _ck(self, rc: int):
+        if rc != LFHE_OK:
+            raise LfheError(rc, self._L.lfhe_last_error(self._h).decode())
+
+    # ---- keys
+    def keygen(self):
+        self._ck(self._L.lfhe_keygen(self._h))
+
+    def import_server_keys_raw(self, bsk: np.ndarray, ksk: np.ndarray):
+        bsk, ksk = _u64(bsk), _u64(ksk)
+        self._ck(self._L.lfhe_server_keys_import_raw(self._h, _ptr(bsk), bsk.size, _ptr(ksk), ksk.size))
+
+    def import_client_keys_raw(self, lwe_sk: np.ndarray, glwe_sk: np.ndarray):
+        a, b = _u64(lwe_sk), _u64(glwe_sk)
+        assert a.size == self.n and b.size == self.N
+        self._ck(self._L.lfhe_client_keys_import_raw(self._h, _ptr(a), _ptr(b)))
+
+    def export_keys(self, which: int) -> bytes:
+        n = C.c_uint64(0)
+        self._ck(self._L.lfhe_keys_export(self._h, which, None, C.byref(n)))
+        buf = np.zeros(n.value, dtype=np.uint8)
+        self._ck(self._L.lfhe_keys_export(self._h, which, _ptr(buf), C.byref(n)))
+        return buf.tobytes()
+
+    def import_keys(self, which: int, blob: bytes):
+        buf = np.frombuffer(blob, dtype=np.uint8)
+        self._ck(self._L.lfhe_keys_import(self._h, which, _ptr(buf), buf.size))
+
+    def device_keys(self):
+        """(bsk_ptr, bsk_bytes, ksk_ptr, ksk_bytes) of the device key images."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._ck(self._L.lfhe_device_keys_size(self._h, C.byref(a), C.byref(b)))
+        pa, pb = C.c_void_p(), C.c_void_p()
+        self._ck(self._L.lfhe_device_keys_ptr(self._h, C.byref(pa), C.byref(pb)))
+        return pa.value, a.value, pb.value, b.value
+
+    def device_keys_size(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self._ck(self._L.lfhe_device_keys_size(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def attach_device_keys(self, bsk_ptr: int, ksk_ptr: int):
+        self._ck(self._L.lfhe_device_keys_attach(self._h, C.c_void_p(bsk_ptr), C.c_void_p(ksk_ptr)))
+
+    def health(self) -> str:
+        n = C.c_uint64(0)
+        self._ck(self._L.lfhe_health(self._h, None, C.byref(n)))
+        buf = C.create_string_buffer(n.value)
+        self._ck(self._L.lfhe_health(self._h, buf, C.byref(n)))
+        return buf.value.decode()
+
+    # ---- integers
+    def ciphertext_size(self, bit_width: int) -> int:
+        n = C.c_uint64()
+        self._ck(self._L.lfhe_ciphertext_size(self._h, bit_width, C.byref(n)))
+        return n.value
+
+    def encrypt(self, value: int, bit_width: int, trivial: bool = False) -> bytes:
+        n = C.c_uint64(self.ciphertext_size(bit_width))
+        buf = np.zeros(n.value, dtype=np.uint8)
+        fn = self._L.lfhe_trivial_encrypt if trivial else self._L.lfhe_encrypt
+        self._ck(fn(self._h, le32(value % (1 << max(bit_width, 1))), bit_width, _ptr(buf), C.byref(n)))
+        return buf.tobytes()
+
+    def decrypt(self, ct: bytes) -> int:
+        buf = np.frombuffer(ct, dtype=np.uint8)
+        out = np.zeros(32, dtype=np.uint8)
+        w = C.c_uint32()
+        self._ck(self._L.lfhe_decrypt(self._h, _ptr(buf), buf.size, _ptr(out), C.byref(w)))
+        return int.from_bytes(out.tobytes(), "little")
+
+    def evaluate(self, op: str, bit_width: int, lhs: bytes, rhs=None, cond: bytes | None = None) -> bytes:
+        """rhs: ciphertext bytes, or a Python int for a clear right operand."""
+        a = np.frombuffer(lhs, dtype=np.uint8)
+        scalar = isinstance(rhs, int)
+        b = np.frombuffer(le32(rhs % (1 << 256)) if scalar else (rhs or b""), dtype=np.uint8)
+        c = np.frombuffer(cond or b"", dtype=np.uint8)
+        out_w = 1 if op in COMPARISONS else bit_width
+        n = C.c_uint64(self.ciphertext_size(out_w))
+        out = np.zeros(n.value, dtype=np.uint8)
+        self._ck(self._L.lfhe_evaluate(self._h, OPS[op], bit_width, _ptr(a), a.size, _ptr(b) if b.size else None,
+                                       b.size, 1 if scalar else 0, _ptr(c) if c.size else None, c.size, _ptr(out),
+                                       C.byref(n)))
+        return out[: n.value].tobytes()
+
+    def evaluate_batch(self, op: str, bit_width: int, lhs: list, rhs: list | None = None,
+                       cond: list | None = None) -> list:
+        n = len(lhs)
+        scalar = rhs is not None and len(rhs) > 0 and isinstance(rhs[0], int)
+        A = np.frombuffer(b"".join(lhs), dtype=np.uint8)
+        if rhs is None:
+            B = None
+        elif scalar:
+            B = np.frombuffer(b"".join(le32(v % (1 << 256)) for v in rhs), dtype=np.uint8)
+        else:
+            B = np.frombuffer(b"".join(rhs), dtype=np.uint8)
+        Cn = None if cond is None else np.frombuffer(b"".join(cond), dtype=np.uint8)
+        out_w = 1 if op in COMPARISONS else bit_width
+        sz = self.ciphertext_size(out_w)
+        out = np.zeros(n * sz, dtype=np.uint8)
+        self._ck(self._L.lfhe_evaluate_batch(self._h, OPS[op], bit_width, n, _ptr(A), _ptr(B), 1 if scalar else 0,
+                                             _ptr(Cn), _ptr(out)))
+        raw = out.tobytes()
+        return [raw[i * sz:(i + 1) * sz] for i in range(n)]
+
+    def pbs_count(self) -> int:
+        n = C.c_uint64()
+        self._ck(self._L.lfhe_pbs_count(self._h, C.byref(n)))
+        return n.value
+
+    # ---- bootstrap path
+    def make_lut(self, f) -> np.ndarray:
+        space = self.params.message_modulus * self.params.carry_modulus
+        table = np.array([f(i) % (2 * space) for i in range(space)], dtype=np.uint64)
+        body = np.zeros(self.N, dtype=np.uint64)
+        self._ck(self._L.lfhe_make_lut(self._h, _ptr(table), _ptr(body)))
+        return body
+
+    def pbs_batch(self, cts: np.ndarray, lut_bodies: np.ndarray, lut_index=None) -> np.ndarray:
+        cts = _u64(cts).reshape(-1, self.N + 1)
+        luts = _u64(lut_bodies).reshape(-1, self.N)
+        idx = None if lut_index is None else np.ascontiguousarray(lut_index, dtype=np.uint32)
+        out = np.zeros_like(cts)
+        self._ck(self._L.lfhe_pbs_batch(self._h, cts.shape[0], _ptr(cts), _ptr(luts), luts.shape[0], _ptr(idx),
+                                        _ptr(out)))
+        return out
+
+    def pbs_batch_device(self, count: int, d_in: int, d_luts: int, d_idx: int | None, d_out: int):
+        self._ck(self._L.lfhe_pbs_batch_device(self._h, count, C.c_void_p(d_in), C.c_void_p(d_luts),
+                                               C.c_void_p(d_idx) if d_idx else None, C.c_void_p(d_out)))
+
+    def pbs_batch_device_timed(self, count: int, d_in: int, d_luts: int, d_idx: int | None, d_out: int, iters: int):
+        ks, br = C.c_double(), C.c_double()
+        self._ck(self._L.lfhe_pbs_batch_device_timed(self._h, count, C.c_void_p(d_in), C.c_void_p(d_luts),
+                                                     C.c_void_p(d_idx) if d_idx else None, C.c_void_p(d_out), iters,
+                                                     C.byref(ks), C.byref(br)))
+        return ks.value, br.value
+
+    def sync(self):
+        self._ck(self._L.lfhe_sync(self._h))
+
+    # ---- stages
+    def ntt_info(self):
+        p = (C.c_uint64 * 2)()
+        psi = (C.c_uint64 * 2)()
+        self._ck(self._L.lfhe_ntt_info(self._h, p, psi))
+        return [int(p[0]), int(p[1])], [int(psi[0]), int(psi[1])]
+
+    def ntt_forward(self, polys: np.ndarray) -> np.ndarray:
+        polys = _u64(polys).reshape(-1, self.N)
+        out = np.zeros((polys.shape[0], 2, self.N), dtype=np.uint64)
+        self._ck(self._L.lfhe_ntt_forward(self._h, polys.shape[0], _ptr(polys), _ptr(out)))
+        return out
+
+    def ntt_inverse(self, residues: np.ndarray) -> np.ndarray:
+        res = _u64(residues).reshape(-1, 2, self.N)
+        out = np.zeros((res.shape[0], self.N), dtype=np.uint64)
+        self._ck(self._L.lfhe_ntt_inverse(self._h, res.shape[0], _ptr(res), _ptr(out)))
+        return out
+
+    def external_product(self, ggsw_index, glwe: np.ndarray) -> np.ndarray:
+        glwe = _u64(glwe).reshape(-1, 2, self.N)
+        idx = np.ascontiguousarray(ggsw_index, dtype=np.uint32)
+        out = np.zeros_like(glwe)
+        self._ck(self._L.lfhe_external_product(self._h, glwe.shape[0], _ptr(idx), _ptr(glwe), _ptr(out)))
+        return out
+
+    def keyswitch(self, cts: np.ndarray) -> np.ndarray:
+        cts = _u64(cts).reshape(-1, self.N + 1)
+        out = np.zeros((cts.shape[0], self.n + 1), dtype=np.uint64)
+        self._ck(self._L.lfhe_keyswitch(self._h, cts.shape[0], _ptr(cts), _ptr(out)))
+        return out
+
+    def blind_rotate(self, small: np.ndarray, lut_bodies: np.ndarray, lut_index=None) -> np.ndarray:
+        small = _u64(small).reshape(-1, self.n + 1)
+        luts = _u64(lut_bodies).reshape(-1, self.N)
+        idx = None if lut_index is None else np.ascontiguousarray(lut_index, dtype=np.uint32)
+        out = np.zeros((small.shape[0], 2, self.N), dtype=np.uint64)
+        self._ck(self._L.lfhe_blind_rotate(self._h, small.shape[0], _ptr(small), _ptr(luts), luts.shape[0], _ptr(idx),
+                                           _ptr(out)))
+        return out

@@ -1,0 +1,177 @@
+/*
+ * lfhe.h -- C ABI of liblfhe, the MI355X (gfx950) TFHE compute backend.
+ *
+ * This is the boundary a host SDK binds (N-API / FFI / cgo / ctypes).  It replaces the engine the
+ * reference reaches over HTTP on :8448 and through its WASM / native bindings; each entry point
+ * names the reference interface it stands in for.  Plain pointers and sizes only.
+ *
+ * Conventions
+ *  - every function returns an int32_t status: LFHE_OK (0) or a negative LFHE_ERR_* code;
+ *    lfhe_last_error(ctx) gives the text of the last failure on that context;
+ *  - byte outputs use a size query: pass out == NULL to get the required length in *out_len;
+ *    a too-small buffer returns LFHE_ERR_SIZE with the required length in *out_len;
+ *  - a context is bound to one GPU and owns one HIP stream; calls on one context must not overlap,
+ *    distinct contexts are independent;
+ *  - there is no CPU fallback: creating a context without a usable GPU fails.
+ */
+#ifndef LFHE_H
+#define LFHE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LFHE_OK 0
+#define LFHE_ERR_ARG (-1)         /* invalid argument */
+#define LFHE_ERR_STATE (-2)       /* missing keys, wrong call order */
+#define LFHE_ERR_DEVICE (-3)      /* HIP failure / no GPU */
+#define LFHE_ERR_SIZE (-4)        /* output buffer too small */
+#define LFHE_ERR_UNSUPPORTED (-5) /* parameter set / operator not supported */
+#define LFHE_ERR_FORMAT (-6)      /* malformed ciphertext or key blob */
+
+/* parameter set ids */
+#define LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128 1u
+
+typedef struct lfhe_ctx lfhe_ctx;
+
+/* Numeric parameter set.  The default is the set the reference names at
+ * sdk/relayer/src/tfhe.ts:14-19 (values as stored in sdk/relayer/src/test/keys/privateKey.bin). */
+typedef struct {
+    uint32_t lwe_dim;         /* 918  */
+    uint32_t glwe_dim;        /* 1    */
+    uint32_t poly_size;       /* 2048 */
+    uint32_t pbs_base_log;    /* 23   */
+    uint32_t pbs_level;       /* 1    */
+    uint32_t ks_base_log;     /* 4    */
+    uint32_t ks_level;        /* 4    */
+    uint32_t message_modulus; /* 4    */
+    uint32_t carry_modulus;   /* 4    */
+    uint32_t lwe_noise_log2;  /* 45   */
+    uint32_t glwe_noise_log2; /* 17   */
+} lfhe_params;
+
+const char* lfhe_version(void);
+void lfhe_default_params(lfhe_params* p);
+
+/* ---- context ------------------------------------------------------------------------------------
+ * Replaces: engine process start-up (`fhe-server -addr :8448`, e2e/scripts/start-server.sh:17;
+ * local-dev/docker-compose.yml:29).  `seed` drives every random draw of the context. */
+int32_t lfhe_ctx_create(lfhe_ctx** out, uint32_t params_id, int32_t device, const uint8_t seed[32]);
+/* same with explicit numbers (the kernels need N = 2048, k = 1, one PBS level of base 2^23; the
+ * LWE dimension and the key-switch decomposition are free) */
+int32_t lfhe_ctx_create_custom(lfhe_ctx** out, const lfhe_params* p, int32_t device, const uint8_t seed[32]);
+void lfhe_ctx_destroy(lfhe_ctx* ctx);
+const char* lfhe_last_error(const lfhe_ctx* ctx);
+int32_t lfhe_get_params(const lfhe_ctx* ctx, lfhe_params* out);
+/* Replaces: GET /health (e2e/test/fhe.test.ts:31-37).  Writes a NUL-terminated JSON object
+ * {"status":"ok","threshold":false,"parties":1,...}. */
+int32_t lfhe_health(lfhe_ctx* ctx, char* out, uint64_t* out_len);
+
+/* ---- keys ---------------------------------------------------------------------------------------
+ * Replaces: server-side key generation at engine start and GET /publickey
+ * (packages/luxfhejs/src/index.ts:63-72, packages/hardhat-plugin/src/index.ts:80-87);
+ * client-side generateKeys (sdk/relayer/generateKeys.js:20-66). */
+int32_t lfhe_keygen(lfhe_ctx* ctx);
+#define LFHE_KEY_CLIENT 1u /* secret keys */
+#define LFHE_KEY_SERVER 2u /* bootstrapping + key-switching keys (coefficient domain) */
+int32_t lfhe_keys_export(lfhe_ctx* ctx, uint32_t which, uint8_t* out, uint64_t* out_len);
+int32_t lfhe_keys_import(lfhe_ctx* ctx, uint32_t which, const uint8_t* in, uint64_t len);
+/* raw import of server keys: bsk[n][row][poly][N], ksk[N][level][n+1], 64-bit words */
+int32_t lfhe_server_keys_import_raw(lfhe_ctx* ctx, const uint64_t* bsk, uint64_t bsk_words, const uint64_t* ksk,
+                                    uint64_t ksk_words);
+/* raw import of the secret keys: lwe_sk[n], glwe_sk[N], words holding 0 or 1 */
+int32_t lfhe_client_keys_import_raw(lfhe_ctx* ctx, const uint64_t* lwe_sk, const uint64_t* glwe_sk);
+int32_t lfhe_public_key(lfhe_ctx* ctx, uint8_t* out, uint64_t* out_len);
+/* device images of the server keys, for replication to other GPUs (one broadcast per key set, no
+ * per-operation collective): sizes, the pointers owned by this context, and attaching images that
+ * were received into caller-owned device memory */
+int32_t lfhe_device_keys_size(const lfhe_ctx* ctx, uint64_t* bsk_bytes, uint64_t* ksk_bytes);
+int32_t lfhe_device_keys_ptr(lfhe_ctx* ctx, void** bsk_dev, void** ksk_dev);
+int32_t lfhe_device_keys_attach(lfhe_ctx* ctx, void* bsk_dev, void* ksk_dev);
+
+/* ---- encrypt / decrypt --------------------------------------------------------------------------
+ * Replaces: POST /encrypt {value,bitWidth} (packages/luxfhejs/src/index.ts:127-141,
+ * packages/hardhat-plugin/src/index.ts:57-67), TrivialEncrypt
+ * (tests/fhevm-suite/e2e/test/utils.ts:209), POST /decrypt
+ * (packages/hardhat-plugin/src/index.ts:69-78).  Values are little-endian, 32 bytes.
+ * bit_width: 1 (ebool), 8, 16, 32, 64, 128, 160, 256. */
+int32_t lfhe_encrypt(lfhe_ctx* ctx, const uint8_t value_le[32], uint32_t bit_width, uint8_t* out, uint64_t* out_len);
+int32_t lfhe_trivial_encrypt(lfhe_ctx* ctx, const uint8_t value_le[32], uint32_t bit_width, uint8_t* out,
+                             uint64_t* out_len);
+int32_t lfhe_decrypt(lfhe_ctx* ctx, const uint8_t* ct, uint64_t ct_len, uint8_t value_le[32], uint32_t* bit_width);
+int32_t lfhe_ciphertext_size(const lfhe_ctx* ctx, uint32_t bit_width, uint64_t* out_len);
+
+/* ---- operators ----------------------------------------------------------------------------------
+ * Replaces: POST /evaluate {op,left,right,bitWidth} (e2e/test/fhe.test.ts:105-175,
+ * local-dev/demo.ts:57-81) and the executor events FheAdd ... FheIfThenElse
+ * (tests/fhevm-suite/e2e/test/utils.ts:182-214). */
+enum {
+    LFHE_OP_ADD = 0, LFHE_OP_SUB = 1, LFHE_OP_MUL = 2,
+    LFHE_OP_EQ = 3, LFHE_OP_NE = 4, LFHE_OP_GE = 5, LFHE_OP_GT = 6, LFHE_OP_LE = 7, LFHE_OP_LT = 8,
+    LFHE_OP_MIN = 9, LFHE_OP_MAX = 10,
+    LFHE_OP_AND = 11, LFHE_OP_OR = 12, LFHE_OP_XOR = 13,
+    LFHE_OP_NOT = 14, LFHE_OP_NEG = 15,
+    LFHE_OP_SELECT = 16, /* cond ? lhs : rhs */
+    LFHE_OP_SHL = 17, LFHE_OP_SHR = 18, LFHE_OP_ROTL = 19, LFHE_OP_ROTR = 20,
+    LFHE_OP_DIV = 21, LFHE_OP_REM = 22, /* clear divisor only, as in the reference's operator set */
+    LFHE_OP_CAST = 23
+};
+int32_t lfhe_op_from_name(const char* name); /* "add", "sub", "lt", ... ; -1 if unknown */
+
+/* One operation.  rhs may be a ciphertext, or (rhs_is_scalar != 0) a 32-byte little-endian clear
+ * value; cond is only read by LFHE_OP_SELECT; unary operators ignore rhs.  The result width is
+ * bit_width, or 1 (ebool) for comparisons. */
+int32_t lfhe_evaluate(lfhe_ctx* ctx, uint32_t op, uint32_t bit_width, const uint8_t* lhs, uint64_t lhs_len,
+                      const uint8_t* rhs, uint64_t rhs_len, int32_t rhs_is_scalar, const uint8_t* cond,
+                      uint64_t cond_len, uint8_t* out, uint64_t* out_len);
+/* n independent instances of one operation, bootstrapped together layer by layer.  Every instance
+ * has the same widths; ciphertext i of an operand array starts at operand + i * stride where stride
+ * is lfhe_ciphertext_size of its width (cond: width 1); scalars are 32 bytes each. */
+int32_t lfhe_evaluate_batch(lfhe_ctx* ctx, uint32_t op, uint32_t bit_width, uint64_t n, const uint8_t* lhs,
+                            const uint8_t* rhs, int32_t rhs_is_scalar, const uint8_t* cond, uint8_t* out);
+/* cumulative count of programmable bootstraps issued by this context */
+int32_t lfhe_pbs_count(const lfhe_ctx* ctx, uint64_t* out);
+
+/* ---- the bootstrap path itself ------------------------------------------------------------------
+ * Replaces: tfhe-rs keyswitch_programmable_bootstrap + generate_accumulator as the reference calls
+ * them at ml/biometrics/notebooks/main.rs:68-71.  A ciphertext block is an LWE under the big key:
+ * N + 1 = 2049 words.  A LUT is given as its table over [0, message_modulus*carry_modulus). */
+int32_t lfhe_make_lut(lfhe_ctx* ctx, const uint64_t* table, uint64_t* lut_body /* [N] */);
+/* host buffers: count bootstraps, LUT bodies [nluts][N], lut_index [count] or NULL (all LUT 0) */
+int32_t lfhe_pbs_batch(lfhe_ctx* ctx, uint64_t count, const uint64_t* lwe_in, const uint64_t* lut_bodies,
+                       uint32_t nluts, const uint32_t* lut_index, uint64_t* lwe_out);
+/* device buffers, asynchronous on the context's stream; lfhe_sync waits */
+int32_t lfhe_pbs_batch_device(lfhe_ctx* ctx, uint64_t count, const void* d_lwe_in, const void* d_lut_bodies,
+                              const void* d_lut_index, void* d_lwe_out);
+int32_t lfhe_sync(lfhe_ctx* ctx);
+/* the same pipeline timed with HIP events on the context's stream: `iters` back-to-back runs;
+ * returns the average duration of the key-switch kernel and of the blind-rotation kernel (ms) */
+int32_t lfhe_pbs_batch_device_timed(lfhe_ctx* ctx, uint64_t count, const void* d_lwe_in, const void* d_lut_bodies,
+                                    const void* d_lut_index, void* d_lwe_out, uint32_t iters, double* ks_ms,
+                                    double* br_ms);
+
+/* ---- stages of the path, for parity checks (host buffers) ---------------------------------------
+ * Replaces: tfhe-rs keyswitch_lwe_ciphertext, blind_rotate_assign, add_external_product_assign and
+ * the polynomial transform inside them (absent dependency; algorithms as published).  The
+ * transform is an exact negacyclic NTT over two primes; lfhe_ntt_info reports them with the
+ * 2N-th roots so that a checker can evaluate the definition out[j] = sum_i a_i psi^((2j+1) i). */
+int32_t lfhe_ntt_info(const lfhe_ctx* ctx, uint64_t primes[2], uint64_t psi[2]);
+/* polys [count][N] torus words -> residues [count][2][N] in [0,p), natural index j */
+int32_t lfhe_ntt_forward(lfhe_ctx* ctx, uint64_t count, const uint64_t* polys, uint64_t* residues);
+/* residues [count][2][N] of a polynomial with coefficients in (-P/2, P/2) -> its coefficients mod 2^64 */
+int32_t lfhe_ntt_inverse(lfhe_ctx* ctx, uint64_t count, const uint64_t* residues, uint64_t* polys);
+/* out[c] = BSK[ggsw_index[c]] [.] glwe[c]; glwe and out are [count][2][N] */
+int32_t lfhe_external_product(lfhe_ctx* ctx, uint64_t count, const uint32_t* ggsw_index, const uint64_t* glwe,
+                              uint64_t* out);
+/* [count][N+1] -> [count][n+1] */
+int32_t lfhe_keyswitch(lfhe_ctx* ctx, uint64_t count, const uint64_t* lwe_in, uint64_t* lwe_small_out);
+/* [count][n+1] small ciphertexts -> rotated accumulators [count][2][N] */
+int32_t lfhe_blind_rotate(lfhe_ctx* ctx, uint64_t count, const uint64_t* lwe_small, const uint64_t* lut_bodies,
+                          uint32_t nluts, const uint32_t* lut_index, uint64_t* glwe_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,176 @@
+"""HIP path vs CPU oracle through the C ABI, bit for bit (integer work: exact equality).
+
+Ciphertext-level parity is GPU-vs-own-oracle: the reference tree holds no engine and no stored
+ciphertexts for this path, so these bits are unpinned against the reference; what the reference's
+fixtures do pin (the negacyclic product, decrypted operator results) is covered in
+test_oracle_golden.py and the operator tests."""
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle, Params as OParams, Rng, seed_bytes, lib as olib
+
+pytestmark = pytest.mark.gpu
+
+N = 2048
+M64 = (1 << 64) - 1
+
+
+def _mk(n, ks_base_log=4, ks_level=4, seed=1):
+    from fhe_amd.native import Context, Params
+    op = OParams(lwe_dim=n, ks_base_log=ks_base_log, ks_level=ks_level)
+    orc = Oracle(op)
+    keys = orc.gen_keys(seed_bytes(seed))
+    p = Params(**{k: getattr(op, k) for k in op.__dataclass_fields__})
+    ctx = Context(seed=seed_bytes(100 + seed), params=p)
+    ctx.import_server_keys_raw(keys[2], keys[3])
+    ctx.import_client_keys_raw(keys[0], keys[1])
+    return orc, keys, ctx
+
+
+@pytest.fixture(scope="module")
+def small():
+    orc, keys, ctx = _mk(12)
+    yield orc, keys, ctx
+    ctx.close()
+
+
+@pytest.fixture(scope="module")
+def full():
+    orc, keys, ctx = _mk(918, seed=2)
+    yield orc, keys, ctx, orc.prepare_bsk(keys[2])
+    ctx.close()
+
+
+def test_ntt_forward_matches_definition(small):
+    orc, _, ctx = small
+    primes, psis = ctx.ntt_info()
+    r = Rng(seed_bytes(20))
+    polys = np.stack([r.u64s(N), np.full(N, 1 << 63, dtype=np.uint64), np.arange(N, dtype=np.uint64)])
+    polys[2][::3] = M64
+    got = ctx.ntt_forward(polys)
+    for c in range(polys.shape[0]):
+        cent = polys[c].astype(np.int64)
+        for k in range(2):
+            p = primes[k]
+            res = np.array([int(v) % p for v in cent], dtype=np.uint64)
+            want = Oracle.ntt_definition(p, psis[k], res)
+            assert np.array_equal(got[c, k], want), (c, k)
+
+
+def test_ntt_inverse_round_trip_and_product(small):
+    orc, _, ctx = small
+    primes, _ = ctx.ntt_info()
+    r = Rng(seed_bytes(21))
+    a = r.u64s(N)
+    small_poly = np.array([(r.u64() % (1 << 23)) - (1 << 22) for _ in range(N)], dtype=np.int64)
+    # round trip of a polynomial whose centred coefficients are below P/2
+    assert np.array_equal(ctx.ntt_inverse(ctx.ntt_forward(a[None]))[0], a)
+    # exact negacyclic product through the device transforms equals the oracle's product
+    A = ctx.ntt_forward(a[None])[0]
+    S = ctx.ntt_forward(small_poly.astype(np.uint64)[None])[0]
+    prod = np.stack([np.array([int(x) * int(y) % primes[k] for x, y in zip(A[k], S[k])], dtype=np.uint64)
+                     for k in range(2)])
+    assert np.array_equal(ctx.ntt_inverse(prod[None])[0], orc.mul_schoolbook(small_poly, a))
+
+
+def test_external_product_bit_exact(small):
+    orc, keys, ctx = small
+    bsk = keys[2]
+    W = orc.ggsw_words()
+    r = Rng(seed_bytes(22))
+    glwe = np.stack([r.u64s(2 * N) for _ in range(6)])
+    glwe[4][:] = 1 << 63                     # every digit +2^22
+    glwe[5][::2] = (1 << 63) + (1 << 41)     # digits alternate -2^22+1 / random
+    idx = np.array([0, 3, 7, 11, 5, 2], dtype=np.uint32)
+    got = ctx.external_product(idx, glwe)
+    for c in range(len(idx)):
+        want = orc.external_product(bsk[idx[c] * W:(idx[c] + 1) * W], glwe[c])
+        assert np.array_equal(got[c].reshape(-1), want), c
+
+
+@pytest.mark.parametrize("base_log,level", [(4, 4), (3, 3), (7, 2)])
+def test_keyswitch_bit_exact(base_log, level):
+    orc, keys, ctx = _mk(40, base_log, level, seed=3)
+    try:
+        r = Rng(seed_bytes(23))
+        cts = np.stack([r.u64s(N + 1) for _ in range(19)])   # ragged: not a multiple of the tile
+        cts[1][:] = 0
+        cts[2][:] = M64
+        cts[3][:] = (1 << 63) - (1 << 47)                    # decomposition carries ripple to the top
+        got = ctx.keyswitch(cts)
+        for c in range(cts.shape[0]):
+            assert np.array_equal(got[c], orc.keyswitch(keys[3], cts[c])), c
+    finally:
+        ctx.close()
+
+
+def test_blind_rotate_and_pbs_bit_exact_small_n(small):
+    orc, keys, ctx = small
+    lwe_sk, glwe_sk, bsk, ksk = keys
+    pb = orc.prepare_bsk(bsk)
+    r = Rng(seed_bytes(24))
+    f = [lambda x: x, lambda x: (3 * x + 1) % 16, lambda x: 15 - x]
+    luts_o = [orc.make_lut(g) for g in f]
+    luts_g = np.stack([ctx.make_lut(g) for g in f])
+    for lo, lg in zip(luts_o, luts_g):
+        assert np.array_equal(lo[N:], lg) and not lo[:N].any()
+    smalls = np.stack([r.u64s(orc.n + 1) for _ in range(5)])
+    smalls[4][:] = 0                                          # every rotation zero: accumulator untouched
+    idx = np.array([0, 1, 2, 1, 0], dtype=np.uint32)
+    got = ctx.blind_rotate(smalls, luts_g, idx)
+    for c in range(5):
+        want = orc.blind_rotate(pb, smalls[c], luts_o[idx[c]])
+        assert np.array_equal(got[c].reshape(-1), want), c
+    cts = np.stack([orc.encrypt_block(glwe_sk, m, r) for m in range(16)])
+    idx = np.array([m % 3 for m in range(16)], dtype=np.uint32)
+    out = ctx.pbs_batch(cts, luts_g, idx)
+    for m in range(16):
+        assert np.array_equal(out[m], orc.pbs(ksk, pb, cts[m], luts_o[idx[m]])), m
+
+
+def test_pbs_full_parameters(full):
+    """The benchmark's parameter set (n = 918): every output decrypts to f(m); a subsample is
+    compared bit for bit with the oracle."""
+    orc, keys, ctx, pb = full
+    lwe_sk, glwe_sk, bsk, ksk = keys
+    r = Rng(seed_bytes(25))
+    f = [lambda x: x, lambda x: (x * x + 3) % 16]
+    luts_o = [orc.make_lut(g) for g in f]
+    luts_g = np.stack([ctx.make_lut(g) for g in f])
+    B = 96
+    msgs = [int(r.u64() % 16) for _ in range(B)]
+    cts = np.stack([orc.encrypt_block(glwe_sk, m, r) for m in msgs])
+    idx = np.array([i % 2 for i in range(B)], dtype=np.uint32)
+    out = ctx.pbs_batch(cts, luts_g, idx)
+    for i in range(B):
+        assert orc.decrypt_block(glwe_sk, out[i]) == f[idx[i]](msgs[i]) % 16, i
+    for i in (0, 1, 50, 95):
+        assert np.array_equal(out[i], orc.pbs(ksk, pb, cts[i], luts_o[idx[i]])), i
+    # idempotence of a second bootstrap by the identity: value preserved
+    out2 = ctx.pbs_batch(out, luts_g[:1])
+    for i in range(0, B, 7):
+        assert orc.decrypt_block(glwe_sk, out2[i]) == f[idx[i]](msgs[i]) % 16
+
+
+def test_library_keygen_round_trip():
+    """Keys made by the library itself: encrypt -> bootstrap -> decrypt, and the oracle decrypts
+    library ciphertexts with the exported secret key."""
+    from fhe_amd.native import Context, KEY_CLIENT
+    ctx = Context(seed=seed_bytes(77))
+    try:
+        ctx.keygen()
+        blob = ctx.export_keys(KEY_CLIENT)
+        words = np.frombuffer(blob[-(918 + 2048) * 8:], dtype=np.uint64)
+        glwe_sk = words[918:].copy()
+        orc = Oracle()
+        lut = ctx.make_lut(lambda x: (x + 5) % 16)
+        for v, w in ((0xA7, 8), (1, 1), (0xBEEF, 16)):
+            ct = ctx.encrypt(v, w)
+            assert ctx.decrypt(ct) == v
+            blocks = np.frombuffer(ct[16:], dtype=np.uint64).reshape(-1, N + 1)
+            digits = [orc.decrypt_block(glwe_sk, b) for b in blocks]
+            assert sum(d << (2 * i) for i, d in enumerate(digits)) == v
+            out = ctx.pbs_batch(blocks, lut[None])
+            assert [orc.decrypt_block(glwe_sk, b) for b in out] == [(d + 5) % 16 for d in digits]
+    finally:
+        ctx.close()
