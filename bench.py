@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Batched programmable-bootstrap benchmark (BASELINE.json config 2).
+
+One step = one pass of the hot path (key switch -> modulus switch + blind rotation + sample
+extraction) over a batch of 4096 independent ciphertext blocks per GPU, inputs and keys resident
+in HBM.  With N GPUs every rank bootstraps its own 4096 blocks (weak scaling); the server keys are
+generated on rank 0 and replicated with one RCCL broadcast of their device images, there is no
+collective on the data path.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH = 4096
+N = 2048
+# algorithmic work of one bootstrap at n=918, k=1, N=2048, l=1 (single-modulus count):
+# 3672 length-2048 transforms * 11264 butterflies + 918*4*2048 point-wise multiply-accumulates
+MODMUL_PER_PBS = 3672 * 11264 + 918 * 4 * 2048
+# register-resident calibration on MI355X (profiles/r01/valu_rates_8wg_per_cu.txt): 4748 G/s exact
+# f64 butterflies per prime, two primes per logical modular product
+PEAK_GMODMUL = 4748.0 / 2
+# algorithmic bytes of one batch launch: both keys once + one ciphertext in and out per bootstrap
+BSK_BYTES, KSK_BYTES, CT_BYTES = 60162048, 60227584, 16392
+
+
+class _DevMem:
+    """Zero-copy view of library-owned device memory for torch (cuda array interface)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def cpu_baseline(seconds_budget: float = 20.0):
+    """The CPU oracle (own port; the reference engine is not available offline) timed on the host
+    cores of this box on a bounded sample of the same workload."""
+    from oracle.oracle import Oracle, Rng, seed_bytes
+    threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    orc = Oracle()
+    lwe_sk, glwe_sk, bsk, ksk = orc.gen_keys(seed_bytes(9))
+    pb = orc.prepare_bsk(bsk)
+    r = Rng(seed_bytes(10))
+    lut = orc.make_lut(lambda x: x)
+    probe = np.stack([orc.encrypt_block(glwe_sk, int(r.u64() % 16), r) for _ in range(threads)])
+    t0 = time.perf_counter()
+    orc.pbs_batch(ksk, pb, probe, lut[None], None, nthreads=threads)
+    per_round = time.perf_counter() - t0
+    rounds = max(1, min(8, int(seconds_budget / max(per_round, 1e-3))))
+    cts = np.stack([orc.encrypt_block(glwe_sk, int(r.u64() % 16), r) for _ in range(threads * rounds)])
+    t0 = time.perf_counter()
+    out = orc.pbs_batch(ksk, pb, cts, lut[None], None, nthreads=threads)
+    dt = time.perf_counter() - t0
+    assert all(orc.decrypt_block(glwe_sk, out[i]) == orc.decrypt_block(glwe_sk, cts[i]) for i in range(0, len(cts), 5))
+    return {"value": len(cts) / dt, "unit": "PBS/s", "cores": threads, "kind": "port",
+            "sample": f"{len(cts)} bootstraps of the same workload (n=918, N=2048), oracle C port with OpenMP"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from fhe_amd.native import Context, KEY_CLIENT
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("no GPU: the HIP path is the only path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    seed = bytes((7 * i + 3) & 0xFF for i in range(32))
+    ctx = Context(seed=seed, device=local)
+    keep = []  # tensors whose memory the context points at
+    if rank == 0:
+        ctx.keygen()
+        client_blob = ctx.export_keys(KEY_CLIENT)
+    if world > 1:
+        # one broadcast per key image, straight out of / into device memory
+        bsk_bytes, ksk_bytes = ctx.device_keys_size()
+        if rank == 0:
+            bp, _, kp, _ = ctx.device_keys()
+            tb = torch.as_tensor(_DevMem(bp, bsk_bytes), device=dev)
+            tk = torch.as_tensor(_DevMem(kp, ksk_bytes), device=dev)
+        else:
+            tb = torch.empty(bsk_bytes, dtype=torch.uint8, device=dev)
+            tk = torch.empty(ksk_bytes, dtype=torch.uint8, device=dev)
+        dist.broadcast(tb, src=0)
+        dist.broadcast(tk, src=0)
+        torch.cuda.synchronize()
+        if rank != 0:
+            ctx.attach_device_keys(tb.data_ptr(), tk.data_ptr())
+            keep += [tb, tk]
+        blob = [client_blob if rank == 0 else None]
+        dist.broadcast_object_list(blob, src=0)
+        if rank != 0:
+            ctx.import_keys(KEY_CLIENT, blob[0])
+
+    # synthetic inputs: batch blocks = batch/4 euint8 values, fresh encryptions, distinct per rank
+    B = args.batch
+    rng = np.random.default_rng(1234 + rank)
+    vals = rng.integers(0, 256, size=(B + 3) // 4)
+    blocks = np.concatenate([np.frombuffer(ctx.encrypt(int(v), 8)[16:], dtype=np.uint64).reshape(4, N + 1)
+                             for v in vals])[:B]
+    msgs = np.array([(int(vals[i // 4]) >> (2 * (i % 4))) & 3 for i in range(B)])
+    f = [lambda x: x, lambda x: (5 * x + 3) % 16]
+    luts = np.stack([ctx.make_lut(g) for g in f])
+    idx = (np.arange(B) % 2).astype(np.uint32)
+    d_in = torch.from_numpy(blocks.view(np.int64)).to(dev)
+    d_luts = torch.from_numpy(luts.view(np.int64)).to(dev)
+    d_idx = torch.from_numpy(idx.view(np.int32)).to(dev)
+    d_out = torch.zeros_like(d_in)
+    torch.cuda.synchronize()
+
+    def step(iters):
+        return ctx.pbs_batch_device_timed(B, d_in.data_ptr(), d_luts.data_ptr(), d_idx.data_ptr(),
+                                          d_out.data_ptr(), iters)
+
+    if args.warmup > 0:
+        step(args.warmup)
+    ctx.sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    ks_ms, br_ms = step(args.steps)   # K back-to-back passes, each kernel bracketed by HIP events
+    ctx.sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # correctness of what was timed: every sampled output decrypts to f(m)
+    out = d_out.cpu().numpy().view(np.uint64)
+    sample = list(range(0, B, max(1, B // 128)))
+    got = ctx.decrypt_blocks(out[sample])
+    ok = all(g == f[idx[i]](int(msgs[i])) % 16 for g, i in zip(got, sample))
+    if dist is not None:
+        flag = torch.tensor([1 if ok else 0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
+
+    if rank == 0:
+        total = B * args.steps * world
+        value = total / elapsed
+        br_s = br_ms * 1e-3
+        achieved = B * MODMUL_PER_PBS / br_s / 1e9
+        algo_bytes = BSK_BYTES + KSK_BYTES + 2 * CT_BYTES * B
+        res = {
+            "metric": "programmable bootstraps/sec (node)",
+            "value": value,
+            "unit": "PBS/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"batched PBS microbench: {B} independent euint8 blocks per GPU, "
+                                   "PARAM_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128 (n=918, N=2048), 2 LUTs",
+                       "batch_per_gpu": B, "parallelism": f"batch-shard x{world}, keys broadcast once"},
+            "verified": ok,
+            "kernel_ms": {"keyswitch": ks_ms, "blind_rotate": br_ms},
+            "roofline": {"bound": "valu", "kernel": "k_blind_rotate", "achieved": achieved, "peak": PEAK_GMODMUL,
+                         "unit": "Gmodmul/s", "frac": achieved / PEAK_GMODMUL, "traffic": None,
+                         "hbm": {"achieved": algo_bytes / ((ks_ms + br_ms) * 1e-3) / 1e9, "peak": 8000.0,
+                                 "unit": "GB/s", "algorithmic_bytes": algo_bytes}},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+    if not ok:
+        raise SystemExit("verification failed")
+
+
+if __name__ == "__main__":
+    main()

@@ -20,18 +20,19 @@ def _stale() -> bool:
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
+def build(force: bool = False, verbose: bool = False, out: str = OUT, defines: tuple = ()) -> str:
+    if out == OUT and not force and not _stale():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-pthread",
            "-Wall", "-Wno-unused-function", "-x", "hip"]
+    cmd += [f"-D{d}" for d in defines]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", OUT]
+    cmd += ["-o", out]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":

@@ -26,7 +26,8 @@ void launch_ntt_inverse(const Tables& T, const double* in, u64* out, size_t poly
 void launch_external_product(const Tables& T, const double* bsk, const u32* idx, const u64* glwe, u64* out,
                              size_t count, hipStream_t st);
 void launch_blind_rotate(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
-                         const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count, hipStream_t st);
+                         const u32* lut_index, u64* acc_ws, u64* glwe_out, u64* lwe_out, size_t count,
+                         hipStream_t st);
 void launch_ksk_colsum(const u64* ksk, int rows, int cols, int half_base, u64* colsum, hipStream_t st);
 void launch_keyswitch(const u64* ksk, const u64* colsum, const u64* in, u64* out, size_t count, int big, int n,
                       int base_log, int levels, hipStream_t st);
@@ -72,8 +73,10 @@ public:
     void ntt_inverse(const double* in, u64* out, size_t count);
     void sync();
 
-    // scratch owned by the engine (grow-only), for the small-LWE intermediate of pbs_batch
+    // scratch owned by the engine (grow-only): the small-LWE intermediate of pbs_batch and the
+    // accumulator workspace of the blind rotation (2N words per ciphertext)
     u64* small_scratch(size_t count);
+    u64* acc_scratch(size_t count);
 
 private:
     int device_;
@@ -86,6 +89,8 @@ private:
     bool own_keys_ = false;
     u64* d_small_ = nullptr;
     size_t small_cap_ = 0;
+    u64* d_acc_ = nullptr;
+    size_t acc_cap_ = 0;
 };
 
 void hip_check(hipError_t e, const char* what);

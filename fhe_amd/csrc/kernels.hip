@@ -15,6 +15,14 @@
 #include "engine.h"
 #include "pbs_phases.h"
 
+#ifndef LFHE_BR_WAVES
+// Register budget of the blind-rotation kernel, as waves per SIMD.  Measured on MI355X with 4096
+// ciphertexts: budget 2 (the compiler then uses 166 VGPRs, so three workgroups still fit per CU)
+// 163 ms; budget 3 (156 VGPRs, same occupancy, tighter schedule) 191 ms; budget 4 (128 VGPRs with
+// 116 B of scratch) 201 ms.  The kernel is bound by FP64-rate VALU issue, not by latency.
+#define LFHE_BR_WAVES 2
+#endif
+
 namespace lfhe {
 
 extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
@@ -117,7 +125,10 @@ __global__ void __launch_bounds__(NT, 2) k_external_product(Tables T, const doub
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int j = 0; j < E; ++j) s.dig[q][j] = decomp23(glwe[(ct * 2 + q) * N + own1(t, j)]);
+        for (int j = 0; j < E; ++j) {
+            s.dig[q][j] = decomp23(glwe[(ct * 2 + q) * N + own1(t, j)]);
+            s.out[q][j] = 0;
+        }
     ep_run(s, lds_dyn, t, T, bsk + (size_t)ggsw_index[ct] * BSK_ROW);
 #pragma unroll
     for (int q = 0; q < 2; ++q)
@@ -128,71 +139,88 @@ __global__ void __launch_bounds__(NT, 2) k_external_product(Tables T, const doub
 // ------------------------------------------------------------------------------------------------
 // blind rotation: modulus switch of the small ciphertext, acc = X^-b~ * lut, n CMux steps,
 // then either the whole accumulator (glwe_out) or its sample-extracted LWE (lwe_out).
+//
+// The accumulator (2 x 2048 words) lives in a per-ciphertext workspace in global memory, which for
+// the resident workgroups stays in L2: each step reads it twice (own coefficients and the
+// rotated ones, both coalesced) and rewrites it once.  Holding it in registers instead costs 32
+// VGPRs for the whole step and halves the occupancy; holding it in LDS does not fit beside the
+// exchange buffer at four workgroups per CU.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(NT, 2) k_blind_rotate(Tables T, const double* __restrict__ bsk,
+template <int... PH>
+__device__ __forceinline__ void ep_run_assign(EpState& s, double* lds, int t, const Tables& T,
+                                              const double* __restrict__ bsk_i,
+                                              std::integer_sequence<int, PH...>) {
+    // barrier between phases, none after the last: the caller publishes its result first
+#ifdef LFHE_ABLATE_NO_BARRIER   // timing experiment only: results are wrong
+    ((ep_phase<PH, false>(s, lds, t, T, bsk_i)), ...);
+#else
+    ((ep_phase<PH, false>(s, lds, t, T, bsk_i), (PH + 1 < EP_PHASES ? __syncthreads() : (void)0)), ...);
+#endif
+}
+
+__global__ void __launch_bounds__(NT, LFHE_BR_WAVES) k_blind_rotate(Tables T, const double* __restrict__ bsk,
                                                         const u64* __restrict__ lwe_small, int n,
                                                         const u64* __restrict__ luts,
                                                         const u32* __restrict__ lut_index,
+                                                        u64* __restrict__ acc_ws,
                                                         u64* __restrict__ glwe_out,
                                                         u64* __restrict__ lwe_out) {
     const int t = threadIdx.x;
     const size_t ct = blockIdx.x;
     const u64* __restrict__ lwe = lwe_small + ct * (size_t)(n + 1);
     const u64* __restrict__ lut = luts + (size_t)(lut_index ? lut_index[ct] : 0) * N;
-    u64* pub = reinterpret_cast<u64*>(lds_dyn);
+    u64* ws = acc_ws + ct * (size_t)(2 * N);
 
-    u64 acc[2][E];
     {
         const int bt = (int)modswitch_2n(lwe[n]);
         const int a = (2 * N - bt) & (2 * N - 1);  // multiply by X^-b~
-        const int ar = a & (N - 1);
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             const int e = own1(t, j);
-            int idx = e - ar;
-            bool neg = (a & N) != 0;
-            if (idx < 0) { idx += N; neg = !neg; }
-            const u64 v = lut[idx];
-            acc[0][j] = 0;
-            acc[1][j] = neg ? (u64)0 - v : v;
+            bool neg;
+            const u64 v = lut[rot_index(e, a, neg)];
+            ws[e] = 0;
+            ws[N + e] = neg ? (u64)0 - v : v;
         }
     }
+    __syncthreads();
 
     EpState s;
     for (int i = 0; i < n; ++i) {
         const int a = (int)modswitch_2n(lwe[i]);
         if (a == 0) continue;  // X^0 - 1 = 0: this CMux adds exactly zero
+        int tt = t;
+        asm volatile("" : "+v"(tt));  // recompute the workspace addresses per step (see ep_phase)
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int j = 0; j < E; ++j) pub[q * POLY_STRIDE + own1(t, j)] = acc[q][j];
-        __syncthreads();
+            for (int j = 0; j < E; ++j) {
+                const int e = own1(tt, j);
+                bool neg;
+                const u64 r = ws[q * N + rot_index(e, a, neg)];
+                s.dig[q][j] = decomp23((neg ? (u64)0 - r : r) - ws[q * N + e]);
+            }
+        ep_run_assign(s, lds_dyn, t, T, bsk + (size_t)i * BSK_ROW, std::make_integer_sequence<int, EP_PHASES>{});
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int j = 0; j < E; ++j)
-                s.dig[q][j] = decomp23(rot_minus_self(pub + q * POLY_STRIDE, own1(t, j), a, acc[q][j]));
-        __syncthreads();
-        ep_run(s, lds_dyn, t, T, bsk + (size_t)i * BSK_ROW);
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int j = 0; j < E; ++j) acc[q][j] += s.out[q][j];
+            for (int j = 0; j < E; ++j) ws[q * N + own1(tt, j)] += s.out[q][j];
+        __syncthreads();  // the new accumulator is visible to the whole workgroup before the next step
     }
 
     if (glwe_out) {
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int j = 0; j < E; ++j) glwe_out[(ct * 2 + q) * N + own1(t, j)] = acc[q][j];
+            for (int j = 0; j < E; ++j) glwe_out[(ct * 2 + q) * N + own1(t, j)] = ws[q * N + own1(t, j)];
     }
     if (lwe_out) {  // sample extraction of coefficient 0
         u64* o = lwe_out + ct * (size_t)(N + 1);
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             const int e = own1(t, j);
-            if (e == 0) { o[0] = acc[0][j]; o[N] = acc[1][j]; }
-            else o[N - e] = (u64)0 - acc[0][j];
+            if (e == 0) { o[0] = ws[0]; o[N] = ws[N]; }
+            else o[N - e] = (u64)0 - ws[e];
         }
     }
 }
@@ -312,9 +340,10 @@ void launch_external_product(const Tables& T, const double* bsk, const u32* idx,
     hipLaunchKernelGGL(k_external_product, dim3((unsigned)count), dim3(NT), LDS_BYTES, st, T, bsk, idx, glwe, out);
 }
 void launch_blind_rotate(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
-                         const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count, hipStream_t st) {
+                         const u32* lut_index, u64* acc_ws, u64* glwe_out, u64* lwe_out, size_t count,
+                         hipStream_t st) {
     hipLaunchKernelGGL(k_blind_rotate, dim3((unsigned)count), dim3(NT), LDS_BYTES, st, T, bsk, lwe_small, n, luts,
-                       lut_index, glwe_out, lwe_out);
+                       lut_index, acc_ws, glwe_out, lwe_out);
 }
 void launch_ksk_colsum(const u64* ksk, int rows, int cols, int half_base, u64* colsum, hipStream_t st) {
     hipLaunchKernelGGL(k_ksk_colsum, dim3((cols + 255) / 256), dim3(256), 0, st, ksk, rows, cols, half_base, colsum);

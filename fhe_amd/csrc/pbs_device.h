@@ -154,6 +154,11 @@ LFHE_HD int base2(int t) { return 8 + (t >> 5); }
 LFHE_HD int base3(int t) { return 64 + (t >> 2); }
 
 // ---- LDS exchange halves.  `buf` is one polynomial's region (POLY_STRIDE words).
+#ifdef LFHE_ABLATE_NO_LDS   // timing experiment only: results are wrong
+#define LFHE_XCHG(NAME, OWN, PAD)                                                         \
+    LFHE_HD void st_##NAME(double*, int, const double (&)[8]) {}                          \
+    LFHE_HD void ld_##NAME(const double*, int, double (&)[8]) {}
+#else
 #define LFHE_XCHG(NAME, OWN, PAD)                                                         \
     LFHE_HD void st_##NAME(double* buf, int t, const double (&x)[8]) {                    \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) buf[PAD(OWN(t, j))] = x[j];         \
@@ -161,6 +166,7 @@ LFHE_HD int base3(int t) { return 64 + (t >> 2); }
     LFHE_HD void ld_##NAME(const double* buf, int t, double (&x)[8]) {                    \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) x[j] = buf[PAD(OWN(t, j))];         \
     }
+#endif
 LFHE_XCHG(o1p12, own1, pad12)
 LFHE_XCHG(o2p12, own2, pad12)
 LFHE_XCHG(o2p23, own2, pad23)

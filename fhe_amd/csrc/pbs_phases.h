@@ -28,19 +28,33 @@ struct EpState {
     int dig[2][E];     // in: decomposition digits, pass-1 ownership
     double x[2][E];    // working residues
     double y0[2][E];   // prime-0 result, pass-1 ownership
-    u64 out[2][E];     // result, pass-1 ownership
+    u64 out[2][E];     // result, pass-1 ownership: added to (ACCUM) or overwritten
 };
 
 constexpr int EP_PHASES = 24;  // 12 per prime
 
 // phase p of the external product.  `lds` holds two padded polynomials.
-template <int PH>
+template <int PH, bool ACCUM = true>
 LFHE_HD void ep_phase(EpState& s, double* lds, int t, const Tables& T, const double* __restrict__ bsk_i) {
     constexpr int r = PH / 12;
     constexpr int ph = PH % 12;
     const Prime P = T.pr[r];
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Everything a thread addresses (twiddles, key row, LDS slots) depends on its index only, not
+    // on the blind-rotation step, so the compiler would hoist the loads or at least their 64-bit
+    // addresses out of the step loop and keep hundreds of registers live across it.  Making the
+    // thread index and a zero table offset opaque per phase turns them back into a few integer
+    // instructions and per-step loads served by L1/L2 (the pointers themselves stay kernel
+    // arguments, so the loads remain global, not flat).
+    unsigned zero = 0;
+    asm volatile("" : "+v"(t));
+    asm volatile("" : "+s"(zero));
+    const double* __restrict__ twf = T.tw_fwd[r] + zero;
+    const double* __restrict__ twi = T.tw_inv[r] + zero;
+#else
     const double* __restrict__ twf = T.tw_fwd[r];
     const double* __restrict__ twi = T.tw_inv[r];
+#endif
     double* b0 = lds;
     double* b1 = lds + POLY_STRIDE;
 
@@ -65,22 +79,31 @@ LFHE_HD void ep_phase(EpState& s, double* lds, int t, const Tables& T, const dou
     } else if constexpr (ph == 5) {  // forward pass 4, point-wise with the key row, inverse pass 4
         ld_o4p34(b0, t, s.x[0]); ld_o4p34(b1, t, s.x[1]);
         ct_radix4x2(s.x[0], twf, t, P); ct_radix4x2(s.x[1], twf, t, P);
-        double o0[E], o1[E];
+        // key row, two coefficients (one 16-byte load per polynomial) at a time, the next chunk's
+        // loads in flight while this one is multiplied; the fences keep the compiler from hoisting
+        // all sixteen loads (64 registers) to the top of the phase
+        double kc[4][2], kn[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const double* k = bsk_i + bsk_off(r, q, 0, t); kc[q][0] = k[0]; kc[q][1] = k[1]; }
 #pragma unroll
         for (int c4 = 0; c4 < 4; ++c4) {
-            const double* k00 = bsk_i + bsk_off(r, 0, c4, t);
-            const double* k01 = bsk_i + bsk_off(r, 1, c4, t);
-            const double* k10 = bsk_i + bsk_off(r, 2, c4, t);
-            const double* k11 = bsk_i + bsk_off(r, 3, c4, t);
+            if (c4 < 3) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const double* k = bsk_i + bsk_off(r, q, c4 + 1, t); kn[q][0] = k[0]; kn[q][1] = k[1]; }
+            }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int j = 2 * c4 + h;
-                o0[j] = mmul(s.x[0][j], k00[h], P) + mmul(s.x[1][j], k10[h], P);
-                o1[j] = mmul(s.x[0][j], k01[h], P) + mmul(s.x[1][j], k11[h], P);
+                const double d0 = s.x[0][j], d1 = s.x[1][j];
+                s.x[0][j] = mmul(d0, kc[0][h], P) + mmul(d1, kc[2][h], P);
+                s.x[1][j] = mmul(d0, kc[1][h], P) + mmul(d1, kc[3][h], P);
             }
-        }
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" ::: "memory");
+#endif
 #pragma unroll
-        for (int j = 0; j < E; ++j) { s.x[0][j] = o0[j]; s.x[1][j] = o1[j]; }
+            for (int q = 0; q < 4; ++q) { kc[q][0] = kn[q][0]; kc[q][1] = kn[q][1]; }
+        }
         gs_radix4x2(s.x[0], twi, t, P); gs_radix4x2(s.x[1], twi, t, P);
         norm8(s.x[0], P); norm8(s.x[1], P);
     } else if constexpr (ph == 6) {
@@ -111,20 +134,20 @@ LFHE_HD void ep_phase(EpState& s, double* lds, int t, const Tables& T, const dou
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int j = 0; j < E; ++j)
-                    s.out[q][j] = crt_wrap(s.y0[q][j], s.x[q][j], T.p0inv_mod_p1, T.pr[1]);
+                for (int j = 0; j < E; ++j) {
+                    const u64 v = crt_wrap(s.y0[q][j], s.x[q][j], T.p0inv_mod_p1, T.pr[1]);
+                    if constexpr (ACCUM) s.out[q][j] += v; else s.out[q][j] = v;
+                }
         }
     }
 }
 
-// X^a * acc - acc at coefficient e, reading the rotated term from the published copy
-LFHE_HD u64 rot_minus_self(const u64* pub, int e, int a, u64 self) {
-    const int ar = a & (N - 1);
-    int idx = e - ar;
-    bool neg = (a & N) != 0;
+// coefficient e of X^a * poly: index to read and whether to negate it
+LFHE_HD int rot_index(int e, int a, bool& neg) {
+    int idx = e - (a & (N - 1));
+    neg = (a & N) != 0;
     if (idx < 0) { idx += N; neg = !neg; }
-    u64 v = pub[idx];
-    return (neg ? (u64)0 - v : v) - self;
+    return idx;
 }
 
 LFHE_HD u32 modswitch_2n(u64 x) {  // round to Z_{2N}

@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblfhe.so")
+LIB_PATH = os.environ.get("LFHE_LIB", os.path.join(_HERE, "liblfhe.so"))  # override: A/B builds
 
 LFHE_OK = 0
 ERR_NAMES = {-1: "LFHE_ERR_ARG", -2: "LFHE_ERR_STATE", -3: "LFHE_ERR_DEVICE", -4: "LFHE_ERR_SIZE",
@@ -210,6 +210,13 @@ class Context:
         w = C.c_uint32()
         self._ck(self._L.lfhe_decrypt(self._h, _ptr(buf), buf.size, _ptr(out), C.byref(w)))
         return int.from_bytes(out.tobytes(), "little")
+
+    def decrypt_blocks(self, blocks: np.ndarray) -> list:
+        """Decrypt single radix blocks (values 0..15: message and carry bits)."""
+        blocks = _u64(blocks).reshape(-1, self.N + 1)
+        hdr = self.encrypt(0, 8, trivial=True)[:16]
+        pad = bytes(3 * (self.N + 1) * 8)
+        return [self.decrypt(hdr + b.tobytes() + pad) & 0xF for b in blocks]
 
     def evaluate(self, op: str, bit_width: int, lhs: bytes, rhs=None, cond: bytes | None = None) -> bytes:
         """rhs: ciphertext bytes, or a Python int for a clear right operand."""

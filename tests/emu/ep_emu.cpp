@@ -58,7 +58,7 @@ static int run_case(const orc_ctx* oc, const HostTables& H, const Tables& T, con
     std::vector<double> lds(LDS_WORDS, 0.0);
     for (int t = 0; t < NT; ++t)
         for (int q = 0; q < 2; ++q)
-            for (int j = 0; j < E; ++j) st[t].dig[q][j] = decomp23(glwe[q * N + own1(t, j)]);
+            for (int j = 0; j < E; ++j) { st[t].dig[q][j] = decomp23(glwe[q * N + own1(t, j)]); st[t].out[q][j] = 0; }
     run_phases<0>(st, lds.data(), T, row.data());
     std::vector<u64> want(2 * N);
     orc_external_product(oc, ggsw, glwe, want.data());
