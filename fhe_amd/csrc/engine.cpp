@@ -127,23 +127,40 @@ u64* Engine::acc_scratch(size_t count) {
     return d_acc_;
 }
 
-void Engine::keyswitch(const u64* lwe_in, u64* lwe_small_out, size_t count) {
+void Engine::keyswitch(const u64* lwe_in, u64* lwe_small_out, size_t count, const BlockMap& imap) {
     if (!d_ksk_) throw std::runtime_error("no key-switching key loaded");
     if (!count) return;
     HC(hipSetDevice(device_));
     launch_keyswitch(d_ksk_, d_ksk_ + ksk_words(), lwe_in, lwe_small_out, count, N, (int)prm_.lwe_dim,
-                     (int)prm_.ks_base_log, (int)prm_.ks_level, stream_);
+                     (int)prm_.ks_base_log, (int)prm_.ks_level, imap, stream_);
+    HC(hipGetLastError());
+}
+
+void Engine::pbs_layer(u64* arena, size_t instances, size_t inst_stride_blocks, const u32* in_idx, const u32* out_idx,
+                       const u32* lut_of_op, u32 ops, const u64* luts) {
+    const size_t count = instances * ops;
+    if (!count) return;
+    u64* small = small_scratch(count);
+    BlockMap im{in_idx, ops, inst_stride_blocks}, om{out_idx, ops, inst_stride_blocks};
+    keyswitch(arena, small, count, im);
+    blind_rotate(small, luts, lut_of_op, nullptr, arena, count, om);
+}
+
+void Engine::lin_layer(u64* arena, size_t instances, size_t inst_stride_blocks, const LinOp* ops, int nops, u64 delta) {
+    if (!instances || !nops) return;
+    HC(hipSetDevice(device_));
+    launch_lin_batch(arena, ops, nops, instances, inst_stride_blocks, delta, stream_);
     HC(hipGetLastError());
 }
 
 void Engine::blind_rotate(const u64* lwe_small, const u64* luts, const u32* lut_index, u64* glwe_out, u64* lwe_out,
-                          size_t count) {
+                          size_t count, const BlockMap& omap) {
     if (!d_bsk_) throw std::runtime_error("no bootstrapping key loaded");
     if (!count) return;
     HC(hipSetDevice(device_));
     u64* ws = acc_scratch(count);
     launch_blind_rotate(T_, d_bsk_, lwe_small, (int)prm_.lwe_dim, luts, lut_index, ws, glwe_out, lwe_out, count,
-                        stream_);
+                        omap, stream_);
     HC(hipGetLastError());
 }
 

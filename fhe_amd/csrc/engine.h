@@ -7,8 +7,20 @@
 #include <string>
 
 #include "pbs_phases.h"
+#include "radix_program.h"
 
 namespace lfhe {
+
+// Where ciphertext number ct of a launch lives, in blocks of N + 1 words: contiguous (idx == null)
+// or, for a radix program, block idx[ct % ops] of instance ct / ops in an arena.
+struct BlockMap {
+    const u32* idx = nullptr;
+    u32 ops = 0;
+    size_t inst_stride = 0;
+    __host__ __device__ size_t block(size_t ct) const {
+        return idx ? (ct / ops) * inst_stride + idx[ct % ops] : ct;
+    }
+};
 
 struct EngineParams {
     uint32_t lwe_dim = 918;
@@ -27,10 +39,12 @@ void launch_external_product(const Tables& T, const double* bsk, const u32* idx,
                              size_t count, hipStream_t st);
 void launch_blind_rotate(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
                          const u32* lut_index, u64* acc_ws, u64* glwe_out, u64* lwe_out, size_t count,
-                         hipStream_t st);
+                         const BlockMap& omap, hipStream_t st);
+void launch_lin_batch(u64* arena, const LinOp* ops, int nops, size_t instances, size_t inst_stride_blocks, u64 delta,
+                      hipStream_t st);
 void launch_ksk_colsum(const u64* ksk, int rows, int cols, int half_base, u64* colsum, hipStream_t st);
 void launch_keyswitch(const u64* ksk, const u64* colsum, const u64* in, u64* out, size_t count, int big, int n,
-                      int base_log, int levels, hipStream_t st);
+                      int base_log, int levels, const BlockMap& imap, hipStream_t st);
 void launch_lwe_linear(const u64* a, const u64* b, u64* out, size_t count, int dim1, u64 ca, u64 cb, u64 add_body,
                        hipStream_t st);
 
@@ -65,9 +79,14 @@ public:
     // ---- device-pointer operations, asynchronous on stream()
     // count bootstraps: lwe_in [count][N+1], luts [nluts][N] body polynomials, lut_index [count] or null
     void pbs_batch(const u64* lwe_in, const u64* luts, const u32* lut_index, u64* lwe_out, size_t count);
-    void keyswitch(const u64* lwe_in, u64* lwe_small_out, size_t count);
+    void keyswitch(const u64* lwe_in, u64* lwe_small_out, size_t count, const BlockMap& imap = BlockMap());
     void blind_rotate(const u64* lwe_small, const u64* luts, const u32* lut_index, u64* glwe_out, u64* lwe_out,
-                      size_t count);
+                      size_t count, const BlockMap& omap = BlockMap());
+    // one bootstrap layer of a radix program: ops bootstraps per instance, inputs and outputs are
+    // blocks of the arena, lut_of_op[ops] selects each bootstrap's table
+    void pbs_layer(u64* arena, size_t instances, size_t inst_stride_blocks, const u32* in_idx, const u32* out_idx,
+                   const u32* lut_of_op, u32 ops, const u64* luts);
+    void lin_layer(u64* arena, size_t instances, size_t inst_stride_blocks, const LinOp* ops, int nops, u64 delta);
     void external_product(const u32* ggsw_index, const u64* glwe, u64* out, size_t count);
     void ntt_forward(const u64* polys, double* out, size_t count);
     void ntt_inverse(const double* in, u64* out, size_t count);

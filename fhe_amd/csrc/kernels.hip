@@ -164,11 +164,11 @@ __global__ void __launch_bounds__(NT, LFHE_BR_WAVES) k_blind_rotate(Tables T, co
                                                         const u32* __restrict__ lut_index,
                                                         u64* __restrict__ acc_ws,
                                                         u64* __restrict__ glwe_out,
-                                                        u64* __restrict__ lwe_out) {
+                                                        u64* __restrict__ lwe_out, BlockMap omap) {
     const int t = threadIdx.x;
     const size_t ct = blockIdx.x;
     const u64* __restrict__ lwe = lwe_small + ct * (size_t)(n + 1);
-    const u64* __restrict__ lut = luts + (size_t)(lut_index ? lut_index[ct] : 0) * N;
+    const u64* __restrict__ lut = luts + (size_t)(lut_index ? lut_index[omap.ops ? ct % omap.ops : ct] : 0) * N;
     u64* ws = acc_ws + ct * (size_t)(2 * N);
 
     {
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(NT, LFHE_BR_WAVES) k_blind_rotate(Tables T, co
             for (int j = 0; j < E; ++j) glwe_out[(ct * 2 + q) * N + own1(t, j)] = ws[q * N + own1(t, j)];
     }
     if (lwe_out) {  // sample extraction of coefficient 0
-        u64* o = lwe_out + ct * (size_t)(N + 1);
+        u64* o = lwe_out + omap.block(ct) * (size_t)(N + 1);
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             const int e = own1(t, j);
@@ -264,7 +264,8 @@ __global__ void __launch_bounds__(256) k_ksk_colsum(const u64* __restrict__ ksk,
 __global__ void __launch_bounds__(256) k_keyswitch(const u64* __restrict__ ksk,
                                                    const u64* __restrict__ colsum,
                                                    const u64* __restrict__ in, u64* __restrict__ out,
-                                                   int count, int big, int n, int base_log, int levels) {
+                                                   int count, int big, int n, int base_log, int levels,
+                                                   BlockMap imap) {
     __shared__ u32 dig[KS_CT][KS_CHUNK];
     const int cols = n + 1;
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
@@ -278,7 +279,8 @@ __global__ void __launch_bounds__(256) k_keyswitch(const u64* __restrict__ ksk,
             const int c = k / KS_CHUNK, ii = k % KS_CHUNK;
             const int ct = ct0 + c;
             u32 pk = 0;
-            if (ct < count && i0 + ii < big) pk = ks_digits_packed(in[(size_t)ct * (big + 1) + i0 + ii], base_log, levels);
+            if (ct < count && i0 + ii < big)
+                pk = ks_digits_packed(in[imap.block(ct) * (size_t)(big + 1) + i0 + ii], base_log, levels);
             dig[c][ii] = pk;
         }
         __syncthreads();
@@ -302,7 +304,7 @@ __global__ void __launch_bounds__(256) k_keyswitch(const u64* __restrict__ ksk,
         for (int c = 0; c < KS_CT; ++c) {
             const int ct = ct0 + c;
             if (ct < count) {
-                const u64 b = (col == n) ? in[(size_t)ct * (big + 1) + big] : 0;
+                const u64 b = (col == n) ? in[imap.block(ct) * (size_t)(big + 1) + big] : 0;
                 out[(size_t)ct * cols + col] = b - acc[c] + cs;
             }
         }
@@ -341,17 +343,56 @@ void launch_external_product(const Tables& T, const double* bsk, const u32* idx,
 }
 void launch_blind_rotate(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
                          const u32* lut_index, u64* acc_ws, u64* glwe_out, u64* lwe_out, size_t count,
-                         hipStream_t st) {
+                         const BlockMap& omap, hipStream_t st) {
     hipLaunchKernelGGL(k_blind_rotate, dim3((unsigned)count), dim3(NT), LDS_BYTES, st, T, bsk, lwe_small, n, luts,
-                       lut_index, acc_ws, glwe_out, lwe_out);
+                       lut_index, acc_ws, glwe_out, lwe_out, omap);
 }
 void launch_ksk_colsum(const u64* ksk, int rows, int cols, int half_base, u64* colsum, hipStream_t st) {
     hipLaunchKernelGGL(k_ksk_colsum, dim3((cols + 255) / 256), dim3(256), 0, st, ksk, rows, cols, half_base, colsum);
 }
 void launch_keyswitch(const u64* ksk, const u64* colsum, const u64* in, u64* out, size_t count, int big, int n,
-                      int base_log, int levels, hipStream_t st) {
+                      int base_log, int levels, const BlockMap& imap, hipStream_t st) {
     dim3 grid((n + 1 + 255) / 256, (unsigned)((count + KS_CT - 1) / KS_CT));
-    hipLaunchKernelGGL(k_keyswitch, grid, dim3(256), 0, st, ksk, colsum, in, out, (int)count, big, n, base_log, levels);
+    hipLaunchKernelGGL(k_keyswitch, grid, dim3(256), 0, st, ksk, colsum, in, out, (int)count, big, n, base_log, levels,
+                       imap);
+}
+
+// ------------------------------------------------------------------------------------------------
+// linear layer of a radix program: for every instance and every LinOp,
+//   arena[inst][op.out] = sum_k coef[k] * arena[inst][src[k]] + cst * delta (body word only)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_lin_batch(u64* __restrict__ arena, const LinOp* __restrict__ ops, int nops,
+                                                   size_t inst_stride_blocks, u64 delta) {
+    const size_t inst = blockIdx.x / nops;
+    const LinOp op = ops[blockIdx.x % nops];
+    u64* base = arena + inst * inst_stride_blocks * (size_t)(N + 1);
+    u64* o = base + (size_t)op.out * (N + 1);
+    for (int w = threadIdx.x; w <= N; w += blockDim.x) {
+        u64 v = (w == N) ? (u64)(i64)op.cst * delta : 0;
+        for (uint32_t k = 0; k < op.n; ++k) v += (u64)(i64)op.coef[k] * base[(size_t)op.src[k] * (N + 1) + w];
+        o[w] = v;
+    }
+}
+
+// trivial (noiseless) blocks: all-zero mask, body = bodies[inst][j]; used for clear right operands
+__global__ void __launch_bounds__(256) k_fill_trivial(u64* __restrict__ arena, size_t inst_stride_blocks,
+                                                      u32 first_block, u32 m, const u64* __restrict__ bodies) {
+    const size_t inst = blockIdx.x / m;
+    const u32 j = blockIdx.x % m;
+    u64* o = arena + (inst * inst_stride_blocks + first_block + j) * (size_t)(N + 1);
+    for (int w = threadIdx.x; w <= N; w += blockDim.x) o[w] = (w == N) ? bodies[inst * m + j] : 0;
+}
+
+void launch_fill_trivial(u64* arena, size_t instances, size_t inst_stride_blocks, u32 first_block, u32 m,
+                         const u64* bodies, hipStream_t st) {
+    hipLaunchKernelGGL(k_fill_trivial, dim3((unsigned)(instances * m)), dim3(256), 0, st, arena, inst_stride_blocks,
+                       first_block, m, bodies);
+}
+
+void launch_lin_batch(u64* arena, const LinOp* ops, int nops, size_t instances, size_t inst_stride_blocks, u64 delta,
+                      hipStream_t st) {
+    hipLaunchKernelGGL(k_lin_batch, dim3((unsigned)(instances * nops)), dim3(256), 0, st, arena, ops, nops,
+                       inst_stride_blocks, delta);
 }
 
 void launch_lwe_linear(const u64* a, const u64* b, u64* out, size_t count, int dim1, u64 ca, u64 cb, u64 add_body,

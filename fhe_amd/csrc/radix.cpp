@@ -1,19 +1,22 @@
 // Integer operators on radix ciphertexts (euint8 ... euint256, ebool): serialisation, encryption,
-// decryption and the operator scheduler that turns each operation over a batch into layers of
-// independent programmable bootstraps.
+// decryption and the executor that replays an operator's Program (radix_program.h) for a batch of
+// independent instances, layer by layer, on the GPU.
 #include <cstring>
+#include <map>
 #include <stdexcept>
+#include <tuple>
 
 #include "ctx.h"
+#include "radix_program.h"
 
 using namespace lfhe;
 
-struct lfhe_radix {
-    int placeholder = 0;
-};
+#define HC(x) hip_check((x), #x)
 
-lfhe_ctx::lfhe_ctx() = default;
-lfhe_ctx::~lfhe_ctx() = default;
+namespace lfhe {
+void launch_fill_trivial(u64* arena, size_t instances, size_t inst_stride_blocks, u32 first_block, u32 m,
+                         const u64* bodies, hipStream_t st);
+}
 
 namespace {
 
@@ -28,15 +31,198 @@ struct CtHeader {
     uint16_t reserved;
 };
 static_assert(sizeof(CtHeader) == 16, "header layout");
+constexpr size_t BLK_WORDS = (size_t)N + 1;
+constexpr size_t BLK_BYTES = BLK_WORDS * 8;
 
 bool width_ok(uint32_t w) { return w == 1 || w == 8 || w == 16 || w == 32 || w == 64 || w == 128 || w == 160 || w == 256; }
 uint32_t blocks_of(uint32_t w) { return w == 1 ? 1 : w / 2; }
-
-uint64_t ct_bytes(uint32_t w) { return sizeof(CtHeader) + (uint64_t)blocks_of(w) * (N + 1) * 8; }
+uint64_t ct_bytes(uint32_t w) { return sizeof(CtHeader) + (uint64_t)blocks_of(w) * BLK_BYTES; }
 
 uint32_t block_value(const uint8_t v[32], uint32_t i) {  // i-th base-4 digit
     const uint32_t bit = 2 * i;
     return (v[bit >> 3] >> (bit & 7)) & 3u;
+}
+
+CtHeader parse_header(const uint8_t* ct, uint32_t expect_width) {
+    CtHeader h;
+    std::memcpy(&h, ct, sizeof h);
+    if (h.magic != CT_MAGIC || h.version != 1 || h.bit_width != expect_width || h.nblocks != blocks_of(expect_width))
+        throw std::invalid_argument("malformed ciphertext or width mismatch");
+    if (h.noise_level < 1 || h.noise_level > 2 || h.degree > 3) throw std::invalid_argument("ciphertext metadata out of range");
+    return h;
+}
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    DevBuf() = default;
+    explicit DevBuf(size_t count) { if (count) HC(hipMalloc(&p, count * sizeof(T))); }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p) { o.p = nullptr; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) { if (p) (void)hipFree(p); p = o.p; o.p = nullptr; }
+        return *this;
+    }
+};
+
+// a Program with its descriptors and tables resident on the device
+struct Compiled {
+    Program prog;
+    std::vector<LinOp*> d_lin;            // per layer (null when empty)
+    std::vector<u32*> d_in, d_out, d_lut;  // per layer
+    u64* d_luts = nullptr;                 // [nluts][N]
+    ~Compiled() {
+        for (auto p : d_lin) (void)hipFree(p);
+        for (auto p : d_in) (void)hipFree(p);
+        for (auto p : d_out) (void)hipFree(p);
+        for (auto p : d_lut) (void)hipFree(p);
+        (void)hipFree(d_luts);
+    }
+};
+
+}  // namespace
+
+struct lfhe_radix {
+    std::map<std::tuple<uint32_t, uint32_t, int, int, int>, std::unique_ptr<Compiled>> cache;
+};
+
+lfhe_ctx::lfhe_ctx() = default;
+lfhe_ctx::~lfhe_ctx() {
+    if (eng) (void)hipSetDevice(eng->device());
+    radix.reset();
+}
+
+namespace {
+
+Compiled& compiled_for(lfhe_ctx* ctx, uint32_t op, uint32_t width, int ln, int rn, int cn) {
+    if (!ctx->radix) ctx->radix.reset(new lfhe_radix());
+    auto key = std::make_tuple(op, width, ln, rn, cn);
+    auto it = ctx->radix->cache.find(key);
+    if (it != ctx->radix->cache.end()) return *it->second;
+    std::unique_ptr<Compiled> c(new Compiled());
+    c->prog = build_program(op, width, ln, rn, cn);
+    Engine& E = *ctx->eng;
+    HC(hipSetDevice(E.device()));
+    const Program& P = c->prog;
+    std::vector<u64> bodies(P.luts.size() * (size_t)N);
+    for (size_t i = 0; i < P.luts.size(); ++i)
+        make_lut_body(ctx->space(), ctx->delta(), P.luts[i].data(), bodies.data() + i * N);
+    if (!bodies.empty()) {
+        HC(hipMalloc(&c->d_luts, bodies.size() * 8));
+        HC(hipMemcpy(c->d_luts, bodies.data(), bodies.size() * 8, hipMemcpyHostToDevice));
+    }
+    for (const Layer& L : P.layers) {
+        LinOp* dl = nullptr;
+        if (!L.lin.empty()) {
+            HC(hipMalloc(&dl, L.lin.size() * sizeof(LinOp)));
+            HC(hipMemcpy(dl, L.lin.data(), L.lin.size() * sizeof(LinOp), hipMemcpyHostToDevice));
+        }
+        c->d_lin.push_back(dl);
+        u32 *di = nullptr, *dout = nullptr, *dlut = nullptr;
+        if (!L.pbs.empty()) {
+            std::vector<u32> a, b, l;
+            for (const PbsOp& q : L.pbs) { a.push_back(q.in); b.push_back(q.out); l.push_back(q.lut); }
+            HC(hipMalloc(&di, a.size() * 4)); HC(hipMalloc(&dout, a.size() * 4)); HC(hipMalloc(&dlut, a.size() * 4));
+            HC(hipMemcpy(di, a.data(), a.size() * 4, hipMemcpyHostToDevice));
+            HC(hipMemcpy(dout, b.data(), a.size() * 4, hipMemcpyHostToDevice));
+            HC(hipMemcpy(dlut, l.data(), a.size() * 4, hipMemcpyHostToDevice));
+        }
+        c->d_in.push_back(di); c->d_out.push_back(dout); c->d_lut.push_back(dlut);
+    }
+    Compiled& ref = *c;
+    ctx->radix->cache[key] = std::move(c);
+    return ref;
+}
+
+// ciphertext i of an operand array of stride `stride` bytes: header check, returns noise level
+int check_operand(const uint8_t* base, uint64_t n, uint32_t width) {
+    int noise = 1;
+    const uint64_t stride = ct_bytes(width);
+    for (uint64_t i = 0; i < n; ++i) noise = std::max<int>(noise, parse_header(base + i * stride, width).noise_level);
+    return noise;
+}
+
+void cast_one(lfhe_ctx* ctx, const uint8_t* in, uint64_t in_len, uint32_t to_width, uint8_t* out) {
+    if (in_len < sizeof(CtHeader)) throw std::invalid_argument("ciphertext too short");
+    CtHeader h;
+    std::memcpy(&h, in, sizeof h);
+    if (h.magic != CT_MAGIC || !width_ok(h.bit_width) || in_len != ct_bytes(h.bit_width))
+        throw std::invalid_argument("malformed ciphertext");
+    if (to_width == 1 && h.bit_width != 1) throw std::invalid_argument("cast to ebool: use ne(x, 0)");
+    const uint32_t nb = blocks_of(to_width), have = std::min(nb, (uint32_t)h.nblocks);
+    CtHeader o{CT_MAGIC, 1, (uint16_t)to_width, nb, h.noise_level, h.degree, 0};
+    std::memcpy(out, &o, sizeof o);
+    std::memcpy(out + sizeof o, in + sizeof h, (size_t)have * BLK_BYTES);
+    std::memset(out + sizeof o + (size_t)have * BLK_BYTES, 0, (size_t)(nb - have) * BLK_BYTES);  // trivial zeros
+    (void)ctx;
+}
+
+void run_batch(lfhe_ctx* ctx, uint32_t op, uint32_t width, uint64_t n, const uint8_t* lhs, const uint8_t* rhs,
+               bool rhs_scalar, const uint8_t* cond, uint8_t* out) {
+    if (!width_ok(width)) throw std::invalid_argument("unsupported bit width");
+    if (!n) return;
+    if (!lhs || !out) throw std::invalid_argument("null operand");
+    if (!ctx->eng->has_keys()) throw std::logic_error("server keys not loaded");
+    const bool unary = op == LFHE_OP_NOT || op == LFHE_OP_NEG;
+    if (!unary && !rhs) throw std::invalid_argument("missing right operand");
+    if (op == LFHE_OP_SELECT && !cond) throw std::invalid_argument("select needs a condition");
+    const int ln = check_operand(lhs, n, width);
+    const int rn = (unary || rhs_scalar) ? 1 : check_operand(rhs, n, width);
+    const int cn = op == LFHE_OP_SELECT ? check_operand(cond, n, 1) : 1;
+    Compiled& C = compiled_for(ctx, op, width, ln, rn, cn);
+    const Program& P = C.prog;
+    Engine& E = *ctx->eng;
+    HC(hipSetDevice(E.device()));
+    hipStream_t st = E.stream();
+    const uint32_t m = blocks_of(width);
+    const size_t inst_bytes = (size_t)P.nblocks * BLK_BYTES;
+    DevBuf<u64> arena(n * (size_t)P.nblocks * BLK_WORDS);
+    const uint64_t in_stride = ct_bytes(width);
+    auto upload = [&](const uint8_t* src, uint64_t sstride, uint32_t first, uint32_t nb) {
+        HC(hipMemcpy2DAsync(reinterpret_cast<uint8_t*>(arena.p) + (size_t)first * BLK_BYTES, inst_bytes,
+                            src + sizeof(CtHeader), sstride, (size_t)nb * BLK_BYTES, n, hipMemcpyHostToDevice, st));
+    };
+    upload(lhs, in_stride, P.lhs[0], m);
+    DevBuf<u64> scal;
+    if (!unary) {
+        if (rhs_scalar) {
+            std::vector<u64> bodies(n * m);
+            for (uint64_t i = 0; i < n; ++i)
+                for (uint32_t j = 0; j < m; ++j) {
+                    const uint8_t* v = rhs + i * 32;
+                    const u64 d = width == 1 ? (v[0] & 1u) : block_value(v, j);
+                    bodies[i * m + j] = d * ctx->delta();
+                }
+            DevBuf<u64> tmp(bodies.size());
+            scal = std::move(tmp);
+            HC(hipMemcpyAsync(scal.p, bodies.data(), bodies.size() * 8, hipMemcpyHostToDevice, st));
+            HC(hipStreamSynchronize(st));  // bodies goes out of scope
+            launch_fill_trivial(arena.p, n, P.nblocks, P.rhs[0], m, scal.p, st);
+            HC(hipGetLastError());
+        } else {
+            upload(rhs, in_stride, P.rhs[0], m);
+        }
+    }
+    if (op == LFHE_OP_SELECT) upload(cond, ct_bytes(1), P.cond[0], 1);
+
+    for (size_t l = 0; l < P.layers.size(); ++l) {
+        const Layer& L = P.layers[l];
+        E.lin_layer(arena.p, n, P.nblocks, C.d_lin[l], (int)L.lin.size(), ctx->delta());
+        if (!L.pbs.empty()) {
+            E.pbs_layer(arena.p, n, P.nblocks, C.d_in[l], C.d_out[l], C.d_lut[l], (u32)L.pbs.size(), C.d_luts);
+            ctx->pbs_count += n * L.pbs.size();
+        }
+    }
+    const uint64_t out_stride = ct_bytes(P.out_width);
+    for (size_t j = 0; j < P.out.size(); ++j)
+        HC(hipMemcpy2DAsync(out + sizeof(CtHeader) + j * BLK_BYTES, out_stride,
+                            reinterpret_cast<uint8_t*>(arena.p) + (size_t)P.out[j] * BLK_BYTES, inst_bytes, BLK_BYTES, n,
+                            hipMemcpyDeviceToHost, st));
+    E.sync();
+    CtHeader h{CT_MAGIC, 1, (uint16_t)P.out_width, (uint32_t)P.out.size(), P.out_noise, P.out_degree, 0};
+    for (uint64_t i = 0; i < n; ++i) std::memcpy(out + i * out_stride, &h, sizeof h);
 }
 
 }  // namespace
@@ -62,7 +248,7 @@ static int32_t encrypt_impl(lfhe_ctx* ctx, const uint8_t value_le[32], uint32_t 
         CtHeader h{CT_MAGIC, 1, (uint16_t)bit_width, nb, 1, 3, 0};
         if (bit_width == 1) h.degree = 1;
         std::memcpy(out, &h, sizeof h);
-        std::vector<uint64_t> blk(N + 1);
+        std::vector<uint64_t> blk(BLK_WORDS);
         for (uint32_t i = 0; i < nb; ++i) {
             uint64_t m = bit_width == 1 ? (value_le[0] & 1u) : block_value(value_le, i);
             if (trivial) {
@@ -71,7 +257,7 @@ static int32_t encrypt_impl(lfhe_ctx* ctx, const uint8_t value_le[32], uint32_t 
             } else {
                 lwe_encrypt(ctx->glwe_sk.data(), N, m * ctx->delta(), ctx->prm.glwe_noise_log2, ctx->enc_rng, blk.data());
             }
-            std::memcpy(out + sizeof h + (size_t)i * (N + 1) * 8, blk.data(), (N + 1) * 8);
+            std::memcpy(out + sizeof h + (size_t)i * BLK_BYTES, blk.data(), BLK_BYTES);
         }
         *out_len = need;
         return LFHE_OK;
@@ -100,12 +286,12 @@ int32_t lfhe_decrypt(lfhe_ctx* ctx, const uint8_t* ct, uint64_t ct_len, uint8_t 
         return LFHE_ERR_FORMAT;
     }
     std::memset(value_le, 0, 32);
-    std::vector<uint64_t> blk(N + 1);
+    std::vector<uint64_t> blk(BLK_WORDS);
     // recombine base 4 with carries: blocks may hold values up to 15
     uint64_t carry = 0;
     const uint32_t bits = h.bit_width;
     for (uint32_t i = 0; i < h.nblocks; ++i) {
-        std::memcpy(blk.data(), ct + sizeof h + (size_t)i * (N + 1) * 8, (N + 1) * 8);
+        std::memcpy(blk.data(), ct + sizeof h + (size_t)i * BLK_BYTES, BLK_BYTES);
         const uint64_t phase = lwe_phase(ctx->glwe_sk.data(), N, blk.data());
         const uint64_t delta = ctx->delta();
         uint64_t m = ((phase + delta / 2) / delta) % ctx->space();
@@ -140,18 +326,70 @@ int32_t lfhe_op_from_name(const char* name) {
     return -1;
 }
 
-int32_t lfhe_evaluate(lfhe_ctx* ctx, uint32_t, uint32_t, const uint8_t*, uint64_t, const uint8_t*, uint64_t, int32_t,
-                      const uint8_t*, uint64_t, uint8_t*, uint64_t*) {
-    if (!ctx) return LFHE_ERR_ARG;
-    ctx->err = "operator layer not built yet";
-    return LFHE_ERR_UNSUPPORTED;
+int32_t lfhe_program_dump(uint32_t op, uint32_t bit_width, int32_t lhs_noise, int32_t rhs_noise, int32_t cond_noise,
+                          char* out, uint64_t* out_len) {
+    if (!out_len) return LFHE_ERR_ARG;
+    std::string js;
+    try {
+        if (!width_ok(bit_width)) return LFHE_ERR_ARG;
+        js = build_program(op, bit_width, lhs_noise, rhs_noise, cond_noise).to_json();
+    } catch (const std::invalid_argument&) {
+        return LFHE_ERR_UNSUPPORTED;
+    } catch (const std::exception&) {
+        return LFHE_ERR_STATE;
+    }
+    const uint64_t need = js.size() + 1;
+    if (!out) { *out_len = need; return LFHE_OK; }
+    if (*out_len < need) { *out_len = need; return LFHE_ERR_SIZE; }
+    std::memcpy(out, js.c_str(), need);
+    *out_len = need;
+    return LFHE_OK;
 }
 
-int32_t lfhe_evaluate_batch(lfhe_ctx* ctx, uint32_t, uint32_t, uint64_t, const uint8_t*, const uint8_t*, int32_t,
-                            const uint8_t*, uint8_t*) {
+int32_t lfhe_evaluate_batch(lfhe_ctx* ctx, uint32_t op, uint32_t bit_width, uint64_t n, const uint8_t* lhs,
+                            const uint8_t* rhs, int32_t rhs_is_scalar, const uint8_t* cond, uint8_t* out) {
     if (!ctx) return LFHE_ERR_ARG;
-    ctx->err = "operator layer not built yet";
-    return LFHE_ERR_UNSUPPORTED;
+    if (op == LFHE_OP_CAST || op == LFHE_OP_SHL || op == LFHE_OP_SHR || op == LFHE_OP_ROTL || op == LFHE_OP_ROTR ||
+        op == LFHE_OP_DIV || op == LFHE_OP_REM) {
+        ctx->err = "operator not supported in batch form yet";
+        return LFHE_ERR_UNSUPPORTED;
+    }
+    int32_t rc = guarded(ctx, [&]() -> int32_t {
+        run_batch(ctx, op, bit_width, n, lhs, rhs, rhs_is_scalar != 0, cond, out);
+        return LFHE_OK;
+    });
+    if (rc == LFHE_ERR_ARG && ctx->err == "operator not supported") rc = LFHE_ERR_UNSUPPORTED;
+    return rc;
+}
+
+int32_t lfhe_evaluate(lfhe_ctx* ctx, uint32_t op, uint32_t bit_width, const uint8_t* lhs, uint64_t lhs_len,
+                      const uint8_t* rhs, uint64_t rhs_len, int32_t rhs_is_scalar, const uint8_t* cond,
+                      uint64_t cond_len, uint8_t* out, uint64_t* out_len) {
+    if (!ctx) return LFHE_ERR_ARG;
+    if (!out_len || !width_ok(bit_width)) { ctx->err = "bad argument"; return LFHE_ERR_ARG; }
+    const bool cmp = op >= LFHE_OP_EQ && op <= LFHE_OP_LT;
+    const uint64_t need = ct_bytes(cmp ? 1 : bit_width);
+    if (!out) { *out_len = need; return LFHE_OK; }
+    if (*out_len < need) { *out_len = need; return LFHE_ERR_SIZE; }
+    if (op == LFHE_OP_CAST) {
+        const int32_t rc = guarded(ctx, [&]() -> int32_t {
+            if (!lhs) throw std::invalid_argument("null operand");
+            cast_one(ctx, lhs, lhs_len, bit_width, out);
+            return LFHE_OK;
+        });
+        if (rc == LFHE_OK) *out_len = need;
+        return rc;
+    }
+    const bool unary = op == LFHE_OP_NOT || op == LFHE_OP_NEG;
+    if (!lhs || lhs_len != ct_bytes(bit_width) || (!unary && !rhs) ||
+        (!unary && rhs_len != (rhs_is_scalar ? 32u : ct_bytes(bit_width))) ||
+        (op == LFHE_OP_SELECT && (!cond || cond_len != ct_bytes(1)))) {
+        ctx->err = "operand length does not match the bit width";
+        return LFHE_ERR_ARG;
+    }
+    const int32_t rc = lfhe_evaluate_batch(ctx, op, bit_width, 1, lhs, rhs, rhs_is_scalar, cond, out);
+    if (rc == LFHE_OK) *out_len = need;
+    return rc;
 }
 
 int32_t lfhe_pbs_count(const lfhe_ctx* ctx, uint64_t* out) {

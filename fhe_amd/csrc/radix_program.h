@@ -1,0 +1,114 @@
+// Radix integer operators as programs over ciphertext blocks.
+//
+// An encrypted integer is a little-endian vector of blocks, each an LWE ciphertext holding a value
+// in [0,16): two message bits, two carry bits, one padding bit above them.  Every operator is
+// compiled once per (operator, width, input noise) into a Program: a list of layers, each made of
+// linear combinations of blocks (free of bootstraps) followed by independent programmable
+// bootstraps.  The executor (radix.cpp) replays the program for a whole batch of independent
+// instances at once, so every layer becomes one key-switch launch and one blind-rotation launch
+// over instances x bootstraps-per-layer ciphertexts.
+//
+// The builder tracks, for every block, the range of values it can hold and its noise level in
+// units of one bootstrap output (the parameter set allows 5), and refuses to build a program that
+// would overflow the 4-bit block or exceed the noise budget.
+#pragma once
+#include <stdint.h>
+
+#include <array>
+#include <functional>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace lfhe {
+
+constexpr int LIN_MAX_TERMS = 6;
+
+struct LinOp {  // out = sum coef[k] * block[src[k]] + cst * delta   (plain data: copied to the device)
+    uint32_t out, n;
+    uint32_t src[LIN_MAX_TERMS];
+    int32_t coef[LIN_MAX_TERMS];
+    int32_t cst;
+};
+struct PbsOp {
+    uint32_t in, out, lut;
+};
+struct Layer {
+    std::vector<LinOp> lin;
+    std::vector<PbsOp> pbs;
+};
+
+struct Program {
+    uint32_t op = 0, width = 0, out_width = 0;
+    uint32_t nblocks = 0;                  // arena blocks per instance
+    std::vector<uint32_t> lhs, rhs, cond;  // input block ids
+    std::vector<uint32_t> out;             // output block ids, little-endian
+    std::vector<std::array<uint64_t, 16>> luts;
+    std::vector<Layer> layers;
+    uint8_t out_noise = 1, out_degree = 3;
+    uint64_t pbs_per_instance() const {
+        uint64_t s = 0;
+        for (const auto& l : layers) s += l.pbs.size();
+        return s;
+    }
+    std::string to_json() const;
+};
+
+constexpr int MAX_NOISE = 5;   // max_noise_level of the parameter set
+constexpr int BLOCK_MAX = 15;  // message + carry bits
+
+class Builder {
+public:
+    struct Expr {
+        std::vector<std::pair<int, uint32_t>> t;  // (coefficient, block)
+        int cst = 0;
+    };
+    Program P;
+
+    uint32_t input(int hi, int noise) { return new_block(0, 0, hi, noise); }
+    Expr E(uint32_t b) const { Expr e; e.t.push_back({1, b}); return e; }
+    static Expr C(int c) { Expr e; e.cst = c; return e; }
+    static Expr add(Expr a, const Expr& b) {
+        for (auto& x : b.t) a.t.push_back(x);
+        a.cst += b.cst;
+        return a;
+    }
+    static Expr scale(Expr a, int c) {
+        for (auto& x : a.t) x.first *= c;
+        a.cst *= c;
+        return a;
+    }
+    static Expr sub(const Expr& a, const Expr& b) { return add(a, scale(b, -1)); }
+
+    // bootstrap of e through the table f : [0,16) -> [0,16)
+    uint32_t pbs(const Expr& e, const std::function<int(int)>& f);
+    // e as a block (a linear op unless e already is a plain block); hi_known >= 0 overrides the
+    // interval bound when the caller knows a tighter one (e.g. a sum whose terms exclude each other)
+    uint32_t mat(const Expr& e, int hi_known = -1);
+    int hi(uint32_t b) const { return info_[b].hi; }
+    int noise(uint32_t b) const { return info_[b].noise; }
+    void finish();
+
+private:
+    struct Info { int level, lo, hi, noise; };
+    std::vector<Info> info_;
+    std::map<std::array<uint64_t, 16>, uint32_t> lut_ids_;
+    uint32_t new_block(int level, int lo, int hi, int noise) {
+        info_.push_back({level, lo, hi, noise});
+        return P.nblocks++;
+    }
+    Info eval(const Expr& e) const;
+    Layer& layer(int l) {
+        if ((int)P.layers.size() <= l) P.layers.resize(l + 1);
+        return P.layers[l];
+    }
+    uint32_t lut_id(const std::function<int(int)>& f);
+    uint32_t lin(const Expr& e, const Info& i);
+};
+
+// operator ids are the LFHE_OP_* values of include/lfhe.h
+Program build_program(uint32_t op, uint32_t width, int lhs_noise, int rhs_noise, int cond_noise);
+
+}  // namespace lfhe

@@ -131,6 +131,12 @@ int32_t lfhe_evaluate(lfhe_ctx* ctx, uint32_t op, uint32_t bit_width, const uint
  * is lfhe_ciphertext_size of its width (cond: width 1); scalars are 32 bytes each. */
 int32_t lfhe_evaluate_batch(lfhe_ctx* ctx, uint32_t op, uint32_t bit_width, uint64_t n, const uint8_t* lhs,
                             const uint8_t* rhs, int32_t rhs_is_scalar, const uint8_t* cond, uint8_t* out);
+/* The bootstrap schedule of an operator as JSON (layers of linear combinations and bootstraps over
+ * block ids, the lookup tables, input/output block ids).  Needs no context and no GPU: it is the
+ * host-side plan the executor replays, exposed for inspection and for checking the plan against a
+ * plaintext model. */
+int32_t lfhe_program_dump(uint32_t op, uint32_t bit_width, int32_t lhs_noise, int32_t rhs_noise, int32_t cond_noise,
+                          char* out, uint64_t* out_len);
 /* cumulative count of programmable bootstraps issued by this context */
 int32_t lfhe_pbs_count(const lfhe_ctx* ctx, uint64_t* out);
 

@@ -1,0 +1,103 @@
+"""Host logic of the integer operators, no GPU: the bootstrap schedule the library builds for each
+operator is interpreted on clear blocks and must reproduce every known answer of the reference's
+operator suite (tests/golden/fhevm_operator_kats.json, extracted by tools/extract_kats.py), while
+never leaving the 4-bit block or the noise budget; a few schedules are also run on real ciphertexts
+with the CPU oracle at small parameters."""
+import json
+import os
+import random
+
+import pytest
+
+from fhe_amd.native import program, OPS, LfheError
+from oracle import radix
+from oracle.oracle import Oracle, Params, Rng, seed_bytes
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+KATS = json.load(open(os.path.join(GOLDEN, "fhevm_operator_kats.json")))["kats"]
+SELECT_KATS = json.load(open(os.path.join(GOLDEN, "fhevm_select_kats.json")))["kats"]
+PROGRAM_OPS = {"add", "sub", "mul", "eq", "ne", "ge", "gt", "le", "lt", "min", "max", "and", "or", "xor", "not",
+               "neg", "select"}
+_cache = {}
+
+
+def prog(op, w, ln=1, rn=1, cn=1):
+    key = (op, w, ln, rn, cn)
+    if key not in _cache:
+        _cache[key] = program(op, w, ln, rn, cn)
+    return _cache[key]
+
+
+def test_reference_vectors_follow_the_clear_semantics():
+    """The restated clear semantics (wrapping mod 2^w, promotion to the wider type, shift amounts
+    mod w) reproduce all 2394 reference vectors."""
+    assert len(KATS) == 2394
+    for k in KATS:
+        op, w, ins, exp = radix.kat_case(k)
+        got = radix.clear_op(op, w, ins[0], ins[1] if len(ins) > 1 else None)
+        assert got == exp, k
+
+
+def test_programs_reproduce_every_reference_vector():
+    done = skipped = 0
+    for k in KATS:
+        op, w, ins, exp = radix.kat_case(k)
+        if op not in PROGRAM_OPS:
+            skipped += 1
+            continue
+        got = radix.run_plain(prog(op, w), ins[0], ins[1] if len(ins) > 1 else None)
+        assert got == exp, k
+        done += 1
+    assert done == 2394 - skipped and done >= 2100
+
+
+def test_select_vectors():
+    for k in SELECT_KATS:
+        w = k["width"]
+        got = radix.run_plain(prog("select", w), k["a"], k["b"], k["cond"])
+        assert got == k["expected"], k
+
+
+@pytest.mark.parametrize("w", [1, 8, 16, 32, 64, 128, 256])
+def test_programs_on_random_and_edge_inputs(w):
+    rnd = random.Random(w)
+    m = (1 << w) - 1
+    edge = [0, 1, m, m - 1, m >> 1, (m >> 1) + 1]
+    pairs = [(a, b) for a in edge for b in edge] + [(rnd.randrange(m + 1), rnd.randrange(m + 1)) for _ in range(40)]
+    ops = ["eq", "ne", "and", "or", "xor", "not", "select"] if w == 1 else sorted(PROGRAM_OPS)
+    if w > 64:
+        pairs = pairs[:12] + pairs[36:44]
+    for op in ops:
+        for noises in ((1, 1, 1), (2, 2, 2)):
+            p = prog(op, w, *noises)
+            for a, b in pairs:
+                c = (a ^ b) & 1
+                want = radix.clear_op(op, w, a, b, c)
+                assert radix.run_plain(p, a, b, c) == want, (op, w, a, b)
+
+
+def test_schedule_sizes_are_reported():
+    """Bootstraps per operation (the scheduler's own count; the reference publishes none)."""
+    want_at_most = {("add", 64): 230, ("mul", 64): 2000, ("lt", 64): 63, ("eq", 64): 45, ("select", 64): 64}
+    for (op, w), cap in want_at_most.items():
+        p = prog(op, w)
+        assert p["pbs"] == sum(len(l["pbs"]) for l in p["layers"]) <= cap, (op, w, p["pbs"])
+
+
+def test_unsupported_operator_is_an_error():
+    with pytest.raises(LfheError):
+        program("cast", 8)
+
+
+def test_programs_on_real_ciphertexts_small_parameters():
+    """Full cryptography on the CPU: the same schedules over LWE blocks with the oracle's PBS."""
+    orc = Oracle(Params(lwe_dim=24, poly_size=512, lwe_noise_log2=36, glwe_noise_log2=12))
+    keys = orc.gen_keys(seed_bytes(41))
+    pb = orc.prepare_bsk(keys[2])
+    r = Rng(seed_bytes(42))
+    cases = [("add", 8, 200, 100, 0), ("sub", 8, 3, 250, 0), ("mul", 8, 23, 45, 0), ("lt", 8, 77, 78, 0),
+             ("ge", 8, 78, 78, 0), ("eq", 8, 5, 5, 0), ("select", 8, 11, 22, 1), ("max", 8, 9, 200, 0),
+             ("xor", 8, 0xAA, 0x0F, 0), ("neg", 8, 1, 0, 0)]
+    for op, w, a, b, c in cases:
+        got = radix.run_oracle(prog(op, w), orc, keys, pb, r, a, b, c)
+        assert got == radix.clear_op(op, w, a, b, c), (op, a, b)
