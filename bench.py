@@ -76,6 +76,7 @@ def main():
 
     import torch
     from fhe_amd.native import Context, KEY_CLIENT
+    from fhe_amd.sharding import max_over_ranks, replicate, replicate_blob
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -108,16 +109,14 @@ def main():
         else:
             tb = torch.empty(bsk_bytes, dtype=torch.uint8, device=dev)
             tk = torch.empty(ksk_bytes, dtype=torch.uint8, device=dev)
-        dist.broadcast(tb, src=0)
-        dist.broadcast(tk, src=0)
+        replicate(dist, [tb, tk])
         torch.cuda.synchronize()
         if rank != 0:
             ctx.attach_device_keys(tb.data_ptr(), tk.data_ptr())
             keep += [tb, tk]
-        blob = [client_blob if rank == 0 else None]
-        dist.broadcast_object_list(blob, src=0)
+        blob = replicate_blob(dist, client_blob if rank == 0 else None)
         if rank != 0:
-            ctx.import_keys(KEY_CLIENT, blob[0])
+            ctx.import_keys(KEY_CLIENT, blob)
 
     # synthetic inputs: batch blocks = batch/4 euint8 values, fresh encryptions, distinct per rank
     B = args.batch
@@ -153,9 +152,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = max_over_ranks(dist, elapsed, dev)
 
     # correctness of what was timed: every sampled output decrypts to f(m)
     out = d_out.cpu().numpy().view(np.uint64)

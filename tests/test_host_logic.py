@@ -1,0 +1,109 @@
+"""CPU-side checks: the C ABI library loads and exports every declared entry point, error paths
+that need no GPU, and the multi-process layout (gloo, two ranks) of the sharded path."""
+import ctypes
+import os
+import re
+import socket
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from fhe_amd import native
+    hdr = open(os.path.join(ROOT, "include", "lfhe.h")).read()
+    declared = sorted(set(re.findall(r"\b(lfhe_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 36
+    lib = ctypes.CDLL(native.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/lfhe.h but not exported"
+    L = native.load()
+    assert sorted(L._declared) == declared, "ctypes binding and header disagree"
+    assert L.lfhe_version().startswith(b"lfhe")
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    from fhe_amd import native
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(native.LfheError):
+        native.Context()
+
+
+def test_context_free_entry_points():
+    from fhe_amd import native
+    L = native.load()
+    p = native.Params()
+    L.lfhe_default_params(ctypes.byref(p))
+    assert (p.lwe_dim, p.poly_size, p.pbs_base_log, p.ks_level) == (918, 2048, 23, 4)
+    assert L.lfhe_op_from_name(b"add") == 0 and L.lfhe_op_from_name(b"select") == 16
+    assert L.lfhe_op_from_name(b"nope") == -1
+    assert L.lfhe_ctx_create(None, 1, 0, bytes(32)) == -1          # LFHE_ERR_ARG
+    h = ctypes.c_void_p()
+    assert L.lfhe_ctx_create(ctypes.byref(h), 99, 0, bytes(32)) == -5  # unknown parameter set
+    assert L.lfhe_last_error(None) == b"null context"
+
+
+def test_shard_bounds_cover_everything():
+    from fhe_amd.sharding import shard_bounds
+    for total in (0, 1, 7, 4096, 10000):
+        for world in (1, 2, 3, 8):
+            cuts = [shard_bounds(total, world, r) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+            sizes = [hi - lo for lo, hi in cuts]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(10, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_main(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from fhe_amd.sharding import shard_bounds, replicate, replicate_blob, max_over_ranks
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # key images: rank 0 holds them, the others receive into preallocated buffers
+    g = torch.Generator().manual_seed(7)
+    bsk = torch.randint(0, 256, (1 << 16,), dtype=torch.uint8, generator=g) if rank == 0 else torch.zeros(1 << 16, dtype=torch.uint8)
+    ksk = torch.randint(0, 256, (1 << 12,), dtype=torch.uint8, generator=g) if rank == 0 else torch.zeros(1 << 12, dtype=torch.uint8)
+    replicate(dist, [bsk, ksk])
+    blob = replicate_blob(dist, b"client-key" if rank == 0 else None)
+    # data path: each rank works on its own slice, no collective; results gathered by the host
+    lo, hi = shard_bounds(1001, world, rank)
+    part = [(7 * i + 3) % 16 for i in range(lo, hi)]
+    t = max_over_ranks(dist, 1.0 + rank)
+    q.put((rank, int(bsk.sum()), int(ksk.sum()), blob, (lo, hi), part, t))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_layout_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, b0, k0, blob0, cut0, part0, t0), (r1, b1, k1, blob1, cut1, part1, t1) = got
+    assert (b0, k0) == (b1, k1) and b0 > 0          # both ranks hold the same key images
+    assert blob0 == blob1 == b"client-key"
+    assert cut0 == (0, 501) and cut1 == (501, 1001)
+    assert part0 + part1 == [(7 * i + 3) % 16 for i in range(1001)]
+    assert t0 == t1 == 2.0                          # max over ranks
