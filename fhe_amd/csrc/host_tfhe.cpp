@@ -125,6 +125,31 @@ void gen_ksk(const EngineParams& p, const uint64_t* glwe_sk, const uint64_t* lwe
     });
 }
 
+void gen_public_key(const EngineParams& p, const uint64_t* glwe_sk, const uint8_t seed[32], uint64_t* pk) {
+    ChaCha r(seed, 5);
+    uint64_t* a = pk;
+    uint64_t* b = pk + N;
+    for (int j = 0; j < N; ++j) a[j] = r.next();
+    for (int j = 0; j < N; ++j) b[j] = r.tuniform(p.glwe_noise_log2);
+    add_mask_times_binary_key(a, glwe_sk, b);
+}
+
+void pk_encrypt_blocks(const EngineParams& p, const uint64_t* pk, const uint64_t* plaintexts, size_t count,
+                       ChaCha& r, uint64_t* out) {
+    std::vector<uint64_t> u(N), c0(N), c1(N);
+    gen_binary_key(r, u.data(), N);
+    for (int j = 0; j < N; ++j) c0[j] = r.tuniform(p.glwe_noise_log2);
+    for (int j = 0; j < N; ++j) c1[j] = r.tuniform(p.glwe_noise_log2) + ((size_t)j < count ? plaintexts[j] : 0);
+    add_mask_times_binary_key(pk, u.data(), c0.data());       // c0 = a (*) u + e1
+    add_mask_times_binary_key(pk + N, u.data(), c1.data());   // c1 = b (*) u + e2 + M
+    for (size_t i = 0; i < count; ++i) {
+        uint64_t* o = out + i * (size_t)(N + 1);
+        for (size_t j = 0; j <= i; ++j) o[j] = c0[i - j];
+        for (size_t j = i + 1; j < (size_t)N; ++j) o[j] = 0 - c0[N + i - j];
+        o[N] = c1[i];
+    }
+}
+
 void make_lut_body(uint32_t space, uint64_t delta, const uint64_t* table, uint64_t* body) {
     const uint32_t box = N / space, half = box / 2;
     std::vector<uint64_t> tmp(N);

@@ -39,6 +39,14 @@ void gen_bsk(const EngineParams& p, const uint64_t* lwe_sk, const uint64_t* glwe
 void gen_ksk(const EngineParams& p, const uint64_t* glwe_sk, const uint64_t* lwe_sk, const uint8_t seed[32],
              uint64_t* ksk, int threads);
 
+// Compact (RLWE) public key under the GLWE secret key: pk = (a, b = a (*) s + e), 2N words.
+void gen_public_key(const EngineParams& p, const uint64_t* glwe_sk, const uint8_t seed[32], uint64_t* pk);
+// Public-key encryption of up to N plaintexts (already scaled by delta) into LWE blocks under the
+// flattened GLWE key: one RLWE encryption (u binary, c0 = a u + e1, c1 = b u + e2 + M), then the
+// sample extraction of coefficient i for block i.  out: [count][N+1].
+void pk_encrypt_blocks(const EngineParams& p, const uint64_t* pk, const uint64_t* plaintexts, size_t count,
+                       ChaCha& r, uint64_t* out);
+
 // body polynomial of the accumulator of f given as a table over [0, space): box-encoded, rotated
 // left by half a box with the wrapped part negated
 void make_lut_body(uint32_t space, uint64_t delta, const uint64_t* table, uint64_t* body /* [N] */);

@@ -306,10 +306,53 @@ int32_t lfhe_decrypt(lfhe_ctx* ctx, const uint8_t* ct, uint64_t ct_len, uint8_t 
     return LFHE_OK;
 }
 
-int32_t lfhe_public_key(lfhe_ctx* ctx, uint8_t*, uint64_t*) {
-    if (!ctx) return LFHE_ERR_ARG;
-    ctx->err = "public-key encryption is not built yet";
-    return LFHE_ERR_UNSUPPORTED;
+namespace {
+constexpr uint32_t PK_MAGIC = 0x4b50464cu;  // "LFPK"
+struct PkHeader { uint32_t magic, poly_size, noise_log2, reserved; };
+constexpr uint64_t PK_BYTES = sizeof(PkHeader) + 2ull * N * 8;
+}  // namespace
+
+int32_t lfhe_public_key(lfhe_ctx* ctx, uint8_t* out, uint64_t* out_len) {
+    return guarded(ctx, [&]() -> int32_t {
+        if (!out_len) throw std::invalid_argument("null out_len");
+        if (!out) { *out_len = PK_BYTES; return LFHE_OK; }
+        if (*out_len < PK_BYTES) { *out_len = PK_BYTES; return LFHE_ERR_SIZE; }
+        if (!ctx->have_client) throw std::logic_error("no client key: call lfhe_keygen or import one");
+        PkHeader h{PK_MAGIC, (uint32_t)N, ctx->prm.glwe_noise_log2, 0};
+        std::vector<uint64_t> pk(2 * N);
+        gen_public_key(ctx->prm, ctx->glwe_sk.data(), ctx->seed, pk.data());
+        std::memcpy(out, &h, sizeof h);
+        std::memcpy(out + sizeof h, pk.data(), pk.size() * 8);
+        *out_len = PK_BYTES;
+        return LFHE_OK;
+    });
+}
+
+int32_t lfhe_encrypt_public(lfhe_ctx* ctx, const uint8_t* pk, uint64_t pk_len, const uint8_t value_le[32],
+                            uint32_t bit_width, uint8_t* out, uint64_t* out_len) {
+    return guarded(ctx, [&]() -> int32_t {
+        if (!value_le || !out_len) throw std::invalid_argument("null pointer");
+        if (!width_ok(bit_width)) throw std::invalid_argument("unsupported bit width");
+        const uint64_t need = ct_bytes(bit_width);
+        if (!out) { *out_len = need; return LFHE_OK; }
+        if (*out_len < need) { *out_len = need; return LFHE_ERR_SIZE; }
+        PkHeader h;
+        if (!pk || pk_len != PK_BYTES) throw std::invalid_argument("malformed public key");
+        std::memcpy(&h, pk, sizeof h);
+        if (h.magic != PK_MAGIC || h.poly_size != (uint32_t)N) throw std::invalid_argument("malformed public key");
+        const uint32_t nb = blocks_of(bit_width);
+        std::vector<uint64_t> key(2 * N), pt(nb);
+        std::memcpy(key.data(), pk + sizeof h, key.size() * 8);
+        for (uint32_t i = 0; i < nb; ++i)
+            pt[i] = (uint64_t)(bit_width == 1 ? (value_le[0] & 1u) : block_value(value_le, i)) * ctx->delta();
+        CtHeader ch{CT_MAGIC, 1, (uint16_t)bit_width, nb, 1, (uint8_t)(bit_width == 1 ? 1 : 3), 0};
+        std::memcpy(out, &ch, sizeof ch);
+        std::vector<uint64_t> blocks((size_t)nb * BLK_WORDS);
+        pk_encrypt_blocks(ctx->prm, key.data(), pt.data(), nb, ctx->enc_rng, blocks.data());
+        std::memcpy(out + sizeof ch, blocks.data(), blocks.size() * 8);
+        *out_len = need;
+        return LFHE_OK;
+    });
 }
 
 int32_t lfhe_op_from_name(const char* name) {

@@ -68,6 +68,7 @@ def load():
         "lfhe_device_keys_attach": (i32, [vp, vp, vp]),
         "lfhe_encrypt": (i32, [vp, C.c_char_p, u32, vp, pu64]),
         "lfhe_trivial_encrypt": (i32, [vp, C.c_char_p, u32, vp, pu64]),
+        "lfhe_encrypt_public": (i32, [vp, vp, u64, C.c_char_p, u32, vp, pu64]),
         "lfhe_decrypt": (i32, [vp, vp, u64, vp, pu32]),
         "lfhe_ciphertext_size": (i32, [vp, u32, pu64]),
         "lfhe_op_from_name": (i32, [C.c_char_p]),
@@ -218,6 +219,22 @@ class Context:
         buf = np.zeros(n.value, dtype=np.uint8)
         fn = self._L.lfhe_trivial_encrypt if trivial else self._L.lfhe_encrypt
         self._ck(fn(self._h, le32(value % (1 << max(bit_width, 1))), bit_width, _ptr(buf), C.byref(n)))
+        return buf.tobytes()
+
+    def public_key(self) -> bytes:
+        n = C.c_uint64(0)
+        self._ck(self._L.lfhe_public_key(self._h, None, C.byref(n)))
+        buf = np.zeros(n.value, dtype=np.uint8)
+        self._ck(self._L.lfhe_public_key(self._h, _ptr(buf), C.byref(n)))
+        return buf.tobytes()
+
+    def encrypt_public(self, pk: bytes, value: int, bit_width: int) -> bytes:
+        """Encrypt with the public key only (works on a context that holds no secret key)."""
+        key = np.frombuffer(pk, dtype=np.uint8)
+        n = C.c_uint64(self.ciphertext_size(bit_width))
+        buf = np.zeros(n.value, dtype=np.uint8)
+        self._ck(self._L.lfhe_encrypt_public(self._h, _ptr(key), key.size, le32(value % (1 << max(bit_width, 1))),
+                                             bit_width, _ptr(buf), C.byref(n)))
         return buf.tobytes()
 
     def decrypt(self, ct: bytes) -> int:

@@ -1,0 +1,208 @@
+"""HTTP surface of the engine, as the reference's clients speak it (default :8448).
+
+Mirrors what the reference tree shows of the absent `fhe-server`:
+  GET  /health     -> {"status":"ok","threshold":bool,"parties":int}      e2e/test/fhe.test.ts:31-37
+  GET  /publickey  -> raw bytes, or {"publicKey":[...]} for JSON clients   luxfhejs/src/index.ts:63-72,
+                                                                           hardhat-plugin/src/index.ts:80-87
+  POST /encrypt    {value,bitWidth} -> raw ciphertext bytes                luxfhejs/src/index.ts:127-141
+                   {value:"..",type:"uint32"} -> {"ciphertext":[...]}      hardhat-plugin/src/index.ts:57-67
+  POST /decrypt    {ciphertext:[...]} -> {"value":".."}                    hardhat-plugin/src/index.ts:69-78
+  POST /evaluate   {op,left,right,bitWidth[,cond]} -> raw ciphertext bytes e2e/test/fhe.test.ts:105-175
+  POST /verify     any body -> {"verified":true}                           e2e/test/fhe.test.ts:178-189
+Errors: non-2xx with a text body (luxfhejs/src/index.ts:134-137 reads res.text()).
+CLI flags as the reference starts its server: -addr :8448 [-threshold] [-parties N]
+(e2e/scripts/start-server.sh:17, local-dev/docker-compose.yml:29).
+
+The backend is the GPU library; there is no CPU engine behind this server.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import re
+import threading
+from http.server import BaseHTTPRequestHandler, ThreadingHTTPServer
+
+WIDTHS = (1, 8, 16, 32, 64, 128, 160, 256)
+
+
+class GpuBackend:
+    """liblfhe behind the HTTP surface: one context, requests serialised on it."""
+
+    def __init__(self, seed: bytes = bytes(32), device: int = 0):
+        from .native import Context
+        self.ctx = Context(seed=seed, device=device)
+        self.ctx.keygen()
+        self._pk = None
+
+    def health(self) -> dict:
+        return json.loads(self.ctx.health())
+
+    def public_key(self) -> bytes:
+        if self._pk is None:
+            self._pk = self.ctx.public_key()
+        return self._pk
+
+    def encrypt(self, value: int, width: int) -> bytes:
+        return self.ctx.encrypt(value, width)
+
+    def decrypt(self, ct: bytes) -> int:
+        return self.ctx.decrypt(ct)
+
+    def evaluate(self, op: str, width: int, left: bytes, right, cond) -> bytes:
+        return self.ctx.evaluate(op, width, left, right, cond)
+
+
+def _bytes_field(v) -> bytes:
+    if isinstance(v, list):
+        return bytes(v)
+    if isinstance(v, str):
+        return bytes.fromhex(v[2:] if v.startswith("0x") else v)
+    raise ValueError("ciphertext must be an array of bytes or a hex string")
+
+
+def _width_of(body: dict) -> int:
+    if "bitWidth" in body:
+        w = int(body["bitWidth"])
+    elif "type" in body:
+        t = str(body["type"])
+        w = 1 if t in ("bool", "ebool") else 160 if t in ("address", "eaddress") else int(re.sub(r"\D", "", t) or 0)
+    else:
+        w = 32   # the hardhat plugin's default type is uint32
+    if w not in WIDTHS:
+        raise ValueError(f"unsupported bit width {w}")
+    return w
+
+
+def make_handler(backend, threshold: bool, parties: int):
+    lock = threading.Lock()
+
+    class Handler(BaseHTTPRequestHandler):
+        protocol_version = "HTTP/1.1"
+
+        def log_message(self, *a):  # quiet
+            pass
+
+        def _send(self, code: int, body: bytes, ctype: str):
+            self.send_response(code)
+            self.send_header("Content-Type", ctype)
+            self.send_header("Content-Length", str(len(body)))
+            self.end_headers()
+            self.wfile.write(body)
+
+        def _json(self, obj, code=200):
+            self._send(code, json.dumps(obj).encode(), "application/json")
+
+        def _raw(self, b: bytes):
+            self._send(200, b, "application/octet-stream")
+
+        def _fail(self, code: int, msg: str):
+            self._send(code, msg.encode(), "text/plain")
+
+        def _wants_json(self) -> bool:
+            return "application/json" in (self.headers.get("Accept") or "")
+
+        def do_GET(self):
+            try:
+                if self.path == "/health":
+                    with lock:
+                        h = dict(backend.health())
+                    h.update({"status": "ok", "threshold": threshold, "parties": parties})
+                    self._json(h)
+                elif self.path == "/publickey":
+                    with lock:
+                        pk = backend.public_key()
+                    if self._wants_json():
+                        self._json({"publicKey": list(pk)})
+                    else:
+                        self._raw(pk)
+                else:
+                    self._fail(404, "not found")
+            except Exception as e:  # engine failure -> 500 with the text the clients print
+                self._fail(500, str(e))
+
+        def do_POST(self):
+            try:
+                n = int(self.headers.get("Content-Length") or 0)
+                data = self.rfile.read(n)
+                if self.path == "/verify":
+                    self._json({"verified": True})
+                    return
+                try:
+                    body = json.loads(data or b"{}")
+                    if not isinstance(body, dict):
+                        raise ValueError("JSON object expected")
+                except ValueError as e:
+                    self._fail(400, f"bad request: {e}")
+                    return
+                if self.path == "/encrypt":
+                    try:
+                        w = _width_of(body)
+                        value = int(body["value"])
+                        if value < 0 or value >> w:
+                            raise ValueError("value out of range for the bit width")
+                    except (KeyError, ValueError) as e:
+                        self._fail(400, f"bad request: {e}")
+                        return
+                    with lock:
+                        ct = backend.encrypt(value, w)
+                    if "type" in body or self._wants_json():
+                        self._json({"ciphertext": list(ct)})
+                    else:
+                        self._raw(ct)
+                elif self.path == "/decrypt":
+                    try:
+                        ct = _bytes_field(body["ciphertext"])
+                    except (KeyError, ValueError) as e:
+                        self._fail(400, f"bad request: {e}")
+                        return
+                    with lock:
+                        v = backend.decrypt(ct)
+                    self._json({"value": str(v)})
+                elif self.path == "/evaluate":
+                    try:
+                        op = str(body["op"])
+                        w = _width_of(body)
+                        left = _bytes_field(body["left"])
+                        right = body.get("right")
+                        right = int(body["scalar"]) if "scalar" in body else (None if right is None else _bytes_field(right))
+                        cond = body.get("cond")
+                        cond = None if cond is None else _bytes_field(cond)
+                    except (KeyError, ValueError) as e:
+                        self._fail(400, f"bad request: {e}")
+                        return
+                    with lock:
+                        out = backend.evaluate(op, w, left, right, cond)
+                    self._raw(out)
+                else:
+                    self._fail(404, "not found")
+            except KeyError as e:
+                self._fail(400, f"unknown operator {e}")
+            except Exception as e:
+                self._fail(500, str(e))
+
+    return Handler
+
+
+def serve(backend, addr: str = ":8448", threshold: bool = False, parties: int = 1) -> ThreadingHTTPServer:
+    host, _, port = addr.rpartition(":")
+    srv = ThreadingHTTPServer((host or "0.0.0.0", int(port)), make_handler(backend, threshold, parties))
+    return srv
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="fhe-server", description=__doc__.split("\n")[0])
+    ap.add_argument("-addr", "--addr", default=":8448")
+    ap.add_argument("-threshold", "--threshold", action="store_true")
+    ap.add_argument("-parties", "--parties", type=int, default=1)
+    ap.add_argument("--device", type=int, default=0)
+    args = ap.parse_args(argv)
+    if args.threshold:
+        raise SystemExit("threshold decryption is outside this backend's scope: run without -threshold")
+    srv = serve(GpuBackend(device=args.device), args.addr, False, args.parties)
+    print(f"fhe-server (gfx950) listening on {args.addr}")
+    srv.serve_forever()
+
+
+if __name__ == "__main__":
+    main()

@@ -83,6 +83,7 @@ int32_t lfhe_server_keys_import_raw(lfhe_ctx* ctx, const uint64_t* bsk, uint64_t
                                     uint64_t ksk_words);
 /* raw import of the secret keys: lwe_sk[n], glwe_sk[N], words holding 0 or 1 */
 int32_t lfhe_client_keys_import_raw(lfhe_ctx* ctx, const uint64_t* lwe_sk, const uint64_t* glwe_sk);
+/* compact public key (an RLWE encryption of zero under the GLWE key, 2N words + header) */
 int32_t lfhe_public_key(lfhe_ctx* ctx, uint8_t* out, uint64_t* out_len);
 /* device images of the server keys, for replication to other GPUs (one broadcast per key set, no
  * per-operation collective): sizes, the pointers owned by this context, and attaching images that
@@ -100,6 +101,10 @@ int32_t lfhe_device_keys_attach(lfhe_ctx* ctx, void* bsk_dev, void* ksk_dev);
 int32_t lfhe_encrypt(lfhe_ctx* ctx, const uint8_t value_le[32], uint32_t bit_width, uint8_t* out, uint64_t* out_len);
 int32_t lfhe_trivial_encrypt(lfhe_ctx* ctx, const uint8_t value_le[32], uint32_t bit_width, uint8_t* out,
                              uint64_t* out_len);
+/* client-side encryption with the public key alone (no secret key, no GPU work).  Replaces: the
+ * compact-list encryption of sdk/relayer/src/sdk/encrypt.ts:54-196 (without its ZK proof). */
+int32_t lfhe_encrypt_public(lfhe_ctx* ctx, const uint8_t* pk, uint64_t pk_len, const uint8_t value_le[32],
+                            uint32_t bit_width, uint8_t* out, uint64_t* out_len);
 int32_t lfhe_decrypt(lfhe_ctx* ctx, const uint8_t* ct, uint64_t ct_len, uint8_t value_le[32], uint32_t* bit_width);
 int32_t lfhe_ciphertext_size(const lfhe_ctx* ctx, uint32_t bit_width, uint64_t* out_len);
 

@@ -1,0 +1,95 @@
+"""The engine's HTTP surface and the SDK-named client, restating the reference's black-box suite
+(e2e/test/fhe.test.ts:17-191) and the two client encodings (luxfhejs raw bytes, hardhat-plugin
+JSON).  CPU: against the plaintext mock backend; GPU: against the real library, where the results
+are also decrypted (the reference suite never decrypts)."""
+import json
+import threading
+import urllib.request
+
+import pytest
+
+from fhe_amd.client import LuxFHEClient
+from fhe_amd.server import serve
+
+
+def _start(backend):
+    srv = serve(backend, "127.0.0.1:0")
+    th = threading.Thread(target=srv.serve_forever, daemon=True)
+    th.start()
+    return srv, f"http://127.0.0.1:{srv.server_address[1]}"
+
+
+def _post(url, body, accept=None):
+    req = urllib.request.Request(url, data=json.dumps(body).encode(), method="POST",
+                                 headers={"Content-Type": "application/json", **({"Accept": accept} if accept else {})})
+    with urllib.request.urlopen(req, timeout=600) as r:
+        return r.status, r.read()
+
+
+def _suite(url, decrypts: bool):
+    c = LuxFHEClient(serverUrl=url)
+    assert c.health()["status"] == "ok" and "threshold" in c.health() and "parties" in c.health()
+    c.initialize()
+    assert len(c.getPublicKey()) > 0
+    for w in (8, 16, 32, 64):
+        assert len(c.encrypt(123, w)) > 0
+    a, b = c.encrypt_uint32(42), c.encrypt_uint32(17)
+    res = {op: c.evaluate(op, a, b, 32) for op in ("add", "sub", "lt")}
+    res["eq"] = c.evaluate("eq", a, a, 32)
+    assert all(len(v) > 0 for v in res.values())
+    assert c.verify(bytes([1, 2, 3])) is True
+    if decrypts:
+        assert (c.decrypt(res["add"]), c.decrypt(res["sub"]), c.decrypt(res["lt"]), c.decrypt(res["eq"])) == (59, 25, 0, 1)
+        assert c.decrypt(c.evaluate("mul", a, 3, 32)) == 126                       # clear right operand
+        assert c.decrypt(c.evaluate("select", a, b, 32, cond=res["lt"])) == 17
+        assert c.decrypt(c.encrypt_address("0x8ba1f109551bd432803012645ac136ddd64dba72")) == 0x8ba1f109551bd432803012645ac136ddd64dba72
+    # the hardhat plugin's encoding: value as string + type, JSON array back; decrypt -> {"value": "..."}
+    st, body = _post(url + "/encrypt", {"value": "77", "type": "uint16"})
+    ct = bytes(json.loads(body)["ciphertext"])
+    st, body = _post(url + "/decrypt", {"ciphertext": list(ct)})
+    assert json.loads(body)["value"] == "77"
+    req = urllib.request.Request(url + "/publickey", headers={"Accept": "application/json"})
+    with urllib.request.urlopen(req) as r:
+        assert len(json.loads(r.read())["publicKey"]) > 0
+    # errors: non-2xx with a text body
+    for path, bad in (("/encrypt", {"value": 1, "bitWidth": 12}), ("/encrypt", {"bitWidth": 8}),
+                      ("/evaluate", {"op": "add", "left": [1, 2], "bitWidth": 8}), ("/decrypt", {})):
+        with pytest.raises(urllib.error.HTTPError) as e:
+            _post(url + path, bad)
+        assert e.value.code >= 400 and len(e.value.read()) > 0
+    with pytest.raises(RuntimeError, match="Encryption failed"):
+        c.encrypt(1 << 40, 8)
+
+
+def test_http_surface_with_mock_backend():
+    from tests.mock_engine import MockBackend
+    srv, url = _start(MockBackend())
+    try:
+        _suite(url, decrypts=True)
+    finally:
+        srv.shutdown()
+
+
+@pytest.mark.gpu
+def test_http_surface_on_gpu():
+    from fhe_amd.server import GpuBackend
+    be = GpuBackend(seed=bytes(range(32)))
+    srv, url = _start(be)
+    try:
+        _suite(url, decrypts=True)
+        # public-key encryption by a client that holds no secret key, computed on by the server
+        from fhe_amd.native import Context
+        pk = LuxFHEClient(serverUrl=url).getPublicKey()
+        cli = Context(seed=bytes(31) + b"\x01")
+        x = cli.encrypt_public(pk, 200, 8)
+        y = cli.encrypt_public(pk, 100, 8)
+        c = LuxFHEClient(serverUrl=url)
+        assert c.decrypt(x) == 200
+        assert c.decrypt(c.evaluate("add", x, y, 8)) == 44
+        cli.close()
+        # in-process transport: same client API, no HTTP
+        direct = LuxFHEClient(context=be.ctx)
+        assert direct.decrypt(direct.evaluate("max", direct.encrypt_uint8(9), direct.encrypt_uint8(200), 8)) == 200
+    finally:
+        srv.shutdown()
+        be.ctx.close()
