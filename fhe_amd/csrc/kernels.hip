@@ -28,13 +28,13 @@ namespace lfhe {
 extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
 
 template <int... PH>
-__device__ __forceinline__ void ep_run_seq(EpState& s, double* lds, int t, const Tables& T,
+__device__ __forceinline__ void ep_run_seq(EpState& s, double* lds, unsigned t, const Tables& T,
                                            const double* __restrict__ bsk_i,
                                            std::integer_sequence<int, PH...>) {
     ((ep_phase<PH>(s, lds, t, T, bsk_i), __syncthreads()), ...);
 }
 
-__device__ __forceinline__ void ep_run(EpState& s, double* lds, int t, const Tables& T,
+__device__ __forceinline__ void ep_run(EpState& s, double* lds, unsigned t, const Tables& T,
                                        const double* __restrict__ bsk_i) {
     ep_run_seq(s, lds, t, T, bsk_i, std::make_integer_sequence<int, EP_PHASES>{});
 }
@@ -47,7 +47,7 @@ __device__ __forceinline__ void ep_run(EpState& s, double* lds, int t, const Tab
 __global__ void __launch_bounds__(NT) k_ntt_forward(Tables T, const u64* __restrict__ in,
                                                     double* __restrict__ out, int mode) {
     double* buf = lds_dyn;
-    const int t = threadIdx.x;
+    const unsigned t = threadIdx.x;
     const size_t poly = blockIdx.x;
     u64 v[E];
 #pragma unroll
@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(NT) k_ntt_forward(Tables T, const u64* __restr
 __global__ void __launch_bounds__(NT) k_ntt_inverse(Tables T, const double* __restrict__ in,
                                                     u64* __restrict__ out) {
     double* buf = lds_dyn;
-    const int t = threadIdx.x;
+    const unsigned t = threadIdx.x;
     const size_t poly = blockIdx.x;
     double y0[E];
 #pragma unroll
@@ -96,11 +96,11 @@ __global__ void __launch_bounds__(NT) k_ntt_inverse(Tables T, const double* __re
         for (int j = 0; j < E; ++j) x[j] = mmul(in[(poly * 2 + r) * N + own4(t, j)], T.ninv[r], P);
         gs_radix4x2(x, tw, t, P); norm8(x, P);
         st_o4p34(buf, t, x); __syncthreads(); ld_o3p34(buf, t, x); __syncthreads();
-        gs_radix8(x, tw, base3(t), P); norm8(x, P);
+        gs_radix8<3>(x, tw, base3(t), P);
         st_o3p23(buf, t, x); __syncthreads(); ld_o2p23(buf, t, x); __syncthreads();
-        gs_radix8(x, tw, base2(t), P); norm8(x, P);
+        gs_radix8<3>(x, tw, base2(t), P);
         st_o2p12(buf, t, x); __syncthreads(); ld_o1p12(buf, t, x); __syncthreads();
-        gs_radix8(x, tw, 1, P); norm8(x, P);
+        gs_radix8<3>(x, tw, 1, P);
         if (r == 0) {
 #pragma unroll
             for (int j = 0; j < E; ++j) y0[j] = x[j];
@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(NT, 2) k_external_product(Tables T, const doub
                                                             const u32* __restrict__ ggsw_index,
                                                             const u64* __restrict__ glwe,
                                                             u64* __restrict__ out) {
-    const int t = threadIdx.x;
+    const unsigned t = threadIdx.x;
     const size_t ct = blockIdx.x;
     EpState s;
 #pragma unroll
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(NT, 2) k_external_product(Tables T, const doub
 // exchange buffer at four workgroups per CU.
 // ------------------------------------------------------------------------------------------------
 template <int... PH>
-__device__ __forceinline__ void ep_run_assign(EpState& s, double* lds, int t, const Tables& T,
+__device__ __forceinline__ void ep_run_assign(EpState& s, double* lds, unsigned t, const Tables& T,
                                               const double* __restrict__ bsk_i,
                                               std::integer_sequence<int, PH...>) {
     // barrier between phases, none after the last: the caller publishes its result first
@@ -165,18 +165,18 @@ __global__ void __launch_bounds__(NT, LFHE_BR_WAVES) k_blind_rotate(Tables T, co
                                                         u64* __restrict__ acc_ws,
                                                         u64* __restrict__ glwe_out,
                                                         u64* __restrict__ lwe_out, BlockMap omap) {
-    const int t = threadIdx.x;
+    const unsigned t = threadIdx.x;
     const size_t ct = blockIdx.x;
     const u64* __restrict__ lwe = lwe_small + ct * (size_t)(n + 1);
     const u64* __restrict__ lut = luts + (size_t)(lut_index ? lut_index[omap.ops ? ct % omap.ops : ct] : 0) * N;
     u64* ws = acc_ws + ct * (size_t)(2 * N);
 
     {
-        const int bt = (int)modswitch_2n(lwe[n]);
-        const int a = (2 * N - bt) & (2 * N - 1);  // multiply by X^-b~
+        const unsigned bt = modswitch_2n(lwe[n]);
+        const unsigned a = (2 * N - bt) & (2 * N - 1);  // multiply by X^-b~
 #pragma unroll
         for (int j = 0; j < E; ++j) {
-            const int e = own1(t, j);
+            const unsigned e = own1(t, j);
             bool neg;
             const u64 v = lut[rot_index(e, a, neg)];
             ws[e] = 0;
@@ -187,15 +187,15 @@ __global__ void __launch_bounds__(NT, LFHE_BR_WAVES) k_blind_rotate(Tables T, co
 
     EpState s;
     for (int i = 0; i < n; ++i) {
-        const int a = (int)modswitch_2n(lwe[i]);
+        const unsigned a = modswitch_2n(lwe[i]);
         if (a == 0) continue;  // X^0 - 1 = 0: this CMux adds exactly zero
-        int tt = t;
+        unsigned tt = t;
         asm volatile("" : "+v"(tt));  // recompute the workspace addresses per step (see ep_phase)
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int j = 0; j < E; ++j) {
-                const int e = own1(tt, j);
+                const unsigned e = own1(tt, j);
                 bool neg;
                 const u64 r = ws[q * N + rot_index(e, a, neg)];
                 s.dig[q][j] = decomp23((neg ? (u64)0 - r : r) - ws[q * N + e]);
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(NT, LFHE_BR_WAVES) k_blind_rotate(Tables T, co
         u64* o = lwe_out + omap.block(ct) * (size_t)(N + 1);
 #pragma unroll
         for (int j = 0; j < E; ++j) {
-            const int e = own1(t, j);
+            const unsigned e = own1(t, j);
             if (e == 0) { o[0] = ws[0]; o[N] = ws[N]; }
             else o[N - e] = (u64)0 - ws[e];
         }

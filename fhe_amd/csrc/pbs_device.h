@@ -77,6 +77,12 @@ inline void track_max(double v) { double a = v < 0 ? -v : v; if (a > track_max_r
 LFHE_HD void track_max(double) {}
 #endif
 
+// Table loads take a 32-bit unsigned byte offset from a wave-uniform base, which lets the compiler
+// use the scalar-base + 32-bit-offset addressing mode instead of 64-bit address arithmetic per load.
+LFHE_HD double ldt(const double* __restrict__ base, unsigned idx) {
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + idx * 8u);
+}
+
 LFHE_HD void ct_bfly(double& a, double& b, double w, const Prime& P) {
     track_max(b);
     double t = mmul(b, w, P);
@@ -93,54 +99,43 @@ LFHE_HD void gs_bfly(double& a, double& b, double w, const Prime& P) {
 }
 
 // ---- element ownership per pass
-LFHE_HD int own1(int t, int j) { return t + 256 * j; }
-LFHE_HD int own2(int t, int j) { return ((t >> 5) << 8) + (t & 31) + 32 * j; }
-LFHE_HD int own3(int t, int j) { return ((t >> 2) << 5) + (t & 3) + 4 * j; }
-LFHE_HD int own4(int t, int j) { return 8 * t + j; }
+LFHE_HD unsigned own1(unsigned t, unsigned j) { return t + 256 * j; }
+LFHE_HD unsigned own2(unsigned t, unsigned j) { return ((t >> 5) << 8) + (t & 31) + 32 * j; }
+LFHE_HD unsigned own3(unsigned t, unsigned j) { return ((t >> 2) << 5) + (t & 3) + 4 * j; }
+LFHE_HD unsigned own4(unsigned t, unsigned j) { return 8 * t + j; }
 // ---- paddings per exchange
-LFHE_HD int pad12(int e) { return e; }
-LFHE_HD int pad23(int e) { return e + 4 * (e >> 5); }
-LFHE_HD int pad34(int e) { return e + (e >> 3); }
+LFHE_HD unsigned pad12(unsigned e) { return e; }
+LFHE_HD unsigned pad23(unsigned e) { return e + 4 * (e >> 5); }
+LFHE_HD unsigned pad34(unsigned e) { return e + (e >> 3); }
 
 // Radix-8 Cooley-Tukey on the 8 registers of one pass.  tw is the bit-reversed table
 // (tw[m + i] = psi^bitrev(m + i)), b the table index of the pass's first stage.
-LFHE_HD void ct_radix8(double (&x)[8], const double* __restrict__ tw, int b, const Prime& P) {
-    const double w1 = tw[b];
+LFHE_HD void ct_radix8(double (&x)[8], const double* __restrict__ tw, unsigned b, const Prime& P) {
+    const double w1 = ldt(tw, b);
 #pragma unroll
     for (int j = 0; j < 4; ++j) ct_bfly(x[j], x[j + 4], w1, P);
-    const double w2a = tw[2 * b], w2b = tw[2 * b + 1];
+    const double w2a = ldt(tw, 2 * b), w2b = ldt(tw, 2 * b + 1);
     ct_bfly(x[0], x[2], w2a, P); ct_bfly(x[1], x[3], w2a, P);
     ct_bfly(x[4], x[6], w2b, P); ct_bfly(x[5], x[7], w2b, P);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) ct_bfly(x[2 * k], x[2 * k + 1], tw[4 * b + k], P);
+    for (unsigned k = 0; k < 4; ++k) ct_bfly(x[2 * k], x[2 * k + 1], ldt(tw, 4 * b + k), P);
 }
 
 // last forward pass: strides 2 and 1 on 8 consecutive coefficients
-LFHE_HD void ct_radix4x2(double (&x)[8], const double* __restrict__ tw, int t, const Prime& P) {
-    const double wa = tw[512 + 2 * t], wb = tw[512 + 2 * t + 1];
+LFHE_HD void ct_radix4x2(double (&x)[8], const double* __restrict__ tw, unsigned t, const Prime& P) {
+    const double wa = ldt(tw, 512 + 2 * t), wb = ldt(tw, 512 + 2 * t + 1);
     ct_bfly(x[0], x[2], wa, P); ct_bfly(x[1], x[3], wa, P);
     ct_bfly(x[4], x[6], wb, P); ct_bfly(x[5], x[7], wb, P);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) ct_bfly(x[2 * k], x[2 * k + 1], tw[1024 + 4 * t + k], P);
+    for (unsigned k = 0; k < 4; ++k) ct_bfly(x[2 * k], x[2 * k + 1], ldt(tw, 1024 + 4 * t + k), P);
 }
 
-LFHE_HD void gs_radix4x2(double (&x)[8], const double* __restrict__ tw, int t, const Prime& P) {
+LFHE_HD void gs_radix4x2(double (&x)[8], const double* __restrict__ tw, unsigned t, const Prime& P) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) gs_bfly(x[2 * k], x[2 * k + 1], tw[1024 + 4 * t + k], P);
-    const double wa = tw[512 + 2 * t], wb = tw[512 + 2 * t + 1];
+    for (unsigned k = 0; k < 4; ++k) gs_bfly(x[2 * k], x[2 * k + 1], ldt(tw, 1024 + 4 * t + k), P);
+    const double wa = ldt(tw, 512 + 2 * t), wb = ldt(tw, 512 + 2 * t + 1);
     gs_bfly(x[0], x[2], wa, P); gs_bfly(x[1], x[3], wa, P);
     gs_bfly(x[4], x[6], wb, P); gs_bfly(x[5], x[7], wb, P);
-}
-
-LFHE_HD void gs_radix8(double (&x)[8], const double* __restrict__ tw, int b, const Prime& P) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) gs_bfly(x[2 * k], x[2 * k + 1], tw[4 * b + k], P);
-    const double w2a = tw[2 * b], w2b = tw[2 * b + 1];
-    gs_bfly(x[0], x[2], w2a, P); gs_bfly(x[1], x[3], w2a, P);
-    gs_bfly(x[4], x[6], w2b, P); gs_bfly(x[5], x[7], w2b, P);
-    const double w1 = tw[b];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) gs_bfly(x[j], x[j + 4], w1, P);
 }
 
 LFHE_HD void norm8(double (&x)[8], const Prime& P) {
@@ -148,10 +143,28 @@ LFHE_HD void norm8(double (&x)[8], const Prime& P) {
     for (int j = 0; j < 8; ++j) x[j] = mnorm(x[j], P);
 }
 
+// NORM_AFTER: 0 none, k = 1..3 normalise after the k-th of the pass's three stages.  A
+// Gentleman-Sande sum doubles the bound per stage, so from centred values (0.5 p) four stages
+// may run before the sums (8 p) must be brought back; the inverse transform places its three
+// normalisations after stages 2, 6 and 10 of 11.
+template <int NORM_AFTER = 0>
+LFHE_HD void gs_radix8(double (&x)[8], const double* __restrict__ tw, unsigned b, const Prime& P) {
+#pragma unroll
+    for (unsigned k = 0; k < 4; ++k) gs_bfly(x[2 * k], x[2 * k + 1], ldt(tw, 4 * b + k), P);
+    if (NORM_AFTER == 1) norm8(x, P);
+    const double w2a = ldt(tw, 2 * b), w2b = ldt(tw, 2 * b + 1);
+    gs_bfly(x[0], x[2], w2a, P); gs_bfly(x[1], x[3], w2a, P);
+    gs_bfly(x[4], x[6], w2b, P); gs_bfly(x[5], x[7], w2b, P);
+    if (NORM_AFTER == 2) norm8(x, P);
+    const double w1 = ldt(tw, b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gs_bfly(x[j], x[j + 4], w1, P);
+    if (NORM_AFTER == 3) norm8(x, P);
+}
+
 // table index of the first stage of each radix-8 pass
-LFHE_HD int base1(int) { return 1; }
-LFHE_HD int base2(int t) { return 8 + (t >> 5); }
-LFHE_HD int base3(int t) { return 64 + (t >> 2); }
+LFHE_HD unsigned base2(unsigned t) { return 8 + (t >> 5); }
+LFHE_HD unsigned base3(unsigned t) { return 64 + (t >> 2); }
 
 // ---- LDS exchange halves.  `buf` is one polynomial's region (POLY_STRIDE words).
 #ifdef LFHE_ABLATE_NO_LDS   // timing experiment only: results are wrong
@@ -160,11 +173,11 @@ LFHE_HD int base3(int t) { return 64 + (t >> 2); }
     LFHE_HD void ld_##NAME(const double*, int, double (&)[8]) {}
 #else
 #define LFHE_XCHG(NAME, OWN, PAD)                                                         \
-    LFHE_HD void st_##NAME(double* buf, int t, const double (&x)[8]) {                    \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) buf[PAD(OWN(t, j))] = x[j];         \
+    LFHE_HD void st_##NAME(double* buf, unsigned t, const double (&x)[8]) {               \
+        _Pragma("unroll") for (unsigned j = 0; j < 8; ++j) buf[PAD(OWN(t, j))] = x[j];    \
     }                                                                                     \
-    LFHE_HD void ld_##NAME(const double* buf, int t, double (&x)[8]) {                    \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) x[j] = buf[PAD(OWN(t, j))];         \
+    LFHE_HD void ld_##NAME(const double* buf, unsigned t, double (&x)[8]) {               \
+        _Pragma("unroll") for (unsigned j = 0; j < 8; ++j) x[j] = buf[PAD(OWN(t, j))];    \
     }
 #endif
 LFHE_XCHG(o1p12, own1, pad12)

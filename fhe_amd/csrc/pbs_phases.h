@@ -22,7 +22,7 @@ struct Tables {
 //   [i][prime][q = j_in*2 + c_out][chunk c4][thread t][2]   holds position e = 8 t + 2 c4 + h.
 constexpr int BSK_POLY = N;                 // doubles per (i, prime, q)
 constexpr int BSK_ROW = 2 * 4 * BSK_POLY;   // doubles per i
-LFHE_HD int bsk_off(int r, int q, int c4, int t) { return ((r * 4 + q) * 4 + c4) * (NT * 2) + t * 2; }
+LFHE_HD unsigned bsk_off(unsigned r, unsigned q, unsigned c4, unsigned t) { return ((r * 4 + q) * 4 + c4) * (NT * 2) + t * 2; }
 
 struct EpState {
     int dig[2][E];     // in: decomposition digits, pass-1 ownership
@@ -35,7 +35,7 @@ constexpr int EP_PHASES = 24;  // 12 per prime
 
 // phase p of the external product.  `lds` holds two padded polynomials.
 template <int PH, bool ACCUM = true>
-LFHE_HD void ep_phase(EpState& s, double* lds, int t, const Tables& T, const double* __restrict__ bsk_i) {
+LFHE_HD void ep_phase(EpState& s, double* lds, unsigned t, const Tables& T, const double* __restrict__ bsk_i) {
     constexpr int r = PH / 12;
     constexpr int ph = PH % 12;
     const Prime P = T.pr[r];
@@ -84,12 +84,12 @@ LFHE_HD void ep_phase(EpState& s, double* lds, int t, const Tables& T, const dou
         // all sixteen loads (64 registers) to the top of the phase
         double kc[4][2], kn[4][2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const double* k = bsk_i + bsk_off(r, q, 0, t); kc[q][0] = k[0]; kc[q][1] = k[1]; }
+        for (unsigned q = 0; q < 4; ++q) { const unsigned o = bsk_off(r, q, 0, t); kc[q][0] = ldt(bsk_i, o); kc[q][1] = ldt(bsk_i, o + 1); }
 #pragma unroll
         for (int c4 = 0; c4 < 4; ++c4) {
             if (c4 < 3) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { const double* k = bsk_i + bsk_off(r, q, c4 + 1, t); kn[q][0] = k[0]; kn[q][1] = k[1]; }
+                for (unsigned q = 0; q < 4; ++q) { const unsigned o = bsk_off(r, q, c4 + 1, t); kn[q][0] = ldt(bsk_i, o); kn[q][1] = ldt(bsk_i, o + 1); }
             }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -110,21 +110,20 @@ LFHE_HD void ep_phase(EpState& s, double* lds, int t, const Tables& T, const dou
         st_o4p34(b0, t, s.x[0]); st_o4p34(b1, t, s.x[1]);
     } else if constexpr (ph == 7) {
         ld_o3p34(b0, t, s.x[0]); ld_o3p34(b1, t, s.x[1]);
-        gs_radix8(s.x[0], twi, base3(t), P); gs_radix8(s.x[1], twi, base3(t), P);
-        norm8(s.x[0], P); norm8(s.x[1], P);
+        gs_radix8(s.x[0], twi, base3(t), P); gs_radix8(s.x[1], twi, base3(t), P);                 // stages 3-5
     } else if constexpr (ph == 8) {
         st_o3p23(b0, t, s.x[0]); st_o3p23(b1, t, s.x[1]);
     } else if constexpr (ph == 9) {
         ld_o2p23(b0, t, s.x[0]); ld_o2p23(b1, t, s.x[1]);
-        gs_radix8(s.x[0], twi, base2(t), P); gs_radix8(s.x[1], twi, base2(t), P);
-        norm8(s.x[0], P); norm8(s.x[1], P);
+        gs_radix8<1>(s.x[0], twi, base2(t), P); gs_radix8<1>(s.x[1], twi, base2(t), P);           // 6 | 7-8
     } else if constexpr (ph == 10) {
         st_o2p12(b0, t, s.x[0]); st_o2p12(b1, t, s.x[1]);
     } else {  // ph == 11: inverse pass 1, then keep (prime 0) or lift (prime 1)
         static_assert(ph == 11, "phase out of range");
         ld_o1p12(b0, t, s.x[0]); ld_o1p12(b1, t, s.x[1]);
-        gs_radix8(s.x[0], twi, 1, P); gs_radix8(s.x[1], twi, 1, P);
-        norm8(s.x[0], P); norm8(s.x[1], P);
+        // stages 9-10 | 11: the outputs (|y| <= p) go to the CRT lift as they are; it only needs
+        // residues, not centred ones, because |true value| <= 2^97 < 0.33 p0 p1
+        gs_radix8<2>(s.x[0], twi, 1, P); gs_radix8<2>(s.x[1], twi, 1, P);
         if constexpr (r == 0) {
 #pragma unroll
             for (int q = 0; q < 2; ++q)
@@ -143,11 +142,11 @@ LFHE_HD void ep_phase(EpState& s, double* lds, int t, const Tables& T, const dou
 }
 
 // coefficient e of X^a * poly: index to read and whether to negate it
-LFHE_HD int rot_index(int e, int a, bool& neg) {
-    int idx = e - (a & (N - 1));
-    neg = (a & N) != 0;
-    if (idx < 0) { idx += N; neg = !neg; }
-    return idx;
+LFHE_HD unsigned rot_index(unsigned e, unsigned a, bool& neg) {
+    const unsigned ar = a & (N - 1);
+    const bool wrap = e < ar;
+    neg = ((a & N) != 0) != wrap;
+    return wrap ? e + N - ar : e - ar;
 }
 
 LFHE_HD u32 modswitch_2n(u64 x) {  // round to Z_{2N}
