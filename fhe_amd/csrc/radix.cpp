@@ -1,6 +1,7 @@
 // Integer operators on radix ciphertexts (euint8 ... euint256, ebool): serialisation, encryption,
 // decryption and the executor that replays an operator's Program (radix_program.h) for a batch of
 // independent instances, layer by layer, on the GPU.
+#include <array>
 #include <cstring>
 #include <map>
 #include <stdexcept>
@@ -84,8 +85,9 @@ struct Compiled {
 
 }  // namespace
 
+typedef std::array<uint8_t, 32> Scalar;
 struct lfhe_radix {
-    std::map<std::tuple<uint32_t, uint32_t, int, int, int>, std::unique_ptr<Compiled>> cache;
+    std::map<std::tuple<uint32_t, uint32_t, int, int, int, bool, Scalar>, std::unique_ptr<Compiled>> cache;
 };
 
 lfhe_ctx::lfhe_ctx() = default;
@@ -96,13 +98,22 @@ lfhe_ctx::~lfhe_ctx() {
 
 namespace {
 
-Compiled& compiled_for(lfhe_ctx* ctx, uint32_t op, uint32_t width, int ln, int rn, int cn) {
+// programs specialised on a clear right operand: shift and rotation amounts, divisors
+bool specialised_op(uint32_t op) {
+    return op == LFHE_OP_SHL || op == LFHE_OP_SHR || op == LFHE_OP_ROTL || op == LFHE_OP_ROTR || op == LFHE_OP_DIV ||
+           op == LFHE_OP_REM;
+}
+bool shift_op(uint32_t op) { return op == LFHE_OP_SHL || op == LFHE_OP_SHR || op == LFHE_OP_ROTL || op == LFHE_OP_ROTR; }
+
+Compiled& compiled_for(lfhe_ctx* ctx, uint32_t op, uint32_t width, int ln, int rn, int cn, const uint8_t* scalar) {
     if (!ctx->radix) ctx->radix.reset(new lfhe_radix());
-    auto key = std::make_tuple(op, width, ln, rn, cn);
+    Scalar sc{};
+    if (scalar) std::memcpy(sc.data(), scalar, 32);
+    auto key = std::make_tuple(op, width, ln, rn, cn, scalar != nullptr, sc);
     auto it = ctx->radix->cache.find(key);
     if (it != ctx->radix->cache.end()) return *it->second;
     std::unique_ptr<Compiled> c(new Compiled());
-    c->prog = build_program(op, width, ln, rn, cn);
+    c->prog = build_program(op, width, ln, rn, cn, scalar);
     Engine& E = *ctx->eng;
     HC(hipSetDevice(E.device()));
     const Program& P = c->prog;
@@ -169,9 +180,15 @@ void run_batch(lfhe_ctx* ctx, uint32_t op, uint32_t width, uint64_t n, const uin
     if (!unary && !rhs) throw std::invalid_argument("missing right operand");
     if (op == LFHE_OP_SELECT && !cond) throw std::invalid_argument("select needs a condition");
     const int ln = check_operand(lhs, n, width);
-    const int rn = (unary || rhs_scalar) ? 1 : check_operand(rhs, n, width);
+    const uint32_t rhs_width = shift_op(op) ? 8 : width;  // shift amounts are euint8
+    const int rn = (unary || rhs_scalar) ? 1 : check_operand(rhs, n, rhs_width);
     const int cn = op == LFHE_OP_SELECT ? check_operand(cond, n, 1) : 1;
-    Compiled& C = compiled_for(ctx, op, width, ln, rn, cn);
+    // a specialised program serves instances that share the clear operand: the caller groups them
+    const bool special = rhs_scalar && specialised_op(op);
+    if (special)
+        for (uint64_t i = 1; i < n; ++i)
+            if (std::memcmp(rhs, rhs + i * 32, 32)) throw std::logic_error("instances of one specialised run differ");
+    Compiled& C = compiled_for(ctx, op, width, ln, rn, cn, special ? rhs : nullptr);
     const Program& P = C.prog;
     Engine& E = *ctx->eng;
     HC(hipSetDevice(E.device()));
@@ -186,7 +203,7 @@ void run_batch(lfhe_ctx* ctx, uint32_t op, uint32_t width, uint64_t n, const uin
     };
     upload(lhs, in_stride, P.lhs[0], m);
     DevBuf<u64> scal;
-    if (!unary) {
+    if (!unary && !special) {
         if (rhs_scalar) {
             std::vector<u64> bodies(n * m);
             for (uint64_t i = 0; i < n; ++i)
@@ -202,7 +219,7 @@ void run_batch(lfhe_ctx* ctx, uint32_t op, uint32_t width, uint64_t n, const uin
             launch_fill_trivial(arena.p, n, P.nblocks, P.rhs[0], m, scal.p, st);
             HC(hipGetLastError());
         } else {
-            upload(rhs, in_stride, P.rhs[0], m);
+            upload(rhs, ct_bytes(rhs_width), P.rhs[0], blocks_of(rhs_width));
         }
     }
     if (op == LFHE_OP_SELECT) upload(cond, ct_bytes(1), P.cond[0], 1);
@@ -370,12 +387,14 @@ int32_t lfhe_op_from_name(const char* name) {
 }
 
 int32_t lfhe_program_dump(uint32_t op, uint32_t bit_width, int32_t lhs_noise, int32_t rhs_noise, int32_t cond_noise,
-                          char* out, uint64_t* out_len) {
+                          const uint8_t* scalar, char* out, uint64_t* out_len) {
     if (!out_len) return LFHE_ERR_ARG;
     std::string js;
     try {
         if (!width_ok(bit_width)) return LFHE_ERR_ARG;
-        js = build_program(op, bit_width, lhs_noise, rhs_noise, cond_noise).to_json();
+        js = build_program(op, bit_width, lhs_noise, rhs_noise, cond_noise, specialised_op(op) ? scalar : nullptr).to_json();
+    } catch (const std::domain_error&) {
+        return LFHE_ERR_ARG;
     } catch (const std::invalid_argument&) {
         return LFHE_ERR_UNSUPPORTED;
     } catch (const std::exception&) {
@@ -392,13 +411,37 @@ int32_t lfhe_program_dump(uint32_t op, uint32_t bit_width, int32_t lhs_noise, in
 int32_t lfhe_evaluate_batch(lfhe_ctx* ctx, uint32_t op, uint32_t bit_width, uint64_t n, const uint8_t* lhs,
                             const uint8_t* rhs, int32_t rhs_is_scalar, const uint8_t* cond, uint8_t* out) {
     if (!ctx) return LFHE_ERR_ARG;
-    if (op == LFHE_OP_CAST || op == LFHE_OP_SHL || op == LFHE_OP_SHR || op == LFHE_OP_ROTL || op == LFHE_OP_ROTR ||
-        op == LFHE_OP_DIV || op == LFHE_OP_REM) {
-        ctx->err = "operator not supported in batch form yet";
+    if (op == LFHE_OP_CAST) {
+        ctx->err = "cast has no batch form: it moves no data through the GPU";
         return LFHE_ERR_UNSUPPORTED;
     }
     int32_t rc = guarded(ctx, [&]() -> int32_t {
-        run_batch(ctx, op, bit_width, n, lhs, rhs, rhs_is_scalar != 0, cond, out);
+        const bool special = rhs_is_scalar && specialised_op(op) && rhs && n > 1;
+        bool uniform = true;
+        if (special)
+            for (uint64_t i = 1; i < n && uniform; ++i) uniform = !std::memcmp(rhs, rhs + i * 32, 32);
+        if (uniform) {
+            run_batch(ctx, op, bit_width, n, lhs, rhs, rhs_is_scalar != 0, cond, out);
+            return LFHE_OK;
+        }
+        // instances grouped by their clear operand; each group is one specialised run
+        if (!width_ok(bit_width) || !lhs || !out) throw std::invalid_argument("bad argument");
+        std::map<Scalar, std::vector<uint64_t>> groups;
+        for (uint64_t i = 0; i < n; ++i) {
+            Scalar sc;
+            std::memcpy(sc.data(), rhs + i * 32, 32);
+            groups[sc].push_back(i);
+        }
+        const uint64_t stride = ct_bytes(bit_width);
+        for (const auto& [sc, idx] : groups) {
+            std::vector<uint8_t> gl(idx.size() * stride), gr(idx.size() * 32), go(idx.size() * stride);
+            for (size_t k = 0; k < idx.size(); ++k) {
+                std::memcpy(gl.data() + k * stride, lhs + idx[k] * stride, stride);
+                std::memcpy(gr.data() + k * 32, sc.data(), 32);
+            }
+            run_batch(ctx, op, bit_width, idx.size(), gl.data(), gr.data(), true, nullptr, go.data());
+            for (size_t k = 0; k < idx.size(); ++k) std::memcpy(out + idx[k] * stride, go.data() + k * stride, stride);
+        }
         return LFHE_OK;
     });
     if (rc == LFHE_ERR_ARG && ctx->err == "operator not supported") rc = LFHE_ERR_UNSUPPORTED;
@@ -425,7 +468,7 @@ int32_t lfhe_evaluate(lfhe_ctx* ctx, uint32_t op, uint32_t bit_width, const uint
     }
     const bool unary = op == LFHE_OP_NOT || op == LFHE_OP_NEG;
     if (!lhs || lhs_len != ct_bytes(bit_width) || (!unary && !rhs) ||
-        (!unary && rhs_len != (rhs_is_scalar ? 32u : ct_bytes(bit_width))) ||
+        (!unary && rhs_len != (rhs_is_scalar ? 32u : ct_bytes(shift_op(op) ? 8 : bit_width))) ||
         (op == LFHE_OP_SELECT && (!cond || cond_len != ct_bytes(1)))) {
         ctx->err = "operand length does not match the bit width";
         return LFHE_ERR_ARG;

@@ -37,7 +37,17 @@ uint32_t Builder::lut_id(const std::function<int(int)>& f) {
     return id;
 }
 
-uint32_t Builder::lin(const Expr& e, const Info& i) {
+uint32_t Builder::lin(const Expr& e0, const Info& i) {
+    // the linear operations of one layer run side by side in one launch: a term that is itself the
+    // output of a linear operation of this layer is replaced by the combination that defines it
+    Expr e;
+    e.cst = e0.cst;
+    for (const auto& [c, b] : e0.t) {
+        auto it = lin_expr_.find(b);
+        if (it == lin_expr_.end() || info_[b].level != i.level) { e.t.push_back({c, b}); continue; }
+        for (const auto& [c2, b2] : it->second.t) e.t.push_back({c * c2, b2});
+        e.cst += c * it->second.cst;
+    }
     if (e.t.size() > (size_t)LIN_MAX_TERMS) throw std::logic_error("linear combination too long");
     if (i.lo < 0 || i.hi > BLOCK_MAX) throw std::logic_error("block value range overflows the carry space");
     if (i.noise > MAX_NOISE) throw std::logic_error("noise level above the parameter set's budget");
@@ -48,6 +58,7 @@ uint32_t Builder::lin(const Expr& e, const Info& i) {
     for (size_t k = 0; k < e.t.size(); ++k) { op.coef[k] = e.t[k].first; op.src[k] = e.t[k].second; }
     op.cst = e.cst;
     layer(i.level).lin.push_back(op);
+    lin_expr_[out] = e;
     return out;
 }
 
@@ -85,7 +96,7 @@ std::string Program::to_json() const {
         for (size_t i = 0; i < v.size(); ++i) o << (i ? "," : "") << v[i];
         o << "]";
     };
-    o << "{\"op\":" << op << ",\"width\":" << width << ",\"out_width\":" << out_width << ",\"nblocks\":" << nblocks
+    o << "{\"op\":" << op << ",\"width\":" << width << ",\"out_width\":" << out_width << ",\"rhs_width\":" << rhs_width << ",\"nblocks\":" << nblocks
       << ",\"out_noise\":" << (int)out_noise << ",\"pbs\":" << pbs_per_instance() << ",\"lhs\":";
     list(lhs); o << ",\"rhs\":"; list(rhs); o << ",\"cond\":"; list(cond); o << ",\"out\":"; list(out);
     o << ",\"luts\":[";
@@ -195,18 +206,11 @@ Blocks op_bitwise(Builder& B, const Blocks& a0, const Blocks& b0, uint32_t op) {
     return r;
 }
 
-// schoolbook product: low and high digit of every block pair, column sums of up to five terms
-// reduced to digit + carry until every column has at most two terms, then one carry propagation
-Blocks op_mul(Builder& B, const Blocks& a0, const Blocks& b0) {
-    const Blocks a = clean(B, a0), b = clean(B, b0);
-    const size_t m = a.size();
-    std::vector<Blocks> cols(m);
-    for (size_t i = 0; i < m; ++i)
-        for (size_t j = 0; i + j < m; ++j) {
-            const Expr in = pack(B, a[i], b[j]);
-            cols[i + j].push_back(B.pbs(in, [](int x) { return (hi2(x) * lo2(x)) & 3; }));
-            if (i + j + 1 < m) cols[i + j + 1].push_back(B.pbs(in, [](int x) { return (hi2(x) * lo2(x)) >> 2; }));
-        }
+// column sums of a schoolbook product: groups of up to five blocks are replaced by their digit (same
+// column) and carry (next column) until every column holds at most two blocks; columns beyond the
+// last are dropped (arithmetic modulo 4^columns)
+std::vector<Expr> reduce_columns(Builder& B, std::vector<Blocks> cols) {
+    const size_t m = cols.size();
     for (;;) {
         size_t longest = 0;
         for (const auto& c : cols) longest = std::max(longest, c.size());
@@ -232,7 +236,22 @@ Blocks op_mul(Builder& B, const Blocks& a0, const Blocks& b0) {
         for (uint32_t blk : cols[c]) s = Builder::add(s, B.E(blk));
         v.push_back(s);
     }
-    return propagate(B, v);
+    return v;
+}
+
+// schoolbook product: low and high digit of every block pair, column sums of up to five terms
+// reduced to digit + carry until every column has at most two terms, then one carry propagation
+Blocks op_mul(Builder& B, const Blocks& a0, const Blocks& b0) {
+    const Blocks a = clean(B, a0), b = clean(B, b0);
+    const size_t m = a.size();
+    std::vector<Blocks> cols(m);
+    for (size_t i = 0; i < m; ++i)
+        for (size_t j = 0; i + j < m; ++j) {
+            const Expr in = pack(B, a[i], b[j]);
+            cols[i + j].push_back(B.pbs(in, [](int x) { return (hi2(x) * lo2(x)) & 3; }));
+            if (i + j + 1 < m) cols[i + j + 1].push_back(B.pbs(in, [](int x) { return (hi2(x) * lo2(x)) >> 2; }));
+        }
+    return propagate(B, reduce_columns(B, cols));
 }
 
 // equality: per-block equality bits, AND-reduced five at a time
@@ -306,9 +325,203 @@ Blocks op_select(Builder& B, uint32_t c0, const Blocks& a0, const Blocks& b0) {
     return r;
 }
 
+
+// ---- shifts and rotations -----------------------------------------------------------------------
+// An integer of W bits is the bit string X[0..W); every variant maps output bit p to one source bit
+// (or to a zero fill) for a given amount t.
+long source_bit(uint32_t op, long W, long p, long t) {
+    switch (op) {
+        case LFHE_OP_SHL: return p - t >= 0 ? p - t : -1;
+        case LFHE_OP_SHR: return p + t < W ? p + t : -1;
+        case LFHE_OP_ROTL: return ((p - t) % W + W) % W;
+        default: return (p + t) % W;  // ROTR
+    }
+}
+
+// the part of output block i (under an amount of t bits) that comes from source block u holding xu
+int shifted_part(uint32_t op, long W, long i, long u, long t, int xu) {
+    int r = 0;
+    for (int ob = 0; ob < 2; ++ob) {
+        const long q = source_bit(op, W, 2 * i + ob, t);
+        if (q >= 0 && q / 2 == u) r |= ((xu >> (q & 1)) & 1) << ob;
+    }
+    return r;
+}
+
+// clear amount: re-indexing of blocks when t is even, one bootstrap per block when it is odd
+Blocks op_shift_clear(Builder& B, uint32_t op, const Blocks& x, long t) {
+    const long m = (long)x.size(), W = 2 * m;
+    t %= W;
+    Blocks r;
+    for (long i = 0; i < m; ++i) {
+        std::vector<long> srcs;
+        for (int ob = 0; ob < 2; ++ob) {
+            const long q = source_bit(op, W, 2 * i + ob, t);
+            if (q >= 0 && (srcs.empty() || srcs.back() != q / 2)) srcs.push_back(q / 2);
+        }
+        if (srcs.empty()) { r.push_back(B.mat(Builder::C(0))); continue; }
+        if (t % 2 == 0) { r.push_back(x[srcs[0]]); continue; }
+        if (srcs.size() == 2 && B.noise(x[srcs[0]]) <= 1 && B.noise(x[srcs[1]]) <= 1 && B.hi(x[srcs[0]]) <= 3 &&
+            B.hi(x[srcs[1]]) <= 3) {
+            const long u0 = srcs[0], u1 = srcs[1];
+            r.push_back(B.pbs(pack(B, x[u0], x[u1]), [=](int in) {
+                return shifted_part(op, W, i, u0, t, hi2(in)) | shifted_part(op, W, i, u1, t, lo2(in));
+            }));
+            continue;
+        }
+        Expr sum;
+        for (long u : srcs)
+            sum = Builder::add(sum, B.E(B.pbs(B.E(x[u]), [=](int in) { return shifted_part(op, W, i, u, t, in & 3); })));
+        r.push_back(B.mat(sum, 3));
+    }
+    return r;
+}
+
+// encrypted amount (the blocks of a euint8, of which the low log2 W bits count): one stage per
+// base-4 digit s of the amount, out[i] = sum over source blocks u of f_u(s, x[u]); the parts are
+// disjoint bit fields, so the sum stays below 4
+Blocks op_shift_encrypted(Builder& B, uint32_t op, const Blocks& x0, const Blocks& amount0) {
+    const long m = (long)x0.size(), W = 2 * m;
+    int log2w = 0;
+    while ((1L << log2w) < W) ++log2w;
+    if ((1L << log2w) != W) throw std::invalid_argument("operator not supported");  // width not a power of two
+    const Blocks amount = clean(B, amount0);
+    const int ndigits = (log2w + 1) / 2;
+    Blocks x = x0;
+    for (int j = 0; j < ndigits; ++j) {
+        x = clean(B, x);
+        const long unit = 1L << (2 * j);
+        const int vmask = (j == ndigits - 1 && (log2w & 1)) ? 1 : 3;
+        const uint32_t s = amount[j];
+        Blocks nx;
+        for (long i = 0; i < m; ++i) {
+            std::vector<long> srcs;
+            for (int v = 0; v <= vmask; ++v)
+                for (int ob = 0; ob < 2; ++ob) {
+                    const long q = source_bit(op, W, 2 * i + ob, v * unit);
+                    if (q >= 0 && std::find(srcs.begin(), srcs.end(), q / 2) == srcs.end()) srcs.push_back(q / 2);
+                }
+            Expr sum;
+            for (long u : srcs)
+                sum = Builder::add(sum, B.E(B.pbs(pack(B, s, x[u]), [=](int in) {
+                    return shifted_part(op, W, i, u, (hi2(in) & vmask) * unit, lo2(in));
+                })));
+            nx.push_back(B.mat(sum, 3));
+        }
+        x = nx;
+    }
+    return clean(B, x);
+}
+
+// ---- division by a clear divisor ----------------------------------------------------------------
+// little-endian multi-word naturals, just enough for the reciprocal of a divisor of up to 256 bits
+typedef std::vector<uint64_t> Nat;
+int nat_bit(const Nat& a, size_t i) { return i / 64 < a.size() ? (int)((a[i / 64] >> (i % 64)) & 1) : 0; }
+size_t nat_bits(const Nat& a) {
+    for (size_t i = a.size() * 64; i-- > 0;)
+        if (nat_bit(a, i)) return i + 1;
+    return 0;
+}
+int nat_cmp(const Nat& a, const Nat& b) {
+    for (size_t i = std::max(a.size(), b.size()); i-- > 0;) {
+        const uint64_t x = i < a.size() ? a[i] : 0, y = i < b.size() ? b[i] : 0;
+        if (x != y) return x < y ? -1 : 1;
+    }
+    return 0;
+}
+void nat_sub(Nat& a, const Nat& b) {  // a -= b, a >= b
+    uint64_t borrow = 0;
+    for (size_t i = 0; i < a.size(); ++i) {
+        const uint64_t y = i < b.size() ? b[i] : 0, x = a[i];
+        a[i] = x - y - borrow;
+        borrow = (x < y || (x == y && borrow)) ? 1 : 0;
+    }
+}
+void nat_shl1(Nat& a, int bit) {
+    uint64_t c = (uint64_t)bit;
+    for (auto& w : a) { const uint64_t n = w >> 63; w = (w << 1) | c; c = n; }
+}
+// floor(num / den) by shift and subtract
+Nat nat_div(const Nat& num, const Nat& den) {
+    Nat q(num.size(), 0), r(num.size() + 1, 0);
+    for (size_t i = num.size() * 64; i-- > 0;) {
+        nat_shl1(r, nat_bit(num, i));
+        if (nat_cmp(r, den) >= 0) { nat_sub(r, den); q[i / 64] |= 1ull << (i % 64); }
+    }
+    return q;
+}
+int nat_digit(const Nat& a, size_t i) { return nat_bit(a, 2 * i) | (nat_bit(a, 2 * i + 1) << 1); }
+
+// product of the blocks a (carry-free) with a clear natural c, `columns` base-4 digits of it
+Blocks op_mul_clear(Builder& B, const Blocks& a, const Nat& c, size_t columns) {
+    const size_t m = a.size();
+    std::vector<Blocks> cols(columns);
+    for (size_t i = 0; i < m; ++i) {
+        uint32_t lo[4] = {0, a[i], 0, 0}, hi[4] = {0, 0, 0, 0};
+        bool have[4] = {false, true, false, false};
+        for (size_t j = 0; i + j < columns && 2 * j < 64 * c.size(); ++j) {
+            const int d = nat_digit(c, j);
+            if (!d) continue;
+            if (!have[d]) {
+                lo[d] = B.pbs(B.E(a[i]), [d](int x) { return ((x & 3) * d) & 3; });
+                hi[d] = B.pbs(B.E(a[i]), [d](int x) { return ((x & 3) * d) >> 2; });
+                have[d] = true;
+            }
+            cols[i + j].push_back(lo[d]);
+            if (d > 1 && i + j + 1 < columns) cols[i + j + 1].push_back(hi[d]);
+        }
+    }
+    return propagate(B, reduce_columns(B, cols));
+}
+
+// Division of a W-bit integer by a clear d that is not a power of two, by multiplication with a
+// reciprocal (Granlund and Montgomery, "Division by invariant integers using multiplication",
+// unsigned case): l = ceil(log2 d), r = floor(2^W (2^l - d) / d) + 1, t = high half of r * a,
+// quotient = (t + ((a - t) >> 1)) >> (l - 1).  All intermediate values fit W bits.
+void op_divrem_clear(Builder& B, const Blocks& a0, const Nat& d, Blocks* quot, Blocks* rem) {
+    const Blocks a = clean(B, a0);
+    const size_t m = a.size(), W = 2 * m;
+    const size_t dbits = nat_bits(d);
+    if (!dbits) throw std::domain_error("division by zero");
+    if (dbits > W) throw std::invalid_argument("divisor wider than the operand");
+    bool pow2 = true;
+    for (size_t i = 0; i + 1 < dbits; ++i) pow2 = pow2 && !nat_bit(d, i);
+    if (pow2) {
+        const long k = (long)dbits - 1;
+        if (quot) *quot = op_shift_clear(B, LFHE_OP_SHR, a, k);
+        if (rem) {
+            Blocks r;
+            for (long i = 0; i < (long)m; ++i) {
+                if (2 * i + 1 < k) r.push_back(a[i]);
+                else if (2 * i < k) r.push_back(B.pbs(B.E(a[i]), [](int x) { return x & 1; }));
+                else r.push_back(B.mat(Builder::C(0)));
+            }
+            *rem = r;
+        }
+        return;
+    }
+    const size_t l = dbits;  // 2^(l-1) < d < 2^l
+    Nat num((2 * W + 63) / 64 + 1, 0), two_l((W + 63) / 64 + 1, 0);
+    two_l[l / 64] |= 1ull << (l % 64);
+    nat_sub(two_l, d);  // 2^l - d
+    for (size_t i = 0; i < W; ++i)
+        if (nat_bit(two_l, i)) num[(i + W) / 64] |= 1ull << ((i + W) % 64);
+    Nat r = nat_div(num, d);
+    for (size_t i = 0; i < r.size(); ++i)  // + 1
+        if (++r[i]) break;
+    const Blocks full = op_mul_clear(B, a, r, 2 * m);
+    const Blocks t(full.begin() + (long)m, full.end());
+    Blocks s = op_sub(B, a, t);
+    s = op_shift_clear(B, LFHE_OP_SHR, s, 1);
+    s = op_add(B, s, t);
+    const Blocks q = op_shift_clear(B, LFHE_OP_SHR, s, (long)l - 1);
+    if (quot) *quot = q;
+    if (rem) *rem = op_sub(B, a, op_mul_clear(B, clean(B, q), d, m));
+}
+
 }  // namespace
 
-Program build_program(uint32_t op, uint32_t width, int lhs_noise, int rhs_noise, int cond_noise) {
+Program build_program(uint32_t op, uint32_t width, int lhs_noise, int rhs_noise, int cond_noise, const uint8_t* scalar) {
     Builder B;
     B.P.op = op;
     B.P.width = width;
@@ -318,8 +531,15 @@ Program build_program(uint32_t op, uint32_t width, int lhs_noise, int rhs_noise,
     for (uint32_t i = 0; i < m; ++i) a.push_back(B.input(deg, lhs_noise));
     B.P.lhs = a;
     const bool unary = op == LFHE_OP_NOT || op == LFHE_OP_NEG;
-    if (!unary) {
-        for (uint32_t i = 0; i < m; ++i) b.push_back(B.input(deg, rhs_noise));
+    const bool shift = op == LFHE_OP_SHL || op == LFHE_OP_SHR || op == LFHE_OP_ROTL || op == LFHE_OP_ROTR;
+    const bool divrem = op == LFHE_OP_DIV || op == LFHE_OP_REM;
+    if ((shift || divrem) && width == 1) throw std::invalid_argument("operator not supported");
+    if (divrem && !scalar) throw std::invalid_argument("operator not supported");  // clear divisor only
+    const bool specialised = scalar && (shift || divrem);
+    B.P.rhs_width = (unary || specialised) ? 0 : (shift ? 8 : width);
+    if (B.P.rhs_width) {
+        const uint32_t mr = B.P.rhs_width == 1 ? 1 : B.P.rhs_width / 2;
+        for (uint32_t i = 0; i < mr; ++i) b.push_back(B.input(deg, rhs_noise));
         B.P.rhs = b;
     }
     uint32_t c = 0;
@@ -344,6 +564,23 @@ Program build_program(uint32_t op, uint32_t width, int lhs_noise, int rhs_noise,
         case LFHE_OP_MIN: B.P.out = op_select(B, op_cmp(B, a, b, LFHE_OP_LT), a, b); break;
         case LFHE_OP_MAX: B.P.out = op_select(B, op_cmp(B, a, b, LFHE_OP_GT), a, b); break;
         case LFHE_OP_SELECT: B.P.out = op_select(B, c, a, b); break;
+        case LFHE_OP_SHL: case LFHE_OP_SHR: case LFHE_OP_ROTL: case LFHE_OP_ROTR:
+            if (scalar) {
+                long t = 0;  // amount modulo the width (a divisor of 2^16 * 5 for every supported width)
+                for (int i = 31; i >= 0; --i) t = (t * 256 + scalar[i]) % (long)width;
+                B.P.out = op_shift_clear(B, op, a, t);
+            } else {
+                B.P.out = op_shift_encrypted(B, op, a, b);
+            }
+            break;
+        case LFHE_OP_DIV: case LFHE_OP_REM: {
+            Nat d(4);
+            for (int i = 0; i < 32; ++i) d[i / 8] |= (uint64_t)scalar[i] << (8 * (i % 8));
+            Blocks r;
+            op_divrem_clear(B, a, d, op == LFHE_OP_DIV ? &r : nullptr, op == LFHE_OP_REM ? &r : nullptr);
+            B.P.out = r;
+            break;
+        }
         default: throw std::invalid_argument("operator not supported");
     }
     B.finish();

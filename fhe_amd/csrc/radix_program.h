@@ -42,6 +42,7 @@ struct Layer {
 
 struct Program {
     uint32_t op = 0, width = 0, out_width = 0;
+    uint32_t rhs_width = 0;                // 0: no encrypted right operand
     uint32_t nblocks = 0;                  // arena blocks per instance
     std::vector<uint32_t> lhs, rhs, cond;  // input block ids
     std::vector<uint32_t> out;             // output block ids, little-endian
@@ -95,6 +96,7 @@ private:
     struct Info { int level, lo, hi, noise; };
     std::vector<Info> info_;
     std::map<std::array<uint64_t, 16>, uint32_t> lut_ids_;
+    std::map<uint32_t, Expr> lin_expr_;  // blocks defined by a linear operation
     uint32_t new_block(int level, int lo, int hi, int noise) {
         info_.push_back({level, lo, hi, noise});
         return P.nblocks++;
@@ -109,6 +111,9 @@ private:
 };
 
 // operator ids are the LFHE_OP_* values of include/lfhe.h
-Program build_program(uint32_t op, uint32_t width, int lhs_noise, int rhs_noise, int cond_noise);
+// scalar: a clear right operand (32 bytes, little-endian) the program is specialised on -- shift and
+// rotation amounts, divisors; null for an encrypted (or trivially encrypted) right operand
+Program build_program(uint32_t op, uint32_t width, int lhs_noise, int rhs_noise, int cond_noise,
+                      const uint8_t* scalar = nullptr);
 
 }  // namespace lfhe

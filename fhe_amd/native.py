@@ -74,7 +74,7 @@ def load():
         "lfhe_op_from_name": (i32, [C.c_char_p]),
         "lfhe_evaluate": (i32, [vp, u32, u32, vp, u64, vp, u64, i32, vp, u64, vp, pu64]),
         "lfhe_evaluate_batch": (i32, [vp, u32, u32, u64, vp, vp, i32, vp, vp]),
-        "lfhe_program_dump": (i32, [u32, u32, i32, i32, i32, C.c_char_p, pu64]),
+        "lfhe_program_dump": (i32, [u32, u32, i32, i32, i32, C.c_char_p, C.c_char_p, pu64]),
         "lfhe_pbs_count": (i32, [vp, pu64]),
         "lfhe_make_lut": (i32, [vp, vp, vp]),
         "lfhe_pbs_batch": (i32, [vp, u64, vp, vp, u32, vp, vp]),
@@ -108,16 +108,19 @@ def le32(value: int) -> bytes:
     return int(value).to_bytes(32, "little", signed=False)
 
 
-def program(op: str, bit_width: int, lhs_noise: int = 1, rhs_noise: int = 1, cond_noise: int = 1) -> dict:
-    """The operator's bootstrap schedule (host-side plan; needs no GPU)."""
+def program(op: str, bit_width: int, lhs_noise: int = 1, rhs_noise: int = 1, cond_noise: int = 1,
+            scalar: int | None = None) -> dict:
+    """The operator's bootstrap schedule (host-side plan; needs no GPU).  `scalar`: the clear shift
+    amount or divisor a specialised schedule is built for."""
     import json
     L = load()
     n = C.c_uint64(0)
-    rc = L.lfhe_program_dump(OPS[op], bit_width, lhs_noise, rhs_noise, cond_noise, None, C.byref(n))
+    sc = None if scalar is None else int(scalar).to_bytes(32, "little")
+    rc = L.lfhe_program_dump(OPS[op], bit_width, lhs_noise, rhs_noise, cond_noise, sc, None, C.byref(n))
     if rc != LFHE_OK:
         raise LfheError(rc, f"no program for {op}/{bit_width}")
     buf = C.create_string_buffer(n.value)
-    rc = L.lfhe_program_dump(OPS[op], bit_width, lhs_noise, rhs_noise, cond_noise, buf, C.byref(n))
+    rc = L.lfhe_program_dump(OPS[op], bit_width, lhs_noise, rhs_noise, cond_noise, sc, buf, C.byref(n))
     if rc != LFHE_OK:
         raise LfheError(rc, f"no program for {op}/{bit_width}")
     return json.loads(buf.value.decode())

@@ -120,6 +120,8 @@ enum {
     LFHE_OP_NOT = 14, LFHE_OP_NEG = 15,
     LFHE_OP_SELECT = 16, /* cond ? lhs : rhs */
     LFHE_OP_SHL = 17, LFHE_OP_SHR = 18, LFHE_OP_ROTL = 19, LFHE_OP_ROTR = 20,
+    /* shift / rotation amounts are taken modulo the width; an encrypted amount is a euint8
+     * (tests/fhevm-suite/e2e/test/fhevmOperations: shl(euintN, euint8) and shl(euintN, uint8)) */
     LFHE_OP_DIV = 21, LFHE_OP_REM = 22, /* clear divisor only, as in the reference's operator set */
     LFHE_OP_CAST = 23
 };
@@ -127,7 +129,9 @@ int32_t lfhe_op_from_name(const char* name); /* "add", "sub", "lt", ... ; -1 if 
 
 /* One operation.  rhs may be a ciphertext, or (rhs_is_scalar != 0) a 32-byte little-endian clear
  * value; cond is only read by LFHE_OP_SELECT; unary operators ignore rhs.  The result width is
- * bit_width, or 1 (ebool) for comparisons. */
+ * bit_width, or 1 (ebool) for comparisons.  Shifts and rotations take a euint8 ciphertext or a
+ * clear amount; division and remainder take a clear divisor (zero is LFHE_ERR_ARG).  Operators
+ * with a clear amount or divisor run a schedule specialised on that value. */
 int32_t lfhe_evaluate(lfhe_ctx* ctx, uint32_t op, uint32_t bit_width, const uint8_t* lhs, uint64_t lhs_len,
                       const uint8_t* rhs, uint64_t rhs_len, int32_t rhs_is_scalar, const uint8_t* cond,
                       uint64_t cond_len, uint8_t* out, uint64_t* out_len);
@@ -141,7 +145,8 @@ int32_t lfhe_evaluate_batch(lfhe_ctx* ctx, uint32_t op, uint32_t bit_width, uint
  * host-side plan the executor replays, exposed for inspection and for checking the plan against a
  * plaintext model. */
 int32_t lfhe_program_dump(uint32_t op, uint32_t bit_width, int32_t lhs_noise, int32_t rhs_noise, int32_t cond_noise,
-                          char* out, uint64_t* out_len);
+                          const uint8_t* scalar /* 32 bytes or NULL: clear shift amount / divisor */, char* out,
+                          uint64_t* out_len);
 /* cumulative count of programmable bootstraps issued by this context */
 int32_t lfhe_pbs_count(const lfhe_ctx* ctx, uint64_t* out);
 

@@ -31,7 +31,8 @@ def run_plain(prog: dict, lhs: int, rhs: int | None = None, cond: int | None = N
     for b, v in zip(prog["lhs"], digits(lhs, w)):
         blk[b] = v
     if prog["rhs"]:
-        for b, v in zip(prog["rhs"], digits(rhs, w)):
+        rw = prog.get("rhs_width") or w
+        for b, v in zip(prog["rhs"], digits(rhs & ((1 << rw) - 1), rw)):
             blk[b] = v
     if prog["cond"]:
         blk[prog["cond"][0]] = cond & 1
@@ -58,7 +59,8 @@ def run_oracle(prog: dict, orc, keys, pbsk, rng, lhs: int, rhs: int | None = Non
     for b, v in zip(prog["lhs"], digits(lhs, w)):
         blk[b] = orc.encrypt_block(glwe_sk, v, rng)
     if prog["rhs"]:
-        for b, v in zip(prog["rhs"], digits(rhs, w)):
+        rw = prog.get("rhs_width") or w
+        for b, v in zip(prog["rhs"], digits(rhs & ((1 << rw) - 1), rw)):
             blk[b] = orc.encrypt_block(glwe_sk, v, rng)
     if prog["cond"]:
         blk[prog["cond"][0]] = orc.encrypt_block(glwe_sk, cond & 1, rng)

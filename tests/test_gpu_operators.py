@@ -14,7 +14,9 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 KATS = json.load(open(os.path.join(GOLDEN, "fhevm_operator_kats.json")))["kats"]
 SELECT_KATS = json.load(open(os.path.join(GOLDEN, "fhevm_select_kats.json")))["kats"]
-GPU_OPS = {"add", "sub", "mul", "eq", "ne", "ge", "gt", "le", "lt", "min", "max", "and", "or", "xor", "not", "neg"}
+GPU_OPS = {"add", "sub", "mul", "eq", "ne", "ge", "gt", "le", "lt", "min", "max", "and", "or", "xor", "not", "neg",
+           "shl", "shr", "rotl", "rotr", "div", "rem"}
+SPECIALISED = {"shl", "shr", "rotl", "rotr", "div", "rem"}
 
 
 @pytest.fixture(scope="module")
@@ -31,6 +33,9 @@ def _operands(ctx, k):
     (left clear operand) or passed as a scalar (right clear operand)."""
     op, w, ins, exp = radix.kat_case(k)
     enc = [t.startswith("e") for t in k["types"]]
+    if op in SPECIALISED:      # amounts are euint8 / clear, divisors clear: they do not widen the operand
+        w = radix.type_width(k["types"][0])
+        return op, w, ctx.encrypt(ins[0], w), ctx.encrypt(ins[1], 8) if enc[1] else ins[1], exp
     lhs = ctx.encrypt(ins[0], w, trivial=not enc[0])
     rhs = None
     if len(ins) > 1:
@@ -110,6 +115,16 @@ def test_batch_matches_single_and_clear_model(ctx):
     out = ctx.evaluate_batch("add", 64, A, [y & 0xFFFF for y in ys])  # clear right operands
     assert [ctx.decrypt(o) for o in out] == [(x + (y & 0xFFFF)) & ((1 << 64) - 1) for x, y in zip(xs, ys)]
     assert ctx.evaluate_batch("add", 64, [], []) == []
+    # clear amounts and divisors that differ between instances: grouped into specialised runs
+    amounts = [(3 * i) % 5 + 60 * (i % 2) for i in range(n)]
+    out = ctx.evaluate_batch("rotl", 64, A, amounts)
+    assert [ctx.decrypt(o) for o in out] == [radix.clear_op("rotl", 64, x, t) for x, t in zip(xs, amounts)]
+    divs = [1000003 if i % 3 else 4096 for i in range(n)]
+    out = ctx.evaluate_batch("rem", 64, A[:6], divs[:6])
+    assert [ctx.decrypt(o) for o in out] == [x % d for x, d in zip(xs[:6], divs[:6])]
+    S = [ctx.encrypt(t, 8) for t in amounts]            # encrypted amounts: one run
+    out = ctx.evaluate_batch("shr", 64, A, S)
+    assert [ctx.decrypt(o) for o in out] == [radix.clear_op("shr", 64, x, t) for x, t in zip(xs, amounts)]
 
 
 def test_erc20_transfer_semantics(ctx):
@@ -140,3 +155,9 @@ def test_error_paths(ctx):
         ctx.evaluate("select", 8, a8, a8, None)    # missing condition
     with pytest.raises(LfheError):
         ctx.encrypt(1, 12)                         # unsupported width
+    with pytest.raises(LfheError):
+        ctx.evaluate("div", 8, a8, 0)              # division by zero
+    with pytest.raises(LfheError):
+        ctx.evaluate("div", 8, a8, a8)             # encrypted divisor
+    with pytest.raises(LfheError):
+        ctx.evaluate("shl", 16, a16, a16)          # the amount must be a euint8

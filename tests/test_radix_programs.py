@@ -18,13 +18,15 @@ KATS = json.load(open(os.path.join(GOLDEN, "fhevm_operator_kats.json")))["kats"]
 SELECT_KATS = json.load(open(os.path.join(GOLDEN, "fhevm_select_kats.json")))["kats"]
 PROGRAM_OPS = {"add", "sub", "mul", "eq", "ne", "ge", "gt", "le", "lt", "min", "max", "and", "or", "xor", "not",
                "neg", "select"}
+SHIFTS = {"shl", "shr", "rotl", "rotr"}
+SPECIALISED = SHIFTS | {"div", "rem"}  # a clear right operand selects a schedule built for that value
 _cache = {}
 
 
-def prog(op, w, ln=1, rn=1, cn=1):
-    key = (op, w, ln, rn, cn)
+def prog(op, w, ln=1, rn=1, cn=1, scalar=None):
+    key = (op, w, ln, rn, cn, scalar)
     if key not in _cache:
-        _cache[key] = program(op, w, ln, rn, cn)
+        _cache[key] = program(op, w, ln, rn, cn, scalar=scalar)
     return _cache[key]
 
 
@@ -39,16 +41,21 @@ def test_reference_vectors_follow_the_clear_semantics():
 
 
 def test_programs_reproduce_every_reference_vector():
-    done = skipped = 0
+    done = 0
     for k in KATS:
         op, w, ins, exp = radix.kat_case(k)
-        if op not in PROGRAM_OPS:
-            skipped += 1
-            continue
-        got = radix.run_plain(prog(op, w), ins[0], ins[1] if len(ins) > 1 else None)
+        if op in SPECIALISED:
+            w = radix.type_width(k["types"][0])       # the amount / divisor does not widen the operand
+            if k["types"][1].startswith("e"):         # encrypted amount: a euint8
+                got = radix.run_plain(prog(op, w), ins[0], ins[1])
+            else:
+                got = radix.run_plain(prog(op, w, scalar=ins[1]), ins[0])
+        else:
+            assert op in PROGRAM_OPS
+            got = radix.run_plain(prog(op, w), ins[0], ins[1] if len(ins) > 1 else None)
         assert got == exp, k
         done += 1
-    assert done == 2394 - skipped and done >= 2100
+    assert done == 2394
 
 
 def test_select_vectors():
@@ -76,6 +83,51 @@ def test_programs_on_random_and_edge_inputs(w):
                 assert radix.run_plain(p, a, b, c) == want, (op, w, a, b)
 
 
+@pytest.mark.parametrize("w", [8, 16, 32, 64, 128, 256])
+def test_shifts_and_rotations_every_amount(w):
+    rnd = random.Random(100 + w)
+    m = (1 << w) - 1
+    vals = [m, 1, 1 << (w - 1), rnd.randrange(m + 1), rnd.randrange(m + 1)]
+    amounts = list(range(w)) if w <= 32 else [0, 1, 2, 3, w // 2 - 1, w // 2, w - 2, w - 1] + [rnd.randrange(w) for _ in range(6)]
+    for op in sorted(SHIFTS):
+        for noise in (1, 2):
+            enc = prog(op, w, noise, noise)
+            assert enc["rhs_width"] == 8
+            for t in amounts:
+                clear = prog(op, w, noise, scalar=t)
+                assert clear["pbs"] <= w // 2 * 2 and (t % 2 or clear["pbs"] == 0)
+                for a in vals[:3 if w > 64 else 5]:
+                    want = radix.clear_op(op, w, a, t)
+                    assert radix.run_plain(clear, a) == want, (op, w, a, t)
+                    # the encrypted amount is a full euint8: bits above log2(w) are ignored
+                    t8 = (t + w * rnd.randrange(256 // w)) & 0xFF if w < 256 else t
+                    assert radix.run_plain(enc, a, t8) == want, (op, w, a, t8)
+    # a clear amount beyond the width wraps like the reference's (amount mod width)
+    assert radix.run_plain(prog("shl", w, scalar=w + 3), 5) == radix.clear_op("shl", w, 5, 3)
+
+
+@pytest.mark.parametrize("w", [8, 16, 32, 64, 128, 256])
+def test_division_by_clear_divisors(w):
+    rnd = random.Random(200 + w)
+    m = (1 << w) - 1
+    divisors = [1, 2, 3, 5, 7, 10, 1 << (w // 2), (1 << (w // 2)) + 1, 1 << (w - 1), (1 << (w - 1)) + 1, m, m - 1]
+    divisors += [rnd.randrange(1, m + 1) >> rnd.randrange(w) or 1 for _ in range(6 if w <= 64 else 2)]
+    if w > 64:
+            divisors = divisors[:3] + divisors[6:]
+    for d in divisors:
+        pq, pr = prog("div", w, scalar=d), prog("rem", w, scalar=d)
+        vals = [0, 1, m, d, d - 1, (d + 1) & m, (m // d) * d, ((m // d) * d - 1) & m] + [rnd.randrange(m + 1) for _ in range(12 if w <= 64 else 3)]
+        for a in vals:
+            assert radix.run_plain(pq, a) == a // d, (w, a, d)
+            assert radix.run_plain(pr, a) == a % d, (w, a, d)
+    q2 = prog("div", w, 2, scalar=3)   # noise-2 input (a select result)
+    assert radix.run_plain(q2, m) == m // 3
+    with pytest.raises(LfheError):
+        program("div", w, scalar=0)       # division by zero
+    with pytest.raises(LfheError):
+        program("div", w)                 # encrypted divisor: not in the reference's operator set
+
+
 def test_schedule_sizes_are_reported():
     """Bootstraps per operation (the scheduler's own count; the reference publishes none)."""
     want_at_most = {("add", 64): 230, ("mul", 64): 2000, ("lt", 64): 63, ("eq", 64): 45, ("select", 64): 64}
@@ -101,3 +153,7 @@ def test_programs_on_real_ciphertexts_small_parameters():
     for op, w, a, b, c in cases:
         got = radix.run_oracle(prog(op, w), orc, keys, pb, r, a, b, c)
         assert got == radix.clear_op(op, w, a, b, c), (op, a, b)
+    for op, a, t in [("shl", 0xB5, 3), ("rotr", 0xB5, 5), ("shr", 0xB5, 7)]:   # encrypted amounts
+        assert radix.run_oracle(prog(op, 8), orc, keys, pb, r, a, t) == radix.clear_op(op, 8, a, t), (op, a, t)
+    for op, a, d in [("rotl", 0xB5, 3), ("div", 200, 7), ("rem", 200, 7), ("div", 255, 16)]:  # clear operand
+        assert radix.run_oracle(prog(op, 8, scalar=d), orc, keys, pb, r, a) == radix.clear_op(op, 8, a, d), (op, a, d)
