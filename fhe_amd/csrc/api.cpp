@@ -4,6 +4,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <thread>
+#include <vector>
 
 #include "ctx.h"
 #include "tables.h"
@@ -52,14 +53,20 @@ extern "C" {
 
 const char* lfhe_version(void) { return "lfhe-mi355x 0.1 (gfx950)"; }
 
-void lfhe_default_params(lfhe_params* p) {
-    if (!p) return;
-    EngineParams d;
+static void params_out(const EngineParams& d, lfhe_params* p) {
+    std::memset(p, 0, sizeof *p);
     p->lwe_dim = d.lwe_dim; p->glwe_dim = d.glwe_dim; p->poly_size = d.poly_size;
     p->pbs_base_log = d.pbs_base_log; p->pbs_level = d.pbs_level;
     p->ks_base_log = d.ks_base_log; p->ks_level = d.ks_level;
     p->message_modulus = d.message_modulus; p->carry_modulus = d.carry_modulus;
     p->lwe_noise_log2 = d.lwe_noise_log2; p->glwe_noise_log2 = d.glwe_noise_log2;
+    p->ms_zeros_count = d.ms_zeros_count; p->ms_bound_log2 = d.ms_bound_log2;
+    p->ms_r_sigma_factor = d.ms_r_sigma_factor; p->ms_input_variance = d.ms_input_variance;
+}
+
+void lfhe_default_params(lfhe_params* p) {
+    if (!p) return;
+    params_out(EngineParams(), p);
 }
 
 int32_t lfhe_ctx_create_custom(lfhe_ctx** out, const lfhe_params* p, int32_t device, const uint8_t seed[32]) {
@@ -72,6 +79,8 @@ int32_t lfhe_ctx_create_custom(lfhe_ctx** out, const lfhe_params* p, int32_t dev
     c->prm.ks_base_log = p->ks_base_log; c->prm.ks_level = p->ks_level;
     c->prm.message_modulus = p->message_modulus; c->prm.carry_modulus = p->carry_modulus;
     c->prm.lwe_noise_log2 = p->lwe_noise_log2; c->prm.glwe_noise_log2 = p->glwe_noise_log2;
+    c->prm.ms_zeros_count = p->ms_zeros_count; c->prm.ms_bound_log2 = p->ms_bound_log2;
+    c->prm.ms_r_sigma_factor = p->ms_r_sigma_factor; c->prm.ms_input_variance = p->ms_input_variance;
     std::memcpy(c->seed, seed, 32);
     c->enc_rng.init(seed, 16);
     int32_t rc = LFHE_OK;
@@ -107,12 +116,7 @@ const char* lfhe_last_error(const lfhe_ctx* ctx) { return ctx ? ctx->err.c_str()
 
 int32_t lfhe_get_params(const lfhe_ctx* ctx, lfhe_params* p) {
     if (!ctx || !p) return LFHE_ERR_ARG;
-    const EngineParams& d = ctx->prm;
-    p->lwe_dim = d.lwe_dim; p->glwe_dim = d.glwe_dim; p->poly_size = d.poly_size;
-    p->pbs_base_log = d.pbs_base_log; p->pbs_level = d.pbs_level;
-    p->ks_base_log = d.ks_base_log; p->ks_level = d.ks_level;
-    p->message_modulus = d.message_modulus; p->carry_modulus = d.carry_modulus;
-    p->lwe_noise_log2 = d.lwe_noise_log2; p->glwe_noise_log2 = d.glwe_noise_log2;
+    params_out(ctx->prm, p);
     return LFHE_OK;
 }
 
@@ -135,7 +139,7 @@ int32_t lfhe_health(lfhe_ctx* ctx, char* out, uint64_t* out_len) {
 // ---- keys --------------------------------------------------------------------------------------
 static void upload_server_keys(lfhe_ctx* c) {
     c->eng->load_bsk(c->bsk.data());
-    c->eng->load_ksk(c->ksk.data());
+    c->eng->load_ksk(c->ksk.data(), c->ms_zeros.empty() ? nullptr : c->ms_zeros.data());
     c->have_server = true;
 }
 
@@ -152,19 +156,24 @@ int32_t lfhe_keygen(lfhe_ctx* ctx) {
         ctx->ksk.resize(ctx->eng->ksk_words());
         gen_bsk(p, ctx->lwe_sk.data(), ctx->glwe_sk.data(), ctx->seed, ctx->bsk.data(), host_threads());
         gen_ksk(p, ctx->glwe_sk.data(), ctx->lwe_sk.data(), ctx->seed, ctx->ksk.data(), host_threads());
+        ctx->ms_zeros.resize(ctx->eng->ms_zeros_words());
+        gen_ms_zeros(p, ctx->lwe_sk.data(), ctx->seed, ctx->ms_zeros.data(), host_threads());
         upload_server_keys(ctx);
         return LFHE_OK;
     });
 }
 
 int32_t lfhe_server_keys_import_raw(lfhe_ctx* ctx, const uint64_t* bsk, uint64_t bsk_words, const uint64_t* ksk,
-                                    uint64_t ksk_words) {
+                                    uint64_t ksk_words, const uint64_t* ms_zeros, uint64_t ms_words) {
     return guarded(ctx, [&]() -> int32_t {
         if (!bsk || !ksk) throw std::invalid_argument("null key pointer");
-        if (bsk_words != ctx->eng->bsk_raw_words() || ksk_words != ctx->eng->ksk_words())
+        if (bsk_words != ctx->eng->bsk_raw_words() || ksk_words != ctx->eng->ksk_words() ||
+            (ms_zeros && ms_words && ms_words != ctx->eng->ms_zeros_words()))
             throw std::invalid_argument("server key size does not match the parameter set");
         ctx->bsk.assign(bsk, bsk + bsk_words);
         ctx->ksk.assign(ksk, ksk + ksk_words);
+        if (ms_zeros && ms_words) ctx->ms_zeros.assign(ms_zeros, ms_zeros + ms_words);
+        else ctx->ms_zeros.clear();
         upload_server_keys(ctx);
         return LFHE_OK;
     });
@@ -189,33 +198,35 @@ constexpr uint32_t KEY_MAGIC = 0x4b46484cu;  // "LHFK"
 struct KeyHeader {
     uint32_t magic, which;
     lfhe_params prm;
-    uint64_t words_a, words_b;
+    uint64_t words_a, words_b, words_c;
 };
 }  // namespace
 
 int32_t lfhe_keys_export(lfhe_ctx* ctx, uint32_t which, uint8_t* out, uint64_t* out_len) {
     return guarded(ctx, [&]() -> int32_t {
         if (!out_len) throw std::invalid_argument("null out_len");
-        const std::vector<uint64_t>*a, *b;
+        static const std::vector<uint64_t> none;
+        const std::vector<uint64_t>*a, *b, *c = &none;
         if (which == LFHE_KEY_CLIENT) {
             if (!ctx->have_client) throw std::logic_error("no client keys");
             a = &ctx->lwe_sk; b = &ctx->glwe_sk;
         } else if (which == LFHE_KEY_SERVER) {
             if (!ctx->have_server) throw std::logic_error("no server keys");
-            a = &ctx->bsk; b = &ctx->ksk;
+            a = &ctx->bsk; b = &ctx->ksk; c = &ctx->ms_zeros;
         } else {
             throw std::invalid_argument("unknown key kind");
         }
-        const uint64_t need = sizeof(KeyHeader) + (a->size() + b->size()) * 8;
+        const uint64_t need = sizeof(KeyHeader) + (a->size() + b->size() + c->size()) * 8;
         if (!out) { *out_len = need; return LFHE_OK; }
         if (*out_len < need) { *out_len = need; return LFHE_ERR_SIZE; }
         KeyHeader h{};
         h.magic = KEY_MAGIC; h.which = which;
         lfhe_get_params(ctx, &h.prm);
-        h.words_a = a->size(); h.words_b = b->size();
+        h.words_a = a->size(); h.words_b = b->size(); h.words_c = c->size();
         std::memcpy(out, &h, sizeof h);
         std::memcpy(out + sizeof h, a->data(), a->size() * 8);
         std::memcpy(out + sizeof h + a->size() * 8, b->data(), b->size() * 8);
+        if (!c->empty()) std::memcpy(out + sizeof h + (a->size() + b->size()) * 8, c->data(), c->size() * 8);
         *out_len = need;
         return LFHE_OK;
     });
@@ -229,19 +240,21 @@ int32_t lfhe_keys_import(lfhe_ctx* ctx, uint32_t which, const uint8_t* in, uint6
     lfhe_params mine;
     lfhe_get_params(ctx, &mine);
     if (h.magic != KEY_MAGIC || h.which != which || std::memcmp(&h.prm, &mine, sizeof mine) != 0 ||
-        len != sizeof h + (h.words_a + h.words_b) * 8) {
+        len != sizeof h + (h.words_a + h.words_b + h.words_c) * 8) {
         ctx->err = "key blob does not match this context";
         return LFHE_ERR_FORMAT;
     }
     const uint64_t* a = reinterpret_cast<const uint64_t*>(in + sizeof h);
-    std::vector<uint64_t> va(h.words_a), vb(h.words_b);
+    std::vector<uint64_t> va(h.words_a), vb(h.words_b), vc(h.words_c);
     std::memcpy(va.data(), a, h.words_a * 8);
     std::memcpy(vb.data(), in + sizeof h + h.words_a * 8, h.words_b * 8);
+    if (h.words_c) std::memcpy(vc.data(), in + sizeof h + (h.words_a + h.words_b) * 8, h.words_c * 8);
     if (which == LFHE_KEY_CLIENT) {
         if (h.words_a != ctx->prm.lwe_dim || h.words_b != (uint64_t)N) { ctx->err = "bad client key size"; return LFHE_ERR_FORMAT; }
         return lfhe_client_keys_import_raw(ctx, va.data(), vb.data());
     }
-    return lfhe_server_keys_import_raw(ctx, va.data(), va.size(), vb.data(), vb.size());
+    return lfhe_server_keys_import_raw(ctx, va.data(), va.size(), vb.data(), vb.size(), vc.empty() ? nullptr : vc.data(),
+                                       vc.size());
 }
 
 int32_t lfhe_device_keys_size(const lfhe_ctx* ctx, uint64_t* bsk_bytes, uint64_t* ksk_bytes) {
@@ -308,6 +321,7 @@ int32_t lfhe_pbs_batch_device_timed(lfhe_ctx* ctx, uint64_t count, const void* d
         for (uint32_t it = 0; it < iters; ++it) {
             HC(hipEventRecord(e0, E.stream()));
             E.keyswitch(static_cast<const u64*>(d_lwe_in), small, count);
+            E.ms_noise_reduce(small, count);
             HC(hipEventRecord(e1, E.stream()));
             E.blind_rotate(small, static_cast<const u64*>(d_lut_bodies), static_cast<const u32*>(d_lut_index),
                            nullptr, static_cast<u64*>(d_lwe_out), count);
@@ -444,6 +458,28 @@ int32_t lfhe_keyswitch(lfhe_ctx* ctx, uint64_t count, const uint64_t* lwe_in, ui
         E.keyswitch(din.p, dout.p, count);
         dout.download(lwe_small_out, count * ws, E.stream());
         E.sync();
+        return LFHE_OK;
+    });
+}
+
+int32_t lfhe_ms_noise_reduce(lfhe_ctx* ctx, uint64_t count, uint64_t* lwe_small, int32_t* chosen) {
+    return guarded(ctx, [&]() -> int32_t {
+        if (!count) return LFHE_OK;
+        if (!lwe_small) throw std::invalid_argument("null pointer");
+        require_server(ctx);
+        Engine& E = *ctx->eng;
+        if (!E.has_ms_zeros()) throw std::logic_error("the key set holds no encryptions of zero");
+        HC(hipSetDevice(E.device()));
+        const size_t ws = (size_t)ctx->prm.lwe_dim + 1;
+        DevBuf<u64> d(count * ws);
+        DevBuf<int> dc(count);
+        d.upload(lwe_small, count * ws, E.stream());
+        E.ms_noise_reduce(d.p, count, dc.p);
+        d.download(lwe_small, count * ws, E.stream());
+        std::vector<int> hc(count);
+        dc.download(hc.data(), count, E.stream());
+        E.sync();
+        if (chosen) for (uint64_t i = 0; i < count; ++i) chosen[i] = hc[i];
         return LFHE_OK;
     });
 }

@@ -18,6 +18,7 @@ struct lfhe_ctx {
     std::vector<uint64_t> glwe_sk; // N words of 0/1
     bool have_client = false;
     std::vector<uint64_t> bsk, ksk;  // host copies of the server keys (coefficient domain)
+    std::vector<uint64_t> ms_zeros;  // [ms_zeros_count][n+1], empty when the key set has none
     bool have_server = false;
     uint64_t pbs_count = 0;
     std::unique_ptr<struct lfhe_radix> radix;  // operator layer state (radix.cpp)

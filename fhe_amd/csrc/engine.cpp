@@ -1,5 +1,6 @@
 #include "engine.h"
 
+#include <cmath>
 #include <stdexcept>
 #include <vector>
 
@@ -20,6 +21,10 @@ Engine::Engine(int device, const EngineParams& p) : device_(device), prm_(p) {
         p.ks_base_log * p.ks_level > 32)
         throw std::runtime_error("unsupported key-switch decomposition");
     if (p.lwe_dim < 1 || p.lwe_dim > 4096) throw std::runtime_error("unsupported LWE dimension");
+    if (p.ms_zeros_count && (p.ms_bound_log2 < 27 || p.ms_bound_log2 > 63 || !(p.ms_r_sigma_factor > 0) ||
+                             !(p.ms_r_sigma_factor < 1024) || !(p.ms_input_variance >= 0) ||
+                             !(p.ms_input_variance < 1e-3)))
+        throw std::runtime_error("unsupported modulus-switch noise reduction parameters");
     int ndev = 0;
     HC(hipGetDeviceCount(&ndev));
     if (ndev <= 0) throw std::runtime_error("no HIP device: the HIP path is the only path");
@@ -79,7 +84,17 @@ void Engine::load_bsk(const u64* host_bsk) {
     HC(hipFree(d_raw));
 }
 
-void Engine::load_ksk(const u64* host_ksk) {
+void Engine::set_ms_params(u32 zcount) {
+    ms_ = MsParams{};
+    ms_.zcount = zcount;
+    if (!zcount) return;
+    ms_.var_in_fx = (u64)std::llround(std::ldexp(prm_.ms_input_variance, 76));
+    ms_.r_fx = (u64)std::llround(std::ldexp(prm_.ms_r_sigma_factor, 16));
+    ms_.bound_fx = 1ull << (prm_.ms_bound_log2 - 26);
+    ms_.log2_2n = LOGN + 1;
+}
+
+void Engine::load_ksk(const u64* host_ksk, const u64* ms_zeros) {
     HC(hipSetDevice(device_));
     if (!d_ksk_) {
         if (d_bsk_ && !own_keys_) throw std::runtime_error("keys are attached, not owned");
@@ -90,17 +105,34 @@ void Engine::load_ksk(const u64* host_ksk) {
     launch_ksk_colsum(d_ksk_, N * (int)prm_.ks_level, (int)prm_.lwe_dim + 1, 1 << (prm_.ks_base_log - 1),
                       d_ksk_ + ksk_words(), stream_);
     HC(hipGetLastError());
+    const u64 zc = (ms_zeros && prm_.ms_zeros_count) ? prm_.ms_zeros_count : 0;
+    HC(hipMemcpyAsync(ms_zeros_dev() - 1, &zc, sizeof zc, hipMemcpyHostToDevice, stream_));
+    if (zc) HC(hipMemcpyAsync(ms_zeros_dev(), ms_zeros, ms_zeros_words() * sizeof(u64), hipMemcpyHostToDevice, stream_));
+    else if (ms_zeros_words()) HC(hipMemsetAsync(ms_zeros_dev(), 0, ms_zeros_words() * sizeof(u64), stream_));
     HC(hipStreamSynchronize(stream_));
+    set_ms_params((u32)zc);
 }
 
-void Engine::attach_device_keys(double* bsk_dev, u64* ksk_dev_with_colsum) {
+void Engine::attach_device_keys(double* bsk_dev, u64* ksk_dev_image) {
+    HC(hipSetDevice(device_));
     if (own_keys_) {
         (void)hipFree(d_bsk_);
         (void)hipFree(d_ksk_);
         own_keys_ = false;
     }
     d_bsk_ = bsk_dev;
-    d_ksk_ = ksk_dev_with_colsum;
+    d_ksk_ = ksk_dev_image;
+    u64 zc = 0;
+    HC(hipMemcpy(&zc, ms_zeros_dev() - 1, sizeof zc, hipMemcpyDeviceToHost));
+    if (zc != 0 && zc != prm_.ms_zeros_count) throw std::runtime_error("attached key image does not match the parameter set");
+    set_ms_params((u32)zc);
+}
+
+void Engine::ms_noise_reduce(u64* lwe_small, size_t count, int* chosen) {
+    if (!count || !ms_.zcount) return;
+    HC(hipSetDevice(device_));
+    launch_ms_noise_reduce(lwe_small, (int)prm_.lwe_dim, ms_zeros_dev(), ms_, chosen, count, stream_);
+    HC(hipGetLastError());
 }
 
 u64* Engine::small_scratch(size_t count) {
@@ -143,6 +175,7 @@ void Engine::pbs_layer(u64* arena, size_t instances, size_t inst_stride_blocks, 
     u64* small = small_scratch(count);
     BlockMap im{in_idx, ops, inst_stride_blocks}, om{out_idx, ops, inst_stride_blocks};
     keyswitch(arena, small, count, im);
+    ms_noise_reduce(small, count);
     blind_rotate(small, luts, lut_of_op, nullptr, arena, count, om);
 }
 
@@ -168,6 +201,7 @@ void Engine::pbs_batch(const u64* lwe_in, const u64* luts, const u32* lut_index,
     if (!count) return;
     u64* small = small_scratch(count);
     keyswitch(lwe_in, small, count);
+    ms_noise_reduce(small, count);
     blind_rotate(small, luts, lut_index, nullptr, lwe_out, count);
 }
 

@@ -6,6 +6,7 @@
 
 #include <string>
 
+#include "ms_noise.h"
 #include "pbs_phases.h"
 #include "radix_program.h"
 
@@ -30,6 +31,11 @@ struct EngineParams {
     uint32_t ks_base_log = 4, ks_level = 4;
     uint32_t message_modulus = 4, carry_modulus = 4;
     uint32_t lwe_noise_log2 = 45, glwe_noise_log2 = 17;
+    // modulus-switch noise reduction (ms_noise.h); ms_zeros_count = 0 switches it off
+    uint32_t ms_zeros_count = 1449;
+    uint32_t ms_bound_log2 = 58;
+    double ms_r_sigma_factor = 13.179852282053789;
+    double ms_input_variance = 2.63039184094559e-07;
 };
 
 // kernel launchers (kernels.hip)
@@ -45,6 +51,8 @@ void launch_lin_batch(u64* arena, const LinOp* ops, int nops, size_t instances, 
 void launch_ksk_colsum(const u64* ksk, int rows, int cols, int half_base, u64* colsum, hipStream_t st);
 void launch_keyswitch(const u64* ksk, const u64* colsum, const u64* in, u64* out, size_t count, int big, int n,
                       int base_log, int levels, const BlockMap& imap, hipStream_t st);
+void launch_ms_noise_reduce(u64* lwe_small, int n, const u64* zeros, const MsParams& m, int* chosen, size_t count,
+                            hipStream_t st);
 void launch_lwe_linear(const u64* a, const u64* b, u64* out, size_t count, int dim1, u64 ca, u64 cb, u64 add_body,
                        hipStream_t st);
 
@@ -65,21 +73,29 @@ public:
     size_t bsk_raw_words() const { return (size_t)prm_.lwe_dim * 4 * N; }
     size_t ksk_words() const { return (size_t)N * prm_.ks_level * (prm_.lwe_dim + 1); }
     size_t bsk_dev_bytes() const { return (size_t)prm_.lwe_dim * BSK_ROW * sizeof(double); }
-    size_t ksk_dev_bytes() const { return (ksk_words() + prm_.lwe_dim + 1) * sizeof(u64); }
+    size_t ms_zeros_words() const { return (size_t)prm_.ms_zeros_count * (prm_.lwe_dim + 1); }
+    // device image of the key-switching key: key words, n+1 column sums, one word holding the
+    // number of encryptions of zero that follow (0 when the key set came without them), the zeros
+    size_t ksk_dev_bytes() const { return (ksk_words() + prm_.lwe_dim + 1 + 1 + ms_zeros_words()) * sizeof(u64); }
 
     // key material: host coefficient-domain keys in, device images built here
     void load_bsk(const u64* host_bsk);   // [n][row][poly][N]
-    void load_ksk(const u64* host_ksk);   // [N][level][n+1]
+    // [N][level][n+1]; ms_zeros [ms_zeros_count][n+1] or null
+    void load_ksk(const u64* host_ksk, const u64* ms_zeros = nullptr);
     // or attach images that already sit in device memory (e.g. received by a broadcast);
     // the engine does not take ownership
-    void attach_device_keys(double* bsk_dev, u64* ksk_dev_with_colsum);
+    void attach_device_keys(double* bsk_dev, u64* ksk_dev_image);
     double* bsk_dev() const { return d_bsk_; }
-    u64* ksk_dev() const { return d_ksk_; }   // ksk words followed by the n+1 column sums
+    u64* ksk_dev() const { return d_ksk_; }
+    bool has_ms_zeros() const { return ms_.zcount != 0; }
 
     // ---- device-pointer operations, asynchronous on stream()
     // count bootstraps: lwe_in [count][N+1], luts [nluts][N] body polynomials, lut_index [count] or null
     void pbs_batch(const u64* lwe_in, const u64* luts, const u32* lut_index, u64* lwe_out, size_t count);
     void keyswitch(const u64* lwe_in, u64* lwe_small_out, size_t count, const BlockMap& imap = BlockMap());
+    // in place on [count][n+1] small ciphertexts; a no-op without encryptions of zero;
+    // chosen [count] (device, may be null) receives the candidate taken (-1: none added)
+    void ms_noise_reduce(u64* lwe_small, size_t count, int* chosen = nullptr);
     void blind_rotate(const u64* lwe_small, const u64* luts, const u32* lut_index, u64* glwe_out, u64* lwe_out,
                       size_t count, const BlockMap& omap = BlockMap());
     // one bootstrap layer of a radix program: ops bootstraps per instance, inputs and outputs are
@@ -110,6 +126,9 @@ private:
     size_t small_cap_ = 0;
     u64* d_acc_ = nullptr;
     size_t acc_cap_ = 0;
+    MsParams ms_{};
+    void set_ms_params(u32 zcount);
+    u64* ms_zeros_dev() const { return d_ksk_ + ksk_words() + prm_.lwe_dim + 1 + 1; }
 };
 
 void hip_check(hipError_t e, const char* what);

@@ -125,6 +125,14 @@ void gen_ksk(const EngineParams& p, const uint64_t* glwe_sk, const uint64_t* lwe
     });
 }
 
+void gen_ms_zeros(const EngineParams& p, const uint64_t* lwe_sk, const uint8_t seed[32], uint64_t* zeros, int threads) {
+    const size_t n1 = (size_t)p.lwe_dim + 1;
+    parallel_for((size_t)p.ms_zeros_count, threads, [&](size_t i) {
+        ChaCha r(seed, 0x300000000ull + i);
+        lwe_encrypt(lwe_sk, p.lwe_dim, 0, p.lwe_noise_log2, r, zeros + i * n1);
+    });
+}
+
 void gen_public_key(const EngineParams& p, const uint64_t* glwe_sk, const uint8_t seed[32], uint64_t* pk) {
     ChaCha r(seed, 5);
     uint64_t* a = pk;

@@ -39,6 +39,10 @@ void gen_bsk(const EngineParams& p, const uint64_t* lwe_sk, const uint64_t* glwe
 void gen_ksk(const EngineParams& p, const uint64_t* glwe_sk, const uint64_t* lwe_sk, const uint8_t seed[32],
              uint64_t* ksk, int threads);
 
+// encryptions of zero under the small key for the modulus-switch noise reduction:
+// zeros[ms_zeros_count][n+1]
+void gen_ms_zeros(const EngineParams& p, const uint64_t* lwe_sk, const uint8_t seed[32], uint64_t* zeros, int threads);
+
 // Compact (RLWE) public key under the GLWE secret key: pk = (a, b = a (*) s + e), 2N words.
 void gen_public_key(const EngineParams& p, const uint64_t* glwe_sk, const uint8_t seed[32], uint64_t* pk);
 // Public-key encryption of up to N plaintexts (already scaled by delta) into LWE blocks under the

@@ -395,6 +395,64 @@ void launch_lin_batch(u64* arena, const LinOp* ops, int nops, size_t instances, 
                        inst_stride_blocks, delta);
 }
 
+// ------------------------------------------------------------------------------------------------
+// modulus-switch noise reduction (ms_noise.h): one workgroup per small ciphertext, one wavefront
+// per candidate, four candidates per round in index order (-1 = the ciphertext as it is)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ i64 wave_sum_i64(i64 v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+__global__ void __launch_bounds__(256) k_ms_noise_reduce(u64* __restrict__ lwe_small, int n,
+                                                         const u64* __restrict__ zeros, MsParams m,
+                                                         int* __restrict__ chosen_out) {
+    extern __shared__ u64 ms_ct[];  // n + 1 words
+    __shared__ u64 est[4];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    u64* ct = lwe_small + (size_t)blockIdx.x * (n + 1);
+    for (int j = t; j <= n; j += 256) ms_ct[j] = ct[j];
+    __syncthreads();
+    u64 best = ~0ull;
+    int best_idx = -1, chosen = -2;
+    for (int base = -1; base < (int)m.zcount && chosen == -2; base += 4) {
+        const int cand = base + wave;
+        if (cand < (int)m.zcount) {
+            const u64* z = zeros + (size_t)(cand < 0 ? 0 : cand) * (n + 1);
+            i64 s1 = 0, s2 = 0;
+            for (int j = lane; j <= n; j += 64) {
+                const u64 a = ms_ct[j] + (cand < 0 ? 0 : z[j]);
+                const i64 e = ms_round_error(a, m.log2_2n);
+                if (j == n) s1 += 2 * e;
+                else { s1 -= e; const i64 h = e >> 26; s2 += h * h; }
+            }
+            s1 = wave_sum_i64(s1);
+            s2 = wave_sum_i64(s2);
+            if (lane == 0) est[wave] = ms_estimate(s1, (u64)s2, m);
+        }
+        __syncthreads();
+        for (int w = 0; w < 4 && base + w < (int)m.zcount; ++w) {
+            const u64 e = est[w];
+            if (e <= m.bound_fx) { chosen = base + w; break; }
+            if (e < best) { best = e; best_idx = base + w; }
+        }
+        __syncthreads();
+    }
+    if (chosen == -2) chosen = best_idx;
+    if (chosen >= 0) {
+        const u64* z = zeros + (size_t)chosen * (n + 1);
+        for (int j = t; j <= n; j += 256) ct[j] = ms_ct[j] + z[j];
+    }
+    if (chosen_out && t == 0) chosen_out[blockIdx.x] = chosen;
+}
+
+void launch_ms_noise_reduce(u64* lwe_small, int n, const u64* zeros, const MsParams& m, int* chosen, size_t count,
+                            hipStream_t st) {
+    hipLaunchKernelGGL(k_ms_noise_reduce, dim3((unsigned)count), dim3(256), (size_t)(n + 1) * sizeof(u64), st,
+                       lwe_small, n, zeros, m, chosen);
+}
+
 void launch_lwe_linear(const u64* a, const u64* b, u64* out, size_t count, int dim1, u64 ca, u64 cb, u64 add_body,
                        hipStream_t st) {
     const size_t total = count * (size_t)dim1;

@@ -31,7 +31,14 @@ class LfheError(RuntimeError):
 class Params(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "lwe_dim", "glwe_dim", "poly_size", "pbs_base_log", "pbs_level", "ks_base_log", "ks_level",
-        "message_modulus", "carry_modulus", "lwe_noise_log2", "glwe_noise_log2")]
+        "message_modulus", "carry_modulus", "lwe_noise_log2", "glwe_noise_log2", "ms_zeros_count",
+        "ms_bound_log2")] + [("ms_r_sigma_factor", C.c_double), ("ms_input_variance", C.c_double)]
+
+
+def default_params() -> Params:
+    p = Params()
+    load().lfhe_default_params(C.byref(p))
+    return p
 
 
 _lib = None
@@ -60,7 +67,7 @@ def load():
         "lfhe_keygen": (i32, [vp]),
         "lfhe_keys_export": (i32, [vp, u32, vp, pu64]),
         "lfhe_keys_import": (i32, [vp, u32, vp, u64]),
-        "lfhe_server_keys_import_raw": (i32, [vp, vp, u64, vp, u64]),
+        "lfhe_server_keys_import_raw": (i32, [vp, vp, u64, vp, u64, vp, u64]),
         "lfhe_client_keys_import_raw": (i32, [vp, vp, vp]),
         "lfhe_public_key": (i32, [vp, vp, pu64]),
         "lfhe_device_keys_size": (i32, [vp, pu64, pu64]),
@@ -87,6 +94,7 @@ def load():
         "lfhe_external_product": (i32, [vp, u64, vp, vp, vp]),
         "lfhe_keyswitch": (i32, [vp, u64, vp, vp]),
         "lfhe_blind_rotate": (i32, [vp, u64, vp, vp, u32, vp, vp]),
+        "lfhe_ms_noise_reduce": (i32, [vp, u64, vp, vp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -168,9 +176,13 @@ class Context:
     def keygen(self):
         self._ck(self._L.lfhe_keygen(self._h))
 
-    def import_server_keys_raw(self, bsk: np.ndarray, ksk: np.ndarray):
+    def import_server_keys_raw(self, bsk: np.ndarray, ksk: np.ndarray, ms_zeros: np.ndarray | None = None):
+        """ms_zeros: the encryptions of zero of the modulus-switch noise reduction, or None for a
+        key set without them (the step is then skipped)."""
         bsk, ksk = _u64(bsk), _u64(ksk)
-        self._ck(self._L.lfhe_server_keys_import_raw(self._h, _ptr(bsk), bsk.size, _ptr(ksk), ksk.size))
+        z = None if ms_zeros is None else _u64(ms_zeros)
+        self._ck(self._L.lfhe_server_keys_import_raw(self._h, _ptr(bsk), bsk.size, _ptr(ksk), ksk.size, _ptr(z),
+                                                     0 if z is None else z.size))
 
     def import_client_keys_raw(self, lwe_sk: np.ndarray, glwe_sk: np.ndarray):
         a, b = _u64(lwe_sk), _u64(glwe_sk)
@@ -355,6 +367,13 @@ class Context:
         out = np.zeros((cts.shape[0], self.n + 1), dtype=np.uint64)
         self._ck(self._L.lfhe_keyswitch(self._h, cts.shape[0], _ptr(cts), _ptr(out)))
         return out
+
+    def ms_noise_reduce(self, small: np.ndarray):
+        """(reduced small ciphertexts, index of the encryption of zero added to each; -1 = none)."""
+        small = np.array(_u64(small).reshape(-1, self.n + 1), copy=True)
+        chosen = np.zeros(small.shape[0], dtype=np.int32)
+        self._ck(self._L.lfhe_ms_noise_reduce(self._h, small.shape[0], _ptr(small), _ptr(chosen)))
+        return small, chosen
 
     def blind_rotate(self, small: np.ndarray, lut_bodies: np.ndarray, lut_index=None) -> np.ndarray:
         small = _u64(small).reshape(-1, self.n + 1)

@@ -50,6 +50,13 @@ typedef struct {
     uint32_t carry_modulus;   /* 4    */
     uint32_t lwe_noise_log2;  /* 45   */
     uint32_t glwe_noise_log2; /* 17   */
+    /* modulus-switch noise reduction (privateKey.bin 24068-24110): encryptions of zero in the
+     * server key, bound on the estimate as a power of two of the 2^64 torus, sigma factor, variance
+     * of the key-switched input as a fraction of the torus squared.  ms_zeros_count = 0: off. */
+    uint32_t ms_zeros_count;  /* 1449 */
+    uint32_t ms_bound_log2;   /* 58   */
+    double ms_r_sigma_factor; /* 13.179852282053789 */
+    double ms_input_variance; /* 2.63039184094559e-07 */
 } lfhe_params;
 
 const char* lfhe_version(void);
@@ -78,14 +85,17 @@ int32_t lfhe_keygen(lfhe_ctx* ctx);
 #define LFHE_KEY_SERVER 2u /* bootstrapping + key-switching keys (coefficient domain) */
 int32_t lfhe_keys_export(lfhe_ctx* ctx, uint32_t which, uint8_t* out, uint64_t* out_len);
 int32_t lfhe_keys_import(lfhe_ctx* ctx, uint32_t which, const uint8_t* in, uint64_t len);
-/* raw import of server keys: bsk[n][row][poly][N], ksk[N][level][n+1], 64-bit words */
+/* raw import of server keys: bsk[n][row][poly][N], ksk[N][level][n+1], and the encryptions of
+ * zero ms_zeros[ms_zeros_count][n+1] of the modulus-switch noise reduction (NULL / 0: the key set
+ * has none and the step is skipped), 64-bit words */
 int32_t lfhe_server_keys_import_raw(lfhe_ctx* ctx, const uint64_t* bsk, uint64_t bsk_words, const uint64_t* ksk,
-                                    uint64_t ksk_words);
+                                    uint64_t ksk_words, const uint64_t* ms_zeros, uint64_t ms_words);
 /* raw import of the secret keys: lwe_sk[n], glwe_sk[N], words holding 0 or 1 */
 int32_t lfhe_client_keys_import_raw(lfhe_ctx* ctx, const uint64_t* lwe_sk, const uint64_t* glwe_sk);
 /* compact public key (an RLWE encryption of zero under the GLWE key, 2N words + header) */
 int32_t lfhe_public_key(lfhe_ctx* ctx, uint8_t* out, uint64_t* out_len);
-/* device images of the server keys, for replication to other GPUs (one broadcast per key set, no
+/* device images of the server keys (the second holds the key-switching key and the encryptions of
+ * zero), for replication to other GPUs (one broadcast per key set, no
  * per-operation collective): sizes, the pointers owned by this context, and attaching images that
  * were received into caller-owned device memory */
 int32_t lfhe_device_keys_size(const lfhe_ctx* ctx, uint64_t* bsk_bytes, uint64_t* ksk_bytes);
@@ -183,6 +193,11 @@ int32_t lfhe_external_product(lfhe_ctx* ctx, uint64_t count, const uint32_t* ggs
                               uint64_t* out);
 /* [count][N+1] -> [count][n+1] */
 int32_t lfhe_keyswitch(lfhe_ctx* ctx, uint64_t count, const uint64_t* lwe_in, uint64_t* lwe_small_out);
+/* modulus-switch noise reduction, in place on [count][n+1] small ciphertexts: the first candidate
+ * ct + zero_k within the bound (or the best) replaces ct; chosen[count] (may be NULL) receives k,
+ * -1 when nothing was added.  Replaces: tfhe-rs improve_lwe_ciphertext_modulus_switch_noise_for_binary_key
+ * (absent dependency; parameters at privateKey.bin 24068-24110). */
+int32_t lfhe_ms_noise_reduce(lfhe_ctx* ctx, uint64_t count, uint64_t* lwe_small, int32_t* chosen);
 /* [count][n+1] small ciphertexts -> rotated accumulators [count][2][N] */
 int32_t lfhe_blind_rotate(lfhe_ctx* ctx, uint64_t count, const uint64_t* lwe_small, const uint64_t* lut_bodies,
                           uint32_t nluts, const uint32_t* lut_index, uint64_t* glwe_out);

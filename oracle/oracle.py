@@ -34,6 +34,11 @@ class _Params(C.Structure):
         "message_modulus", "carry_modulus", "lwe_noise_log2", "glwe_noise_log2")]
 
 
+class _MsParams(C.Structure):
+    _fields_ = [("zeros_count", C.c_uint32), ("bound_log2", C.c_uint32), ("r_sigma_factor", C.c_double),
+                ("input_variance", C.c_double)]
+
+
 class _Rng(C.Structure):
     _fields_ = [("key", C.c_uint32 * 8), ("counter", C.c_uint64), ("stream", C.c_uint64),
                 ("buf", C.c_uint32 * 16), ("pos", C.c_uint32)]
@@ -103,6 +108,11 @@ def lib():
         "orc_cmux_rotate": (None, [vp, _u64p, u32, _u64p]),
         "orc_modswitch": (u32, [u64, u32]),
         "orc_keyswitch": (None, [vp, _u64p, _u64p, _u64p]),
+        "orc_default_ms_params": (None, [C.POINTER(_MsParams)]),
+        "orc_gen_ms_zeros": (None, [vp, _u64p, C.POINTER(_Rng), u32, _u64p]),
+        "orc_ms_estimate": (u64, [vp, C.POINTER(_MsParams), _u64p]),
+        "orc_ms_noise_reduce": (C.c_int32, [vp, C.POINTER(_MsParams), _u64p, _u64p]),
+        "orc_ctx_set_ms": (None, [vp, C.POINTER(_MsParams), vp]),
         "orc_blind_rotate": (None, [vp, _u64p, _u64p, _u64p, _u64p]),
         "orc_sample_extract": (None, [vp, _u64p, _u64p]),
         "orc_pbs": (None, [vp, _u64p, _u64p, _u64p, _u64p, _u64p]),
@@ -265,6 +275,41 @@ class Oracle:
         out = np.zeros(self.n + 1, dtype=np.uint64)
         lib().orc_keyswitch(self._ctx, ksk, np.ascontiguousarray(ct_big, dtype=np.uint64), out)
         return out
+
+    # -- modulus-switch noise reduction
+    def ms_params(self, zeros_count: int | None = None) -> _MsParams:
+        m = _MsParams()
+        lib().orc_default_ms_params(C.byref(m))
+        if zeros_count is not None:
+            m.zeros_count = zeros_count
+        return m
+
+    def gen_ms_zeros(self, lwe_sk: np.ndarray, seed: bytes, count: int) -> np.ndarray:
+        z = np.zeros((count, self.n + 1), dtype=np.uint64)
+        lib().orc_gen_ms_zeros(self._ctx, lwe_sk, Rng(seed, 5).ref, count, z)
+        return z
+
+    def ms_estimate(self, small: np.ndarray, m: _MsParams | None = None) -> int:
+        m = m or self.ms_params()
+        return lib().orc_ms_estimate(self._ctx, C.byref(m), np.ascontiguousarray(small, dtype=np.uint64))
+
+    def ms_noise_reduce(self, small: np.ndarray, zeros: np.ndarray, m: _MsParams | None = None):
+        """(reduced ciphertext, index of the zero that was added or -1)."""
+        m = m or self.ms_params(len(zeros))
+        out = np.array(small, dtype=np.uint64, copy=True)
+        pick = lib().orc_ms_noise_reduce(self._ctx, C.byref(m), np.ascontiguousarray(zeros, dtype=np.uint64), out)
+        return out, pick
+
+    def set_ms(self, zeros: np.ndarray | None, m: _MsParams | None = None):
+        """Make pbs()/pbs_batch() include the noise-reduction step (None switches it off)."""
+        if zeros is None:
+            self._ms_keep = None
+            lib().orc_ctx_set_ms(self._ctx, None, None)
+            return
+        z = np.ascontiguousarray(zeros, dtype=np.uint64)
+        m = m or self.ms_params(len(z))
+        self._ms_keep = (z, m)
+        lib().orc_ctx_set_ms(self._ctx, C.byref(m), z.ctypes.data_as(C.c_void_p))
 
     def prepare_bsk(self, bsk: np.ndarray):
         return _PreparedBsk(self, bsk)

@@ -9,6 +9,7 @@
  */
 #include "tfhe_oracle.h"
 
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -238,6 +239,8 @@ struct orc_ctx {
     u32 logN;
     ntt_prime pr[2];
     u64 p0_inv_mod_p1; /* plain */
+    orc_ms_params ms;    /* zeros_count == 0: the noise-reduction step is off */
+    const u64* ms_zeros; /* borrowed */
 };
 
 void orc_default_params(orc_params* p) {
@@ -557,6 +560,84 @@ uint32_t orc_modswitch(uint64_t x, uint32_t log2_2N) {
     return (u32)(t & (((u64)1 << log2_2N) - 1));
 }
 
+/* ---- modulus-switch noise reduction ---- */
+void orc_default_ms_params(orc_ms_params* m) {
+    /* reference fixture sdk/relayer/src/test/keys/privateKey.bin, offsets 24068-24110 */
+    m->zeros_count = 1449;
+    m->bound_log2 = 58;
+    m->r_sigma_factor = 13.179852282053789;
+    m->input_variance = 2.63039184094559e-07;
+}
+
+void orc_gen_ms_zeros(const orc_ctx* c, const uint64_t* lwe_sk, orc_rng* r, uint32_t count, uint64_t* zeros) {
+    const u32 n = c->prm.lwe_dim;
+    for (u32 i = 0; i < count; ++i)
+        orc_lwe_encrypt(lwe_sk, n, 0, c->prm.lwe_noise_log2, r, zeros + (size_t)i * (n + 1));
+}
+
+static u64 floor_sqrt_u64(u64 v) {
+    u64 lo = 0, hi = (u64)1 << 32; /* invariant: lo^2 <= v < hi^2 */
+    while (hi - lo > 1) {
+        const u64 mid = lo + (hi - lo) / 2;
+        if (mid * mid <= v) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+/* estimate of ct + add (add may be NULL), units of 2^-38 of the torus:
+ *   e = rounded - exact per word (units 2^-64), s1x2 = 2 e_b - sum e_i, s2 = sum (e_i >> 26)^2,
+ *   v = round(input_variance 2^76) + s2 / 4,
+ *   estimate = |s1x2| / 2^27 + round(r_sigma 2^16) floor(sqrt(v)) / 2^16                      */
+static u64 ms_estimate_sum(const orc_ctx* c, const orc_ms_params* m, const u64* ct, const u64* add) {
+    const u32 n = c->prm.lwe_dim, log2n = c->logN + 1;
+    i64 s1x2 = 0;
+    u64 s2 = 0;
+    for (u32 j = 0; j <= n; ++j) {
+        const u64 a = ct[j] + (add ? add[j] : 0);
+        const u64 rounded = (u64)orc_modswitch(a, log2n) << (64 - log2n);
+        u64 diff = rounded - a;
+        /* orc_modswitch reduces mod 2N: a value that rounds up to 2N came back as 0, which is the
+         * same torus point, so the wrapped difference is the signed rounding error */
+        const i64 e = (i64)diff;
+        if (j == n) s1x2 += 2 * e;
+        else {
+            const i64 h = e >> 26;
+            s1x2 -= e;
+            s2 += (u64)(h * h);
+        }
+    }
+    const u64 var_fx = (u64)llround(ldexp(m->input_variance, 76)) + (s2 >> 2);
+    const u64 r_fx = (u64)llround(ldexp(m->r_sigma_factor, 16));
+    const u64 mean_fx = (u64)(s1x2 < 0 ? -s1x2 : s1x2) >> 27;
+    return mean_fx + ((r_fx * floor_sqrt_u64(var_fx)) >> 16);
+}
+
+uint64_t orc_ms_estimate(const orc_ctx* c, const orc_ms_params* m, const uint64_t* lwe_small) {
+    return ms_estimate_sum(c, m, lwe_small, NULL);
+}
+
+int32_t orc_ms_noise_reduce(const orc_ctx* c, const orc_ms_params* m, const uint64_t* zeros, uint64_t* lwe_small) {
+    const u32 n = c->prm.lwe_dim;
+    const u64 bound = (u64)1 << (m->bound_log2 - 26);
+    u64 best = ms_estimate_sum(c, m, lwe_small, NULL);
+    int32_t pick = -1;
+    if (best > bound) {
+        for (u32 k = 0; k < m->zeros_count; ++k) {
+            const u64 e = ms_estimate_sum(c, m, lwe_small, zeros + (size_t)k * (n + 1));
+            if (e <= bound) { pick = (int32_t)k; break; }
+            if (e < best) { best = e; pick = (int32_t)k; }
+        }
+    }
+    if (pick >= 0)
+        for (u32 j = 0; j <= n; ++j) lwe_small[j] += zeros[(size_t)pick * (n + 1) + j];
+    return pick;
+}
+
+void orc_ctx_set_ms(orc_ctx* c, const orc_ms_params* m, const uint64_t* zeros) {
+    if (m && zeros && m->zeros_count) { c->ms = *m; c->ms_zeros = zeros; }
+    else { memset(&c->ms, 0, sizeof c->ms); c->ms_zeros = NULL; }
+}
+
 void orc_keyswitch(const orc_ctx* c, const uint64_t* ksk, const uint64_t* in, uint64_t* out) {
     const orc_params* P = &c->prm;
     const size_t big = (size_t)P->glwe_dim * P->poly_size;
@@ -643,6 +724,7 @@ void orc_pbs_prepared(const orc_ctx* c, const uint64_t* ksk, const orc_prepared_
     u64* small = (u64*)malloc(sizeof(u64) * (P->lwe_dim + 1));
     u64* acc = (u64*)malloc(sizeof(u64) * (size_t)(P->glwe_dim + 1) * P->poly_size);
     orc_keyswitch(c, ksk, lwe_big, small);
+    if (c->ms_zeros) orc_ms_noise_reduce(c, &c->ms, c->ms_zeros, small);
     blind_rotate_hat(c, pb, small, lut, acc);
     orc_sample_extract(c, acc, out_big);
     free(small); free(acc);

@@ -119,6 +119,32 @@ void orc_external_product(const orc_ctx* c, const uint64_t* ggsw, const uint64_t
 void orc_cmux_rotate(const orc_ctx* c, const uint64_t* ggsw, uint32_t rot, uint64_t* acc);
 /* round a torus element to Z_{2N} */
 uint32_t orc_modswitch(uint64_t x, uint32_t log2_2N);
+/* ---- modulus-switch noise reduction ----
+ * tfhe-rs improve_lwe_ciphertext_modulus_switch_noise_for_binary_key (absent dependency; the
+ * parameters are the modulus_switch_noise_reduction fields of the reference fixture
+ * sdk/relayer/src/test/keys/privateKey.bin, offsets 24068-24110: 1449 zeros, bound 2^58,
+ * r_sigma 13.179852282053789, input variance 2.63039184094559e-07).  Rounding a small ciphertext to
+ * Z_{2N} adds e_b - sum e_i s_i; over a uniform binary key that has mean e_b - sum e_i / 2 and
+ * variance sum e_i^2 / 4.  The candidates ct, ct + zero_0, ct + zero_1, ... are tried in order; the
+ * first whose estimate |mean| + r_sigma sqrt(input_variance + variance) is within the bound is
+ * taken, else the one with the smallest estimate.  The estimate is computed in fixed point (units
+ * of 2^-38 of the torus; see orc_ms_estimate) so that the choice does not depend on the order of
+ * floating-point sums.  PARITY UNPINNED: the reference holds no vector for this step. */
+typedef struct {
+    uint32_t zeros_count;
+    uint32_t bound_log2;
+    double r_sigma_factor;
+    double input_variance;
+} orc_ms_params;
+void orc_default_ms_params(orc_ms_params* m);
+/* zeros[count][n+1]: encryptions of zero under the small key, noise TUniform(lwe_noise_log2) */
+void orc_gen_ms_zeros(const orc_ctx* c, const uint64_t* lwe_sk, orc_rng* r, uint32_t count, uint64_t* zeros);
+uint64_t orc_ms_estimate(const orc_ctx* c, const orc_ms_params* m, const uint64_t* lwe_small);
+/* in place; returns the index of the encryption of zero that was added, -1 if none */
+int32_t orc_ms_noise_reduce(const orc_ctx* c, const orc_ms_params* m, const uint64_t* zeros, uint64_t* lwe_small);
+/* make orc_pbs* run the step between key switch and modulus switch (zeros is borrowed; NULL: off) */
+void orc_ctx_set_ms(orc_ctx* c, const orc_ms_params* m, const uint64_t* zeros);
+
 /* key switch LWE(kN) -> LWE(n) */
 void orc_keyswitch(const orc_ctx* c, const uint64_t* ksk, const uint64_t* in, uint64_t* out);
 /* blind rotation of the accumulator `lut` ((k+1) polys) by the small ciphertext; out = GLWE */

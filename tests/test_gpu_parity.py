@@ -15,14 +15,24 @@ N = 2048
 M64 = (1 << 64) - 1
 
 
-def _mk(n, ks_base_log=4, ks_level=4, seed=1):
-    from fhe_amd.native import Context, Params
+def _mk(n, ks_base_log=4, ks_level=4, seed=1, ms_zeros=0):
+    """Oracle and library context over the same keys.  ms_zeros > 0 adds that many encryptions of
+    zero and switches the modulus-switch noise reduction on in both."""
+    from fhe_amd.native import Context, Params, default_params
     op = OParams(lwe_dim=n, ks_base_log=ks_base_log, ks_level=ks_level)
     orc = Oracle(op)
     keys = orc.gen_keys(seed_bytes(seed))
     p = Params(**{k: getattr(op, k) for k in op.__dataclass_fields__})
+    zeros = None
+    if ms_zeros:
+        d = default_params()
+        p.ms_zeros_count, p.ms_bound_log2 = ms_zeros, d.ms_bound_log2
+        p.ms_r_sigma_factor, p.ms_input_variance = d.ms_r_sigma_factor, d.ms_input_variance
+        zeros = orc.gen_ms_zeros(keys[0], seed_bytes(seed), ms_zeros)
+        orc.set_ms(zeros)
+        orc.zeros = zeros
     ctx = Context(seed=seed_bytes(100 + seed), params=p)
-    ctx.import_server_keys_raw(keys[2], keys[3])
+    ctx.import_server_keys_raw(keys[2], keys[3], zeros)
     ctx.import_client_keys_raw(keys[0], keys[1])
     return orc, keys, ctx
 
@@ -36,7 +46,7 @@ def small():
 
 @pytest.fixture(scope="module")
 def full():
-    orc, keys, ctx = _mk(918, seed=2)
+    orc, keys, ctx = _mk(918, seed=2, ms_zeros=1449)   # the reference's parameter set, noise reduction on
     yield orc, keys, ctx, orc.prepare_bsk(keys[2])
     ctx.close()
 
@@ -150,6 +160,35 @@ def test_pbs_full_parameters(full):
     out2 = ctx.pbs_batch(out, luts_g[:1])
     for i in range(0, B, 7):
         assert orc.decrypt_block(glwe_sk, out2[i]) == f[idx[i]](msgs[i]) % 16
+
+
+def test_ms_noise_reduction_bit_exact(full):
+    """The candidate search between key switch and modulus switch: same choice and same words as
+    the oracle; the estimate ends within the bound; the plaintext is untouched."""
+    orc, keys, ctx, _ = full
+    lwe_sk, glwe_sk, bsk, ksk = keys
+    r = Rng(seed_bytes(26))
+    cts = np.stack([orc.encrypt_block(glwe_sk, i % 16, r) for i in range(70)])
+    smalls = ctx.keyswitch(cts)
+    smalls[3] = 0                       # rounds exactly: estimate is the input variance alone, nothing added
+    got, chosen = ctx.ms_noise_reduce(smalls)
+    picks = []
+    for i in range(len(smalls)):
+        want, pick = orc.ms_noise_reduce(smalls[i], orc.zeros)
+        picks.append(pick)
+        assert pick == chosen[i] and np.array_equal(got[i], want), i
+        assert orc.ms_estimate(got[i]) <= 1 << 32
+        if i != 3:
+            assert orc.decode(orc.lwe_phase(lwe_sk, got[i])) == i % 16
+    assert chosen[3] == -1 and max(picks) > 3 and len(set(picks)) > 10   # the search really runs
+    # without encryptions of zero in the key set the stage refuses to run
+    o2, k2, c2 = _mk(12)
+    try:
+        from fhe_amd.native import LfheError
+        with pytest.raises(LfheError):
+            c2.ms_noise_reduce(np.zeros((1, 13), dtype=np.uint64))
+    finally:
+        c2.close()
 
 
 def test_library_keygen_round_trip():

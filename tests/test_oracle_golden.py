@@ -28,6 +28,74 @@ def test_reference_fixture_parameters(golden_dir):
     assert u64(23983) == p.message_modulus and u64(23995) == p.carry_modulus
 
 
+def test_reference_fixture_noise_reduction_parameters(golden_dir):
+    """The modulus_switch_noise_reduction fields of the same blob are the oracle's defaults."""
+    import struct
+    blob = open(golden_dir + "/privateKey.bin", "rb").read()
+    m = Oracle().ms_params()
+    assert int.from_bytes(blob[24068:24072], "little") == m.zeros_count == 1449
+    assert struct.unpack("<d", blob[24080:24088])[0] == 2.0 ** m.bound_log2
+    assert struct.unpack("<d", blob[24092:24100])[0] == m.r_sigma_factor
+    assert struct.unpack("<d", blob[24104:24112])[0] == m.input_variance
+
+
+def test_ms_noise_reduction_properties():
+    """First candidate within the bound wins (every earlier one exceeds it), the estimate agrees
+    with its floating-point definition, the plaintext is untouched, and the actual rounding error
+    under the real key shrinks."""
+    orc = Oracle()
+    n = orc.n
+    lwe_sk = np.zeros(n, dtype=np.uint64)
+    lib().orc_gen_binary_key(Rng(seed_bytes(3), 1).ref, lwe_sk, n)
+    zeros = orc.gen_ms_zeros(lwe_sk, seed_bytes(3), 1449)
+    for z in zeros[:50]:
+        ph = orc.lwe_phase(lwe_sk, z)
+        assert min(ph, (1 << 64) - ph) <= 1 << 45                            # encryptions of zero
+    m = orc.ms_params()
+    bound = 1 << (m.bound_log2 - 26)
+    r = Rng(seed_bytes(7))
+
+    def errors(ct):
+        t = (ct >> np.uint64(51)) + np.uint64(1) >> np.uint64(1)
+        return ((t << np.uint64(52)) - ct).astype(np.int64)
+
+    def float_estimate(ct):
+        e = errors(ct).astype(np.float64) / 2.0 ** 64
+        mean = e[-1] - e[:-1].sum() / 2
+        return (abs(mean) + m.r_sigma_factor * np.sqrt(m.input_variance + (e[:-1] ** 2).sum() / 4)) * 2.0 ** 38
+
+    def true_error(ct):   # rounding error of the phase under the real key, in units of the 2N grid
+        e = errors(ct)
+        return (int(e[-1]) - int((e[:-1] * lwe_sk.astype(np.int64)).sum())) / 2.0 ** 52
+
+    before, after, tries = [], [], []
+    for i in range(120):
+        ct = orc.lwe_encrypt(lwe_sk, orc.encode(i % 16), 45, r)
+        assert abs(orc.ms_estimate(ct) / float_estimate(ct) - 1) < 1e-5
+        out, pick = orc.ms_noise_reduce(ct, zeros)
+        est = orc.ms_estimate(out)
+        assert est <= bound
+        for k in range(-1, pick):   # the candidates before the chosen one all exceed the bound
+            cand = ct if k < 0 else ct + zeros[k]
+            assert orc.ms_estimate(cand) > bound
+        if pick >= 0:
+            assert np.array_equal(out, ct + zeros[pick])
+        else:
+            assert np.array_equal(out, ct)
+        assert orc.decode(orc.lwe_phase(lwe_sk, out)) == i % 16
+        before.append(true_error(ct)); after.append(true_error(out)); tries.append(pick + 2)
+    assert 5 < np.mean(tries) < 60
+    # the estimate bounds the mean part of the error: its spread under the real key drops
+    assert np.std(after) < 0.9 * np.std(before)
+    # no satisfying candidate: the best one is taken
+    tight = orc.ms_params(40)
+    tight.bound_log2 = 57
+    ct = orc.lwe_encrypt(lwe_sk, 0, 45, r)
+    out, pick = orc.ms_noise_reduce(ct, zeros[:40], tight)
+    ests = [orc.ms_estimate(ct)] + [orc.ms_estimate(ct + z) for z in zeros[:40]]
+    assert pick == int(np.argmin(ests)) - 1 and orc.ms_estimate(out) == min(ests)
+
+
 def test_negacyclic_product_pinned_by_reference_public_key(golden_dir):
     """Known answer from the reference's key fixtures: body = mask (*) rev(s) + e, |e| <= 2^17.
     Any error in the sign convention, the wrap or the CRT lift gives a full-range residual."""
