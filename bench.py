@@ -41,7 +41,7 @@ class _DevMem:
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
 
-def cpu_baseline(seconds_budget: float = 20.0):
+def cpu_baseline(seconds_budget: float = 20.0, prime_bsk: bool = False):
     """The CPU oracle (own port; the reference engine is not available offline) timed on the host
     cores of this box on a bounded sample of the same workload."""
     from oracle.oracle import Oracle, Rng, seed_bytes
@@ -49,21 +49,22 @@ def cpu_baseline(seconds_budget: float = 20.0):
     orc = Oracle()
     lwe_sk, glwe_sk, bsk, ksk = orc.gen_keys(seed_bytes(9))
     orc.set_ms(orc.gen_ms_zeros(lwe_sk, seed_bytes(9), orc.ms_params().zeros_count))   # same pipeline as the GPU's
-    pb = orc.prepare_bsk(bsk)
+    pb = orc.prepare_bsk_qp(orc.gen_bsk_qp(lwe_sk, glwe_sk, seed_bytes(9))) if prime_bsk else orc.prepare_bsk(bsk)
+    pbs_batch = orc.pbs_batch_qp if prime_bsk else orc.pbs_batch
     r = Rng(seed_bytes(10))
     lut = orc.make_lut(lambda x: x)
     probe = np.stack([orc.encrypt_block(glwe_sk, int(r.u64() % 16), r) for _ in range(threads)])
     t0 = time.perf_counter()
-    orc.pbs_batch(ksk, pb, probe, lut[None], None, nthreads=threads)
+    pbs_batch(ksk, pb, probe, lut[None], None, nthreads=threads)
     per_round = time.perf_counter() - t0
     rounds = max(1, min(8, int(seconds_budget / max(per_round, 1e-3))))
     cts = np.stack([orc.encrypt_block(glwe_sk, int(r.u64() % 16), r) for _ in range(threads * rounds)])
     t0 = time.perf_counter()
-    out = orc.pbs_batch(ksk, pb, cts, lut[None], None, nthreads=threads)
+    out = pbs_batch(ksk, pb, cts, lut[None], None, nthreads=threads)
     dt = time.perf_counter() - t0
     assert all(orc.decrypt_block(glwe_sk, out[i]) == orc.decrypt_block(glwe_sk, cts[i]) for i in range(0, len(cts), 5))
     t0 = time.perf_counter()
-    orc.pbs_batch(ksk, pb, cts[:3], lut[None], None, nthreads=1)
+    pbs_batch(ksk, pb, cts[:3], lut[None], None, nthreads=1)
     one_core = 3 / (time.perf_counter() - t0)
     return {"value": len(cts) / dt, "unit": "PBS/s", "cores": threads, "kind": "port", "value_1core": one_core,
             "sample": f"{len(cts)} bootstraps of the same workload (n=918, N=2048) on {threads} threads, 3 on one; "
@@ -77,6 +78,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bsk-modulus", choices=["q64", "prime"], default="q64",
+                    help="ring modulus of the bootstrapping key: 2^64 (two-prime transform + lift) or the NTT prime")
     args = ap.parse_args()
 
     import torch
@@ -99,7 +102,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     seed = bytes((7 * i + 3) & 0xFF for i in range(32))
-    ctx = Context(seed=seed, device=local)
+    prime = args.bsk_modulus == "prime"
+    ctx = Context(seed=seed, device=local, params_id=2 if prime else 1)
     keep = []  # tensors whose memory the context points at
     if rank == 0:
         ctx.keygen()
@@ -190,16 +194,17 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"batched PBS microbench: {B} independent euint8 blocks per GPU, "
                                    "PARAM_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128 (n=918, N=2048), 2 LUTs",
+                       "bsk_modulus": "703687441727489 (NTT prime)" if prime else "2^64",
                        "batch_per_gpu": B, "parallelism": f"batch-shard x{world}, keys broadcast once"},
             "verified": ok,
             "kernel_ms": {"keyswitch_and_ms_noise_reduction": ks_ms, "blind_rotate": br_ms},
-            "roofline": {"bound": "valu", "kernel": "k_blind_rotate", "achieved": achieved, "peak": PEAK_GMODMUL,
+            "roofline": {"bound": "valu", "kernel": "k_blind_rotate_q" if prime else "k_blind_rotate", "achieved": achieved, "peak": PEAK_GMODMUL,
                          "unit": "Gmodmul/s", "frac": achieved / PEAK_GMODMUL, "traffic": None,
                          "hbm": {"achieved": algo_bytes / ((ks_ms + br_ms) * 1e-3) / 1e9, "peak": 8000.0,
                                  "unit": "GB/s", "algorithmic_bytes": algo_bytes}},
         }
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline()
+            res["cpu_baseline"] = cpu_baseline(prime_bsk=prime)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

@@ -62,6 +62,7 @@ static void params_out(const EngineParams& d, lfhe_params* p) {
     p->lwe_noise_log2 = d.lwe_noise_log2; p->glwe_noise_log2 = d.glwe_noise_log2;
     p->ms_zeros_count = d.ms_zeros_count; p->ms_bound_log2 = d.ms_bound_log2;
     p->ms_r_sigma_factor = d.ms_r_sigma_factor; p->ms_input_variance = d.ms_input_variance;
+    p->bsk_modulus = d.bsk_modulus;
 }
 
 void lfhe_default_params(lfhe_params* p) {
@@ -81,6 +82,7 @@ int32_t lfhe_ctx_create_custom(lfhe_ctx** out, const lfhe_params* p, int32_t dev
     c->prm.lwe_noise_log2 = p->lwe_noise_log2; c->prm.glwe_noise_log2 = p->glwe_noise_log2;
     c->prm.ms_zeros_count = p->ms_zeros_count; c->prm.ms_bound_log2 = p->ms_bound_log2;
     c->prm.ms_r_sigma_factor = p->ms_r_sigma_factor; c->prm.ms_input_variance = p->ms_input_variance;
+    c->prm.bsk_modulus = p->bsk_modulus;
     std::memcpy(c->seed, seed, 32);
     c->enc_rng.init(seed, 16);
     int32_t rc = LFHE_OK;
@@ -104,9 +106,12 @@ int32_t lfhe_ctx_create_custom(lfhe_ctx** out, const lfhe_params* p, int32_t dev
 }
 
 int32_t lfhe_ctx_create(lfhe_ctx** out, uint32_t params_id, int32_t device, const uint8_t seed[32]) {
-    if (params_id != LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128) return LFHE_ERR_UNSUPPORTED;
+    if (params_id != LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128 &&
+        params_id != LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK)
+        return LFHE_ERR_UNSUPPORTED;
     lfhe_params p;
     lfhe_default_params(&p);
+    if (params_id == LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK) p.bsk_modulus = LFHE_BSK_MODULUS_PRIME;
     return lfhe_ctx_create_custom(out, &p, device, seed);
 }
 
@@ -154,7 +159,8 @@ int32_t lfhe_keygen(lfhe_ctx* ctx) {
         ctx->have_client = true;
         ctx->bsk.resize(ctx->eng->bsk_raw_words());
         ctx->ksk.resize(ctx->eng->ksk_words());
-        gen_bsk(p, ctx->lwe_sk.data(), ctx->glwe_sk.data(), ctx->seed, ctx->bsk.data(), host_threads());
+        if (p.bsk_modulus) gen_bsk_qp(p, ctx->lwe_sk.data(), ctx->glwe_sk.data(), ctx->seed, ctx->bsk.data(), host_threads());
+        else gen_bsk(p, ctx->lwe_sk.data(), ctx->glwe_sk.data(), ctx->seed, ctx->bsk.data(), host_threads());
         gen_ksk(p, ctx->glwe_sk.data(), ctx->lwe_sk.data(), ctx->seed, ctx->ksk.data(), host_threads());
         ctx->ms_zeros.resize(ctx->eng->ms_zeros_words());
         gen_ms_zeros(p, ctx->lwe_sk.data(), ctx->seed, ctx->ms_zeros.data(), host_threads());
@@ -170,6 +176,9 @@ int32_t lfhe_server_keys_import_raw(lfhe_ctx* ctx, const uint64_t* bsk, uint64_t
         if (bsk_words != ctx->eng->bsk_raw_words() || ksk_words != ctx->eng->ksk_words() ||
             (ms_zeros && ms_words && ms_words != ctx->eng->ms_zeros_words()))
             throw std::invalid_argument("server key size does not match the parameter set");
+        if (ctx->prm.bsk_modulus)
+            for (uint64_t i = 0; i < bsk_words; ++i)
+                if (bsk[i] >= ctx->prm.bsk_modulus) throw std::invalid_argument("bootstrapping key word not reduced");
         ctx->bsk.assign(bsk, bsk + bsk_words);
         ctx->ksk.assign(ksk, ksk + ksk_words);
         if (ms_zeros && ms_words) ctx->ms_zeros.assign(ms_zeros, ms_zeros + ms_words);
@@ -431,6 +440,9 @@ int32_t lfhe_external_product(lfhe_ctx* ctx, uint64_t count, const uint32_t* ggs
         if (!ggsw_index || !glwe || !out) throw std::invalid_argument("null pointer");
         for (uint64_t i = 0; i < count; ++i)
             if (ggsw_index[i] >= ctx->prm.lwe_dim) throw std::invalid_argument("ggsw_index out of range");
+        if (ctx->prm.bsk_modulus)
+            for (uint64_t i = 0; i < count * 2 * N; ++i)
+                if (glwe[i] >= ctx->prm.bsk_modulus) throw std::invalid_argument("residue not reduced");
         require_server(ctx);
         Engine& E = *ctx->eng;
         HC(hipSetDevice(E.device()));

@@ -21,6 +21,8 @@ Engine::Engine(int device, const EngineParams& p) : device_(device), prm_(p) {
         p.ks_base_log * p.ks_level > 32)
         throw std::runtime_error("unsupported key-switch decomposition");
     if (p.lwe_dim < 1 || p.lwe_dim > 4096) throw std::runtime_error("unsupported LWE dimension");
+    if (p.bsk_modulus != 0 && p.bsk_modulus != QP_U)
+        throw std::runtime_error("unsupported bootstrapping-key modulus: 0 (2^64) or 703687441727489");
     if (p.ms_zeros_count && (p.ms_bound_log2 < 27 || p.ms_bound_log2 > 63 || !(p.ms_r_sigma_factor > 0) ||
                              !(p.ms_r_sigma_factor < 1024) || !(p.ms_input_variance >= 0) ||
                              !(p.ms_input_variance < 1e-3)))
@@ -77,7 +79,8 @@ void Engine::load_bsk(const u64* host_bsk) {
     for (size_t i0 = 0; i0 < prm_.lwe_dim; i0 += slab) {
         const size_t cnt = (prm_.lwe_dim - i0) < slab ? (prm_.lwe_dim - i0) : slab;
         HC(hipMemcpyAsync(d_raw, host_bsk + i0 * 4 * N, cnt * 4 * N * sizeof(u64), hipMemcpyHostToDevice, stream_));
-        launch_ntt_forward(T_, d_raw, d_bsk_ + i0 * BSK_ROW, cnt * 4, 1, stream_);
+        if (single_modulus()) launch_bskq_prepare(T_, d_raw, d_bsk_ + i0 * BSKQ_ROW, cnt * 4, stream_);
+        else launch_ntt_forward(T_, d_raw, d_bsk_ + i0 * BSK_ROW, cnt * 4, 1, stream_);
         HC(hipGetLastError());
         HC(hipStreamSynchronize(stream_));
     }
@@ -192,8 +195,12 @@ void Engine::blind_rotate(const u64* lwe_small, const u64* luts, const u32* lut_
     if (!count) return;
     HC(hipSetDevice(device_));
     u64* ws = acc_scratch(count);
-    launch_blind_rotate(T_, d_bsk_, lwe_small, (int)prm_.lwe_dim, luts, lut_index, ws, glwe_out, lwe_out, count,
-                        omap, stream_);
+    if (single_modulus())
+        launch_blind_rotate_q(T_, d_bsk_, lwe_small, (int)prm_.lwe_dim, luts, lut_index, reinterpret_cast<double*>(ws),
+                              glwe_out, lwe_out, count, omap, 1.0 / (double)qp_gadget(), stream_);
+    else
+        launch_blind_rotate(T_, d_bsk_, lwe_small, (int)prm_.lwe_dim, luts, lut_index, ws, glwe_out, lwe_out, count,
+                            omap, stream_);
     HC(hipGetLastError());
 }
 
@@ -209,7 +216,8 @@ void Engine::external_product(const u32* ggsw_index, const u64* glwe, u64* out, 
     if (!d_bsk_) throw std::runtime_error("no bootstrapping key loaded");
     if (!count) return;
     HC(hipSetDevice(device_));
-    launch_external_product(T_, d_bsk_, ggsw_index, glwe, out, count, stream_);
+    if (single_modulus()) launch_external_product_q(T_, d_bsk_, ggsw_index, glwe, out, count, 1.0 / (double)qp_gadget(), stream_);
+    else launch_external_product(T_, d_bsk_, ggsw_index, glwe, out, count, stream_);
     HC(hipGetLastError());
 }
 

@@ -36,6 +36,9 @@ struct EngineParams {
     uint32_t ms_bound_log2 = 58;
     double ms_r_sigma_factor = 13.179852282053789;
     double ms_input_variance = 2.63039184094559e-07;
+    // ring modulus of the bootstrapping key and the accumulator: 0 = 2^64 (two-prime transform and
+    // lift), QP_U = the NTT prime itself (single transform, modulus switch on the way in and out)
+    uint64_t bsk_modulus = 0;
 };
 
 // kernel launchers (kernels.hip)
@@ -46,6 +49,12 @@ void launch_external_product(const Tables& T, const double* bsk, const u32* idx,
 void launch_blind_rotate(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
                          const u32* lut_index, u64* acc_ws, u64* glwe_out, u64* lwe_out, size_t count,
                          const BlockMap& omap, hipStream_t st);
+void launch_bskq_prepare(const Tables& T, const u64* in, double* out, size_t polys, hipStream_t st);
+void launch_external_product_q(const Tables& T, const double* bsk, const u32* idx, const u64* glwe, u64* out,
+                               size_t count, double inv_g, hipStream_t st);
+void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
+                           const u32* lut_index, double* acc_ws, u64* glwe_out, u64* lwe_out, size_t count,
+                           const BlockMap& omap, double inv_g, hipStream_t st);
 void launch_lin_batch(u64* arena, const LinOp* ops, int nops, size_t instances, size_t inst_stride_blocks, u64 delta,
                       hipStream_t st);
 void launch_ksk_colsum(const u64* ksk, int rows, int cols, int half_base, u64* colsum, hipStream_t st);
@@ -72,7 +81,10 @@ public:
 
     size_t bsk_raw_words() const { return (size_t)prm_.lwe_dim * 4 * N; }
     size_t ksk_words() const { return (size_t)N * prm_.ks_level * (prm_.lwe_dim + 1); }
-    size_t bsk_dev_bytes() const { return (size_t)prm_.lwe_dim * BSK_ROW * sizeof(double); }
+    bool single_modulus() const { return prm_.bsk_modulus != 0; }
+    // gadget of the single-modulus key: round(q' / 2^base_log); digits are rint(c / gadget)
+    u64 qp_gadget() const { return (QP_U + (1ull << (prm_.pbs_base_log - 1))) >> prm_.pbs_base_log; }
+    size_t bsk_dev_bytes() const { return (size_t)prm_.lwe_dim * (single_modulus() ? BSKQ_ROW : BSK_ROW) * sizeof(double); }
     size_t ms_zeros_words() const { return (size_t)prm_.ms_zeros_count * (prm_.lwe_dim + 1); }
     // device image of the key-switching key: key words, n+1 column sums, one word holding the
     // number of encryptions of zero that follow (0 when the key set came without them), the zeros

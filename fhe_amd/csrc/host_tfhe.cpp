@@ -2,6 +2,7 @@
 
 #include <cstring>
 #include <thread>
+#include <vector>
 
 namespace lfhe {
 
@@ -111,6 +112,40 @@ void gen_bsk(const EngineParams& p, const uint64_t* lwe_sk, const uint64_t* glwe
         const size_t i = row >> 1;
         const int rr = (int)(row & 1);
         (rr == 0 ? mask : body)[0] += lwe_sk[i] << (64 - p.pbs_base_log);
+    });
+}
+
+// the same key over the ring modulus q': residues in [0, q'), noise uniform in [-E, E] with
+// E = round(2^glwe_noise_log2 q' / 2^64), gadget round(q' / 2^base_log)
+void gen_bsk_qp(const EngineParams& p, const uint64_t* lwe_sk, const uint64_t* glwe_sk, const uint8_t seed[32],
+                uint64_t* bsk, int threads) {
+    const uint64_t Q = QP_U;
+    const uint64_t G = (Q + (1ull << (p.pbs_base_log - 1))) >> p.pbs_base_log;
+    const uint64_t E = (uint64_t)((((unsigned __int128)1 << p.glwe_noise_log2) * Q + ((unsigned __int128)1 << 63)) >> 64);
+    const size_t rows = (size_t)p.lwe_dim * 2;
+    parallel_for(rows, threads, [&](size_t row) {
+        ChaCha r(seed, 0x400000000ull + row);
+        uint64_t* mask = bsk + row * 2 * N;
+        uint64_t* body = mask + N;
+        for (int j = 0; j < N; ++j) mask[j] = (uint64_t)(((unsigned __int128)r.next() * Q) >> 64);
+        for (int j = 0; j < N; ++j) {
+            const uint64_t e = r.next() % (2 * E + 1);
+            body[j] = e >= E ? e - E : e + Q - E;
+        }
+        // body += mask (*) s over Z_q' for the binary key s: sum of negacyclic rotations, kept below 2^63
+        // by reducing every 4096 additions (each term is below q' < 2^50)
+        std::vector<uint64_t> pos(N, 0), negs(N, 0);
+        int pending = 0;
+        for (int i = 0; i < N; ++i) {
+            if (!glwe_sk[i]) continue;
+            for (int j = 0; j < N - i; ++j) pos[j + i] += mask[j];
+            for (int j = N - i; j < N; ++j) negs[j + i - N] += mask[j];
+            if (++pending == 4096) { for (int j = 0; j < N; ++j) { pos[j] %= Q; negs[j] %= Q; } pending = 0; }
+        }
+        for (int j = 0; j < N; ++j) body[j] = (body[j] + pos[j] % Q + Q - negs[j] % Q) % Q;
+        const size_t i = row >> 1;
+        const int rr = (int)(row & 1);
+        if (lwe_sk[i]) { uint64_t& w = (rr == 0 ? mask : body)[0]; w = (w + G) % Q; }
     });
 }
 

@@ -36,6 +36,9 @@ uint64_t lwe_phase(const uint64_t* sk, size_t dim, const uint64_t* ct);
 // key-switching key ksk[N][level][n+1]; `threads` host threads
 void gen_bsk(const EngineParams& p, const uint64_t* lwe_sk, const uint64_t* glwe_sk, const uint8_t seed[32],
              uint64_t* bsk, int threads);
+// the bootstrapping key over the prime ring modulus (EngineParams::bsk_modulus), same layout
+void gen_bsk_qp(const EngineParams& p, const uint64_t* lwe_sk, const uint64_t* glwe_sk, const uint8_t seed[32],
+                uint64_t* bsk, int threads);
 void gen_ksk(const EngineParams& p, const uint64_t* glwe_sk, const uint64_t* lwe_sk, const uint8_t seed[32],
              uint64_t* ksk, int threads);
 

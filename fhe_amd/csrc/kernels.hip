@@ -26,6 +26,7 @@
 namespace lfhe {
 
 extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
+static constexpr size_t LDS_BYTES = (size_t)LDS_WORDS * sizeof(double);
 
 template <int... PH>
 __device__ __forceinline__ void ep_run_seq(EpState& s, double* lds, unsigned t, const Tables& T,
@@ -140,11 +141,11 @@ __global__ void __launch_bounds__(NT, 2) k_external_product(Tables T, const doub
 // blind rotation: modulus switch of the small ciphertext, acc = X^-b~ * lut, n CMux steps,
 // then either the whole accumulator (glwe_out) or its sample-extracted LWE (lwe_out).
 //
-// The accumulator (2 x 2048 words) lives in a per-ciphertext workspace in global memory, which for
-// the resident workgroups stays in L2: each step reads it twice (own coefficients and the
-// rotated ones, both coalesced) and rewrites it once.  Holding it in registers instead costs 32
-// VGPRs for the whole step and halves the occupancy; holding it in LDS does not fit beside the
-// exchange buffer at four workgroups per CU.
+// The accumulator (2 x 2048 words) stays on the CU for all n steps: each thread holds its 16
+// coefficients in registers and republishes them after every step in the LDS exchange buffer
+// (free between steps), from which the next step takes its rotated reads.  A workspace in global
+// memory was measured slower: with a thousand resident workgroups it no longer fits the L2 and
+// every step pays a round trip for 64 KB per ciphertext.
 // ------------------------------------------------------------------------------------------------
 template <int... PH>
 __device__ __forceinline__ void ep_run_assign(EpState& s, double* lds, unsigned t, const Tables& T,
@@ -171,6 +172,11 @@ __global__ void __launch_bounds__(NT, LFHE_BR_WAVES) k_blind_rotate(Tables T, co
     const u64* __restrict__ lut = luts + (size_t)(lut_index ? lut_index[omap.ops ? ct % omap.ops : ct] : 0) * N;
     u64* ws = acc_ws + ct * (size_t)(2 * N);
 
+    // The accumulator never leaves the CU: every thread keeps its own 16 coefficients in registers
+    // (pass-1 ownership) and publishes them between steps in the LDS exchange buffer, which serves
+    // the rotated reads of the next step.  The global workspace is written once, at the end.
+    u64* acc_lds[2] = {reinterpret_cast<u64*>(lds_dyn), reinterpret_cast<u64*>(lds_dyn + POLY_STRIDE)};
+    u64 acc[2][E];
     {
         const unsigned bt = modswitch_2n(lwe[n]);
         const unsigned a = (2 * N - bt) & (2 * N - 1);  // multiply by X^-b~
@@ -179,8 +185,10 @@ __global__ void __launch_bounds__(NT, LFHE_BR_WAVES) k_blind_rotate(Tables T, co
             const unsigned e = own1(t, j);
             bool neg;
             const u64 v = lut[rot_index(e, a, neg)];
-            ws[e] = 0;
-            ws[N + e] = neg ? (u64)0 - v : v;
+            acc[0][j] = 0;
+            acc[1][j] = neg ? (u64)0 - v : v;
+            acc_lds[0][e] = acc[0][j];
+            acc_lds[1][e] = acc[1][j];
         }
     }
     __syncthreads();
@@ -190,23 +198,32 @@ __global__ void __launch_bounds__(NT, LFHE_BR_WAVES) k_blind_rotate(Tables T, co
         const unsigned a = modswitch_2n(lwe[i]);
         if (a == 0) continue;  // X^0 - 1 = 0: this CMux adds exactly zero
         unsigned tt = t;
-        asm volatile("" : "+v"(tt));  // recompute the workspace addresses per step (see ep_phase)
+        asm volatile("" : "+v"(tt));  // recompute the addresses per step (see ep_phase)
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int j = 0; j < E; ++j) {
-                const unsigned e = own1(tt, j);
                 bool neg;
-                const u64 r = ws[q * N + rot_index(e, a, neg)];
-                s.dig[q][j] = decomp23((neg ? (u64)0 - r : r) - ws[q * N + e]);
+                const u64 r = acc_lds[q][rot_index(own1(tt, j), a, neg)];
+                s.dig[q][j] = decomp23((neg ? (u64)0 - r : r) - acc[q][j]);
             }
+        __syncthreads();  // every rotated read is done before the first phase overwrites the buffer
         ep_run_assign(s, lds_dyn, t, T, bsk + (size_t)i * BSK_ROW, std::make_integer_sequence<int, EP_PHASES>{});
+        // a thread's last-pass reads and its accumulator writes hit the same LDS words: no barrier between
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int j = 0; j < E; ++j) ws[q * N + own1(tt, j)] += s.out[q][j];
+            for (int j = 0; j < E; ++j) {
+                acc[q][j] += s.out[q][j];
+                acc_lds[q][own1(tt, j)] = acc[q][j];
+            }
         __syncthreads();  // the new accumulator is visible to the whole workgroup before the next step
     }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < E; ++j) ws[q * N + own1(t, j)] = acc[q][j];
+    __syncthreads();
 
     if (glwe_out) {
 #pragma unroll
@@ -223,6 +240,198 @@ __global__ void __launch_bounds__(NT, LFHE_BR_WAVES) k_blind_rotate(Tables T, co
             else o[N - e] = (u64)0 - ws[e];
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The bootstrap over the single ring modulus q' = p0 (pbs_phases.h): bootstrapping key and
+// accumulator are residues mod q', one transform per polynomial, no lift.  The accumulator
+// workspace holds centred residues as doubles.
+// ------------------------------------------------------------------------------------------------
+#ifndef LFHE_BRQ_WAVES
+#define LFHE_BRQ_WAVES 2
+#endif
+
+// key preparation: residues in [0, q') -> transform domain, N^-1 folded in, key-row layout
+__global__ void __launch_bounds__(NT) k_bskq_prepare(Tables T, const u64* __restrict__ in, double* __restrict__ out) {
+    double* buf = lds_dyn;
+    const unsigned t = threadIdx.x;
+    const size_t poly = blockIdx.x;
+    const Prime P = T.pr[0];
+    const double* __restrict__ tw = T.tw_fwd[0];
+    double x[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const u64 v = in[poly * N + own1(t, j)];
+        x[j] = v > QP_U / 2 ? -(double)(QP_U - v) : (double)v;
+    }
+    ct_radix8(x, tw, 1, P);
+    st_o1p12(buf, t, x); __syncthreads(); ld_o2p12(buf, t, x); __syncthreads();
+    ct_radix8(x, tw, base2(t), P);
+    st_o2p23(buf, t, x); __syncthreads(); ld_o3p23(buf, t, x); __syncthreads();
+    ct_radix8(x, tw, base3(t), P);
+    st_o3p34(buf, t, x); __syncthreads(); ld_o4p34(buf, t, x); __syncthreads();
+    ct_radix4x2(x, tw, t, P);
+    double* row = out + (poly >> 2) * BSKQ_ROW;
+    const unsigned q = (unsigned)(poly & 3);
+#pragma unroll
+    for (int j = 0; j < E; ++j) row[bsk_off(0, q, j >> 1, t) + (j & 1)] = mnorm(mmul(x[j], T.ninv[0], P), P);
+}
+
+template <int... PH>
+__device__ __forceinline__ void epq_run(EpState& s, double* lds, unsigned t, const Tables& T,
+                                        const double* __restrict__ bsk_i, std::integer_sequence<int, PH...>) {
+#ifdef LFHE_ABLATE_NO_BARRIER   // timing experiment only: results are wrong
+    ((ep_phase<PH, false, true>(s, lds, t, T, bsk_i)), ...);
+#else
+    ((ep_phase<PH, false, true>(s, lds, t, T, bsk_i), (PH + 1 < EPQ_PHASES ? __syncthreads() : (void)0)), ...);
+#endif
+}
+
+// phases 1..11 (the kernel runs phase 0 itself)
+template <int... PH>
+__device__ __forceinline__ void epq_run_from1(EpState& s, double* lds, unsigned t, const Tables& T,
+                                              const double* __restrict__ bsk_i, std::integer_sequence<int, PH...>) {
+    ((ep_phase<PH + 1, false, true>(s, lds, t, T, bsk_i), (PH + 2 < EPQ_PHASES ? __syncthreads() : (void)0)), ...);
+}
+
+// centred residue of an exact integer |x| < 3 q' (the quotient estimate is exact in this range)
+__device__ __forceinline__ double qp_canon(double x, const Prime& P) { return mnorm(x, P); }
+
+// out = BSK[ggsw_index[ct]] [.] glwe[ct] over Z_q'; glwe and out hold residues in [0, q')
+__global__ void __launch_bounds__(NT, 2) k_external_product_q(Tables T, const double* __restrict__ bsk,
+                                                              const u32* __restrict__ ggsw_index,
+                                                              const u64* __restrict__ glwe, u64* __restrict__ out,
+                                                              double inv_g) {
+    const unsigned t = threadIdx.x;
+    const size_t ct = blockIdx.x;
+    const Prime P = T.pr[0];
+    EpState s;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const u64 v = glwe[(ct * 2 + q) * N + own1(t, j)];
+            const double c = v > QP_U / 2 ? -(double)(QP_U - v) : (double)v;
+            s.x[q][j] = __builtin_rint(c * inv_g);
+        }
+    epq_run(s, lds_dyn, t, T, bsk + (size_t)ggsw_index[ct] * BSKQ_ROW, std::make_integer_sequence<int, EPQ_PHASES>{});
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const double c = qp_canon(s.x[q][j], P);
+            out[(ct * 2 + q) * N + own1(t, j)] = c < 0 ? QP_U - (u64)(-c) : (u64)c;
+        }
+}
+
+__global__ void __launch_bounds__(NT, LFHE_BRQ_WAVES) k_blind_rotate_q(Tables T, const double* __restrict__ bsk,
+                                                                       const u64* __restrict__ lwe_small, int n,
+                                                                       const u64* __restrict__ luts,
+                                                                       const u32* __restrict__ lut_index,
+                                                                       double* __restrict__ acc_ws,
+                                                                       u64* __restrict__ glwe_out,
+                                                                       u64* __restrict__ lwe_out, BlockMap omap,
+                                                                       double inv_g) {
+    const unsigned t = threadIdx.x;
+    const size_t ct = blockIdx.x;
+    const Prime P = T.pr[0];
+    const u64* __restrict__ lwe = lwe_small + ct * (size_t)(n + 1);
+    const u64* __restrict__ lut = luts + (size_t)(lut_index ? lut_index[omap.ops ? ct % omap.ops : ct] : 0) * N;
+    double* ws = acc_ws + ct * (size_t)(2 * N);
+
+    // The accumulator never leaves the CU: every thread keeps its own 16 coefficients in registers
+    // (pass-1 ownership) and publishes them between steps in the LDS exchange buffer, which serves
+    // the rotated reads of the next step.  The global workspace is written once, at the end.
+    double* acc_lds[2] = {lds_dyn, lds_dyn + POLY_STRIDE};
+    double acc[2][E];
+    {
+        const unsigned bt = modswitch_2n(lwe[n]);
+        const unsigned a = (2 * N - bt) & (2 * N - 1);  // multiply by X^-b~
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const unsigned e = own1(t, j);
+            bool neg;
+            const double v = torus_to_qp(lut[rot_index(e, a, neg)]);
+            acc[0][j] = 0.0;
+            acc[1][j] = neg ? -v : v;
+            acc_lds[0][e] = acc[0][j];
+            acc_lds[1][e] = acc[1][j];
+        }
+    }
+    __syncthreads();
+
+    EpState s;
+    for (int i = 0; i < n; ++i) {
+        const unsigned a = modswitch_2n(lwe[i]);
+        if (a == 0) continue;  // X^0 - 1 = 0: this CMux adds exactly zero
+        unsigned tt = t;
+        asm volatile("" : "+v"(tt));  // recompute the addresses per step (see ep_phase)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                bool neg;
+                const double r = acc_lds[q][rot_index(own1(tt, j), a, neg)];
+                const double d = (neg ? -r : r) - acc[q][j];
+                s.x[q][j] = __builtin_rint(qp_canon(d, P) * inv_g);
+            }
+        // first forward pass in registers, then publish: every thread must have read its rotated
+        // coefficients before the buffer is overwritten
+        ct_radix8(s.x[0], T.tw_fwd[0], 1, P);
+        ct_radix8(s.x[1], T.tw_fwd[0], 1, P);
+        __syncthreads();
+        st_o1p12(acc_lds[0], tt, s.x[0]); st_o1p12(acc_lds[1], tt, s.x[1]);
+        __syncthreads();
+        epq_run_from1(s, lds_dyn, t, T, bsk + (size_t)i * BSKQ_ROW, std::make_integer_sequence<int, EPQ_PHASES - 1>{});
+        // a thread's last-pass reads and its accumulator writes hit the same LDS words: no barrier between
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                acc[q][j] = qp_canon(acc[q][j] + s.x[q][j], P);
+                acc_lds[q][own1(tt, j)] = acc[q][j];
+            }
+        __syncthreads();  // the new accumulator is visible to the whole workgroup before the next step
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < E; ++j) ws[q * N + own1(t, j)] = acc[q][j];
+    __syncthreads();
+
+    if (glwe_out) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const double c = ws[q * N + own1(t, j)];
+                glwe_out[(ct * 2 + q) * N + own1(t, j)] = c < 0 ? QP_U - (u64)(-c) : (u64)c;
+            }
+    }
+    if (lwe_out) {  // sample extraction of coefficient 0, every word switched back to 2^64
+        u64* o = lwe_out + omap.block(ct) * (size_t)(N + 1);
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const unsigned e = own1(t, j);
+            if (e == 0) { o[0] = qp_to_torus(ws[0]); o[N] = qp_to_torus(ws[N]); }
+            else o[N - e] = qp_to_torus(-ws[e]);
+        }
+    }
+}
+
+void launch_bskq_prepare(const Tables& T, const u64* in, double* out, size_t polys, hipStream_t st) {
+    hipLaunchKernelGGL(k_bskq_prepare, dim3((unsigned)polys), dim3(NT), LDS_BYTES, st, T, in, out);
+}
+void launch_external_product_q(const Tables& T, const double* bsk, const u32* idx, const u64* glwe, u64* out,
+                               size_t count, double inv_g, hipStream_t st) {
+    hipLaunchKernelGGL(k_external_product_q, dim3((unsigned)count), dim3(NT), LDS_BYTES, st, T, bsk, idx, glwe, out,
+                       inv_g);
+}
+void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
+                           const u32* lut_index, double* acc_ws, u64* glwe_out, u64* lwe_out, size_t count,
+                           const BlockMap& omap, double inv_g, hipStream_t st) {
+    hipLaunchKernelGGL(k_blind_rotate_q, dim3((unsigned)count), dim3(NT), LDS_BYTES, st, T, bsk, lwe_small, n, luts,
+                       lut_index, acc_ws, glwe_out, lwe_out, omap, inv_g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -329,7 +538,6 @@ __global__ void __launch_bounds__(256) k_lwe_linear(const u64* __restrict__ a, c
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-static constexpr size_t LDS_BYTES = (size_t)LDS_WORDS * sizeof(double);
 
 void launch_ntt_forward(const Tables& T, const u64* in, double* out, size_t polys, int mode, hipStream_t st) {
     hipLaunchKernelGGL(k_ntt_forward, dim3((unsigned)polys), dim3(NT), POLY_STRIDE * sizeof(double), st, T, in, out, mode);

@@ -80,7 +80,22 @@ LFHE_HD void track_max(double) {}
 // Table loads take a 32-bit unsigned byte offset from a wave-uniform base, which lets the compiler
 // use the scalar-base + 32-bit-offset addressing mode instead of 64-bit address arithmetic per load.
 LFHE_HD double ldt(const double* __restrict__ base, unsigned idx) {
+#ifdef LFHE_ABLATE_NO_TABLE   // timing experiment only: results are wrong
+    (void)base;
+    return (double)idx;
+#else
     return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + idx * 8u);
+#endif
+}
+
+// twiddle load
+LFHE_HD double ldtw(const double* __restrict__ base, unsigned idx) {
+#ifdef LFHE_ABLATE_NO_TW   // timing experiment only: results are wrong
+    (void)base;
+    return (double)idx;
+#else
+    return ldt(base, idx);
+#endif
 }
 
 LFHE_HD void ct_bfly(double& a, double& b, double w, const Prime& P) {
@@ -111,29 +126,29 @@ LFHE_HD unsigned pad34(unsigned e) { return e + (e >> 3); }
 // Radix-8 Cooley-Tukey on the 8 registers of one pass.  tw is the bit-reversed table
 // (tw[m + i] = psi^bitrev(m + i)), b the table index of the pass's first stage.
 LFHE_HD void ct_radix8(double (&x)[8], const double* __restrict__ tw, unsigned b, const Prime& P) {
-    const double w1 = ldt(tw, b);
+    const double w1 = ldtw(tw, b);
 #pragma unroll
     for (int j = 0; j < 4; ++j) ct_bfly(x[j], x[j + 4], w1, P);
-    const double w2a = ldt(tw, 2 * b), w2b = ldt(tw, 2 * b + 1);
+    const double w2a = ldtw(tw, 2 * b), w2b = ldtw(tw, 2 * b + 1);
     ct_bfly(x[0], x[2], w2a, P); ct_bfly(x[1], x[3], w2a, P);
     ct_bfly(x[4], x[6], w2b, P); ct_bfly(x[5], x[7], w2b, P);
 #pragma unroll
-    for (unsigned k = 0; k < 4; ++k) ct_bfly(x[2 * k], x[2 * k + 1], ldt(tw, 4 * b + k), P);
+    for (unsigned k = 0; k < 4; ++k) ct_bfly(x[2 * k], x[2 * k + 1], ldtw(tw, 4 * b + k), P);
 }
 
 // last forward pass: strides 2 and 1 on 8 consecutive coefficients
 LFHE_HD void ct_radix4x2(double (&x)[8], const double* __restrict__ tw, unsigned t, const Prime& P) {
-    const double wa = ldt(tw, 512 + 2 * t), wb = ldt(tw, 512 + 2 * t + 1);
+    const double wa = ldtw(tw, 512 + 2 * t), wb = ldtw(tw, 512 + 2 * t + 1);
     ct_bfly(x[0], x[2], wa, P); ct_bfly(x[1], x[3], wa, P);
     ct_bfly(x[4], x[6], wb, P); ct_bfly(x[5], x[7], wb, P);
 #pragma unroll
-    for (unsigned k = 0; k < 4; ++k) ct_bfly(x[2 * k], x[2 * k + 1], ldt(tw, 1024 + 4 * t + k), P);
+    for (unsigned k = 0; k < 4; ++k) ct_bfly(x[2 * k], x[2 * k + 1], ldtw(tw, 1024 + 4 * t + k), P);
 }
 
 LFHE_HD void gs_radix4x2(double (&x)[8], const double* __restrict__ tw, unsigned t, const Prime& P) {
 #pragma unroll
-    for (unsigned k = 0; k < 4; ++k) gs_bfly(x[2 * k], x[2 * k + 1], ldt(tw, 1024 + 4 * t + k), P);
-    const double wa = ldt(tw, 512 + 2 * t), wb = ldt(tw, 512 + 2 * t + 1);
+    for (unsigned k = 0; k < 4; ++k) gs_bfly(x[2 * k], x[2 * k + 1], ldtw(tw, 1024 + 4 * t + k), P);
+    const double wa = ldtw(tw, 512 + 2 * t), wb = ldtw(tw, 512 + 2 * t + 1);
     gs_bfly(x[0], x[2], wa, P); gs_bfly(x[1], x[3], wa, P);
     gs_bfly(x[4], x[6], wb, P); gs_bfly(x[5], x[7], wb, P);
 }
@@ -150,13 +165,13 @@ LFHE_HD void norm8(double (&x)[8], const Prime& P) {
 template <int NORM_AFTER = 0>
 LFHE_HD void gs_radix8(double (&x)[8], const double* __restrict__ tw, unsigned b, const Prime& P) {
 #pragma unroll
-    for (unsigned k = 0; k < 4; ++k) gs_bfly(x[2 * k], x[2 * k + 1], ldt(tw, 4 * b + k), P);
+    for (unsigned k = 0; k < 4; ++k) gs_bfly(x[2 * k], x[2 * k + 1], ldtw(tw, 4 * b + k), P);
     if (NORM_AFTER == 1) norm8(x, P);
-    const double w2a = ldt(tw, 2 * b), w2b = ldt(tw, 2 * b + 1);
+    const double w2a = ldtw(tw, 2 * b), w2b = ldtw(tw, 2 * b + 1);
     gs_bfly(x[0], x[2], w2a, P); gs_bfly(x[1], x[3], w2a, P);
     gs_bfly(x[4], x[6], w2b, P); gs_bfly(x[5], x[7], w2b, P);
     if (NORM_AFTER == 2) norm8(x, P);
-    const double w1 = ldt(tw, b);
+    const double w1 = ldtw(tw, b);
 #pragma unroll
     for (int j = 0; j < 4; ++j) gs_bfly(x[j], x[j + 4], w1, P);
     if (NORM_AFTER == 3) norm8(x, P);

@@ -32,10 +32,18 @@ struct EpState {
 };
 
 constexpr int EP_PHASES = 24;  // 12 per prime
+constexpr int EPQ_PHASES = 12; // single ring modulus
+
+// The same product over the single ring modulus q' = p0 (bootstrapping key and accumulator in
+// Z_q'): phases 0-11 only, digits handed over as doubles in s.x, result (|y| <= p0, any
+// representative) left in s.x; key row layout [q = j_in*2 + c_out][c4][t][2].
+constexpr int BSKQ_ROW = 4 * BSK_POLY;      // doubles per i
+constexpr u64 QP_U = P0_U;
 
 // phase p of the external product.  `lds` holds two padded polynomials.
-template <int PH, bool ACCUM = true>
+template <int PH, bool ACCUM = true, bool SINGLE = false>
 LFHE_HD void ep_phase(EpState& s, double* lds, unsigned t, const Tables& T, const double* __restrict__ bsk_i) {
+    static_assert(!SINGLE || PH < 12, "the single-modulus product has twelve phases");
     constexpr int r = PH / 12;
     constexpr int ph = PH % 12;
     const Prime P = T.pr[r];
@@ -58,11 +66,18 @@ LFHE_HD void ep_phase(EpState& s, double* lds, unsigned t, const Tables& T, cons
     double* b0 = lds;
     double* b1 = lds + POLY_STRIDE;
 
+#ifdef LFHE_ABLATE_NO_BSK   // timing experiment only: results are wrong
+#define LFHE_LDK(b, o) ((double)(o))
+#else
+#define LFHE_LDK(b, o) ldt(b, o)
+#endif
     if constexpr (ph == 0) {  // digits -> residues, forward pass 1, publish
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
+            if constexpr (!SINGLE) {
 #pragma unroll
-            for (int j = 0; j < E; ++j) s.x[q][j] = (double)s.dig[q][j];
+                for (int j = 0; j < E; ++j) s.x[q][j] = (double)s.dig[q][j];
+            }
             ct_radix8(s.x[q], twf, 1, P);
         }
         st_o1p12(b0, t, s.x[0]); st_o1p12(b1, t, s.x[1]);
@@ -84,12 +99,12 @@ LFHE_HD void ep_phase(EpState& s, double* lds, unsigned t, const Tables& T, cons
         // all sixteen loads (64 registers) to the top of the phase
         double kc[4][2], kn[4][2];
 #pragma unroll
-        for (unsigned q = 0; q < 4; ++q) { const unsigned o = bsk_off(r, q, 0, t); kc[q][0] = ldt(bsk_i, o); kc[q][1] = ldt(bsk_i, o + 1); }
+        for (unsigned q = 0; q < 4; ++q) { const unsigned o = bsk_off(r, q, 0, t); kc[q][0] = LFHE_LDK(bsk_i, o); kc[q][1] = LFHE_LDK(bsk_i, o + 1); }
 #pragma unroll
         for (int c4 = 0; c4 < 4; ++c4) {
             if (c4 < 3) {
 #pragma unroll
-                for (unsigned q = 0; q < 4; ++q) { const unsigned o = bsk_off(r, q, c4 + 1, t); kn[q][0] = ldt(bsk_i, o); kn[q][1] = ldt(bsk_i, o + 1); }
+                for (unsigned q = 0; q < 4; ++q) { const unsigned o = bsk_off(r, q, c4 + 1, t); kn[q][0] = LFHE_LDK(bsk_i, o); kn[q][1] = LFHE_LDK(bsk_i, o + 1); }
             }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -124,7 +139,8 @@ LFHE_HD void ep_phase(EpState& s, double* lds, unsigned t, const Tables& T, cons
         // stages 9-10 | 11: the outputs (|y| <= p) go to the CRT lift as they are; it only needs
         // residues, not centred ones, because |true value| <= 2^97 < 0.33 p0 p1
         gs_radix8<2>(s.x[0], twi, 1, P); gs_radix8<2>(s.x[1], twi, 1, P);
-        if constexpr (r == 0) {
+        if constexpr (SINGLE) {
+        } else if constexpr (r == 0) {
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -147,6 +163,31 @@ LFHE_HD unsigned rot_index(unsigned e, unsigned a, bool& neg) {
     const bool wrap = e < ar;
     neg = ((a & N) != 0) != wrap;
     return wrap ? e + N - ar : e - ar;
+}
+
+// ---- ring modulus q' <-> 2^64
+// round(v * q' / 2^64) as a centred exact double
+LFHE_HD double torus_to_qp(u64 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u64 hi = __umul64hi(v, QP_U);
+#else
+    const u64 hi = (u64)(((unsigned __int128)v * QP_U) >> 64);
+#endif
+    u64 r = hi + ((v * QP_U) >> 63);
+    if (r == QP_U) r = 0;
+    return r > QP_U / 2 ? -(double)(QP_U - r) : (double)r;
+}
+// round(r * 2^64 / q') for the centred residue c, by restoring division (64 steps)
+LFHE_HD u64 qp_to_torus(double c) {
+    u64 r = c < 0 ? QP_U - (u64)(-c) : (u64)c;
+    u64 w = 0;
+#pragma nounroll
+    for (int i = 0; i < 64; ++i) {
+        r <<= 1;
+        w <<= 1;
+        if (r >= QP_U) { r -= QP_U; w |= 1; }
+    }
+    return w + (2 * r >= QP_U ? 1 : 0);
 }
 
 LFHE_HD u32 modswitch_2n(u64 x) {  // round to Z_{2N}

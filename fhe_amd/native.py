@@ -15,6 +15,8 @@ ERR_NAMES = {-1: "LFHE_ERR_ARG", -2: "LFHE_ERR_STATE", -3: "LFHE_ERR_DEVICE", -4
              -5: "LFHE_ERR_UNSUPPORTED", -6: "LFHE_ERR_FORMAT"}
 KEY_CLIENT, KEY_SERVER = 1, 2
 PARAMS_DEFAULT = 1
+PARAMS_PRIME_BSK = 2          # same set, bootstrapping key over the NTT prime
+BSK_MODULUS_PRIME = 703687441727489
 
 OPS = {"add": 0, "sub": 1, "mul": 2, "eq": 3, "ne": 4, "ge": 5, "gt": 6, "le": 7, "lt": 8, "min": 9, "max": 10,
        "and": 11, "or": 12, "xor": 13, "not": 14, "neg": 15, "select": 16, "shl": 17, "shr": 18, "rotl": 19,
@@ -32,7 +34,8 @@ class Params(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in (
         "lwe_dim", "glwe_dim", "poly_size", "pbs_base_log", "pbs_level", "ks_base_log", "ks_level",
         "message_modulus", "carry_modulus", "lwe_noise_log2", "glwe_noise_log2", "ms_zeros_count",
-        "ms_bound_log2")] + [("ms_r_sigma_factor", C.c_double), ("ms_input_variance", C.c_double)]
+        "ms_bound_log2")] + [("ms_r_sigma_factor", C.c_double), ("ms_input_variance", C.c_double),
+                             ("bsk_modulus", C.c_uint64)]
 
 
 def default_params() -> Params:
@@ -139,11 +142,12 @@ class Context:
 
     N = 2048
 
-    def __init__(self, seed: bytes = bytes(32), device: int = 0, params: Params | None = None):
+    def __init__(self, seed: bytes = bytes(32), device: int = 0, params: Params | None = None,
+                 params_id: int = PARAMS_DEFAULT):
         self._L = load()
         self._h = C.c_void_p()
         if params is None:
-            rc = self._L.lfhe_ctx_create(C.byref(self._h), PARAMS_DEFAULT, device, seed)
+            rc = self._L.lfhe_ctx_create(C.byref(self._h), params_id, device, seed)
         else:
             rc = self._L.lfhe_ctx_create_custom(C.byref(self._h), C.byref(params), device, seed)
         if rc != LFHE_OK:

@@ -33,6 +33,11 @@ extern "C" {
 
 /* parameter set ids */
 #define LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128 1u
+/* the same set with the bootstrapping key and the blind-rotation accumulator over the NTT prime
+ * LFHE_BSK_MODULUS_PRIME instead of 2^64 (LWE ciphertexts, key switch and every interface stay at
+ * 2^64; noise and gadget keep their proportion to the modulus) */
+#define LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK 2u
+#define LFHE_BSK_MODULUS_PRIME 703687441727489ull
 
 typedef struct lfhe_ctx lfhe_ctx;
 
@@ -57,6 +62,10 @@ typedef struct {
     uint32_t ms_bound_log2;   /* 58   */
     double ms_r_sigma_factor; /* 13.179852282053789 */
     double ms_input_variance; /* 2.63039184094559e-07 */
+    /* ring modulus of the bootstrapping key: 0 = 2^64 (exact product through two NTT primes and a
+     * CRT lift), LFHE_BSK_MODULUS_PRIME = that prime (one transform, no lift; the construction of
+     * tfhe-rs programmable_bootstrap_ntt64_lwe_ciphertext) */
+    uint64_t bsk_modulus;
 } lfhe_params;
 
 const char* lfhe_version(void);
@@ -188,7 +197,8 @@ int32_t lfhe_ntt_info(const lfhe_ctx* ctx, uint64_t primes[2], uint64_t psi[2]);
 int32_t lfhe_ntt_forward(lfhe_ctx* ctx, uint64_t count, const uint64_t* polys, uint64_t* residues);
 /* residues [count][2][N] of a polynomial with coefficients in (-P/2, P/2) -> its coefficients mod 2^64 */
 int32_t lfhe_ntt_inverse(lfhe_ctx* ctx, uint64_t count, const uint64_t* residues, uint64_t* polys);
-/* out[c] = BSK[ggsw_index[c]] [.] glwe[c]; glwe and out are [count][2][N] */
+/* out[c] = BSK[ggsw_index[c]] [.] glwe[c]; glwe and out are [count][2][N] (with a prime
+ * bsk_modulus: residues in [0, modulus), and lfhe_blind_rotate returns residues too) */
 int32_t lfhe_external_product(lfhe_ctx* ctx, uint64_t count, const uint32_t* ggsw_index, const uint64_t* glwe,
                               uint64_t* out);
 /* [count][N+1] -> [count][n+1] */

@@ -122,6 +122,18 @@ def lib():
         "orc_pbs_prepared": (None, [vp, _u64p, vp, _u64p, _u64p, _u64p]),
         "orc_pbs_batch_prepared": (None, [vp, _u64p, vp, _u64p, _u64p, vp, _u64p, sz, C.c_int]),
         "orc_make_lut": (None, [vp, _u64p, _u64p]),
+        "orc_qp": (u64, []),
+        "orc_qp_gadget": (u64, [vp]),
+        "orc_qp_noise_bound": (u32, [vp]),
+        "orc_to_qp": (u64, [u64]),
+        "orc_from_qp": (u64, [u64]),
+        "orc_qp_digit": (C.c_int64, [vp, u64]),
+        "orc_gen_bsk_qp": (None, [vp, _u64p, _u64p, C.POINTER(_Rng), _u64p]),
+        "orc_external_product_qp": (None, [vp, _u64p, _u64p, _u64p]),
+        "orc_bsk_qp_prepare": (vp, [vp, _u64p]),
+        "orc_blind_rotate_qp": (None, [vp, vp, _u64p, _u64p, _u64p]),
+        "orc_pbs_qp": (None, [vp, _u64p, vp, _u64p, _u64p, _u64p]),
+        "orc_pbs_batch_qp": (None, [vp, _u64p, vp, _u64p, _u64p, vp, _u64p, sz, C.c_int]),
         "orc_encode": (u64, [vp, u64]),
         "orc_decode": (u64, [vp, u64]),
     }
@@ -343,6 +355,54 @@ class Oracle:
         lib().orc_pbs_batch_prepared(self._ctx, ksk, pbsk.h, cts, luts, idx, out, cts.shape[0], nthreads)
         return out
 
+    # -- bootstrap over the prime ring modulus q' (bootstrapping key and accumulator in Z_q')
+    @property
+    def qp(self) -> int:
+        return lib().orc_qp()
+
+    def qp_gadget(self) -> int:
+        return lib().orc_qp_gadget(self._ctx)
+
+    def qp_noise_bound(self) -> int:
+        return lib().orc_qp_noise_bound(self._ctx)
+
+    def qp_digit(self, res: int) -> int:
+        return lib().orc_qp_digit(self._ctx, res)
+
+    def gen_bsk_qp(self, lwe_sk: np.ndarray, glwe_sk: np.ndarray, seed: bytes) -> np.ndarray:
+        bsk = np.zeros(lib().orc_bsk_len(C.byref(self._cp)), dtype=np.uint64)
+        lib().orc_gen_bsk_qp(self._ctx, lwe_sk, glwe_sk, Rng(seed, 6).ref, bsk)
+        return bsk
+
+    def external_product_qp(self, ggsw: np.ndarray, glwe: np.ndarray) -> np.ndarray:
+        out = np.zeros((self.k + 1) * self.N, dtype=np.uint64)
+        lib().orc_external_product_qp(self._ctx, np.ascontiguousarray(ggsw), np.ascontiguousarray(glwe), out)
+        return out
+
+    def prepare_bsk_qp(self, bsk: np.ndarray):
+        return _PreparedBsk(self, bsk, prime=True)
+
+    def blind_rotate_qp(self, pbsk, lwe_small: np.ndarray, lut: np.ndarray) -> np.ndarray:
+        acc = np.zeros((self.k + 1) * self.N, dtype=np.uint64)
+        lib().orc_blind_rotate_qp(self._ctx, pbsk.h, np.ascontiguousarray(lwe_small), np.ascontiguousarray(lut), acc)
+        return acc
+
+    def pbs_qp(self, ksk: np.ndarray, pbsk, ct_big: np.ndarray, lut: np.ndarray) -> np.ndarray:
+        out = np.zeros(self.big + 1, dtype=np.uint64)
+        lib().orc_pbs_qp(self._ctx, ksk, pbsk.h, np.ascontiguousarray(ct_big), np.ascontiguousarray(lut), out)
+        return out
+
+    def pbs_batch_qp(self, ksk, pbsk, cts: np.ndarray, luts: np.ndarray, lut_index=None, nthreads: int = 1):
+        cts = np.ascontiguousarray(cts, dtype=np.uint64).reshape(-1, self.big + 1)
+        luts = np.ascontiguousarray(luts, dtype=np.uint64)
+        out = np.zeros_like(cts)
+        idx = None
+        if lut_index is not None:
+            idx_arr = np.ascontiguousarray(lut_index, dtype=np.uint32)
+            idx = idx_arr.ctypes.data_as(C.c_void_p)
+        lib().orc_pbs_batch_qp(self._ctx, ksk, pbsk.h, cts, luts, idx, out, cts.shape[0], nthreads)
+        return out
+
     def make_lut(self, f) -> np.ndarray:
         """Accumulator for f: [0, msg*carry) -> [0, msg*carry)."""
         space = self.p.message_modulus * self.p.carry_modulus
@@ -353,9 +413,10 @@ class Oracle:
 
 
 class _PreparedBsk:
-    def __init__(self, orc: Oracle, bsk: np.ndarray):
+    def __init__(self, orc: Oracle, bsk: np.ndarray, prime: bool = False):
         self._orc = orc
-        self.h = lib().orc_bsk_prepare(orc._ctx, np.ascontiguousarray(bsk, dtype=np.uint64))
+        prep = lib().orc_bsk_qp_prepare if prime else lib().orc_bsk_prepare
+        self.h = prep(orc._ctx, np.ascontiguousarray(bsk, dtype=np.uint64))
 
     def __del__(self):
         try:

@@ -234,11 +234,14 @@ void orc_ntt_definition(uint64_t p, uint64_t psi, const uint64_t* in, uint64_t* 
 /* ------------------------------------------------------------------------------------------- */
 /* context                                                                                     */
 /* ------------------------------------------------------------------------------------------- */
+#define ORC_QP ((u64)703687441727489ull)
+
 struct orc_ctx {
     orc_params prm;
     u32 logN;
     ntt_prime pr[2];
     u64 p0_inv_mod_p1; /* plain */
+    ntt_prime qp;        /* the prime ring modulus of the single-modulus bootstrap */
     orc_ms_params ms;    /* zeros_count == 0: the noise-reduction step is off */
     const u64* ms_zeros; /* borrowed */
 };
@@ -265,12 +268,14 @@ orc_ctx* orc_ctx_new(const orc_params* p) {
         if (is_prime_u64(cand)) ntt_prime_init(&c->pr[found++], cand, p->poly_size);
     }
     c->p0_inv_mod_p1 = orc_powmod(c->pr[0].m.p % c->pr[1].m.p, c->pr[1].m.p - 2, c->pr[1].m.p);
+    ntt_prime_init(&c->qp, ORC_QP, p->poly_size);
     return c;
 }
 
 void orc_ctx_free(orc_ctx* c) {
     if (!c) return;
     for (int i = 0; i < 2; ++i) { free(c->pr[i].w_fwd); free(c->pr[i].w_inv); }
+    free(c->qp.w_fwd); free(c->qp.w_inv);
     free(c);
 }
 
@@ -756,6 +761,198 @@ void orc_pbs_batch(const orc_ctx* c, const uint64_t* ksk, const uint64_t* bsk, c
     orc_prepared_bsk* pb = orc_bsk_prepare(c, bsk);
     orc_pbs_batch_prepared(c, ksk, pb, in, luts, lut_index, out, count, nthreads);
     orc_bsk_prepared_free(pb);
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* bootstrap over the prime ring modulus q'                                                    */
+/* ------------------------------------------------------------------------------------------- */
+uint64_t orc_qp(void) { return ORC_QP; }
+
+uint64_t orc_qp_gadget(const orc_ctx* c) {
+    const u32 b = c->prm.pbs_base_log;
+    return (ORC_QP + ((u64)1 << (b - 1))) >> b;
+}
+
+uint32_t orc_qp_noise_bound(const orc_ctx* c) {
+    /* round(2^noise_log2 * q' / 2^64) */
+    const u128 t = ((u128)1 << c->prm.glwe_noise_log2) * ORC_QP + ((u128)1 << 63);
+    return (u32)(t >> 64);
+}
+
+uint64_t orc_to_qp(uint64_t torus) {
+    const u64 r = (u64)(((u128)torus * ORC_QP + ((u128)1 << 63)) >> 64);
+    return r == ORC_QP ? 0 : r;
+}
+
+uint64_t orc_from_qp(uint64_t res) {
+    return (u64)((((u128)res << 64) + ORC_QP / 2) / ORC_QP);
+}
+
+static inline i64 qp_centre(u64 r) { return r > ORC_QP / 2 ? (i64)r - (i64)ORC_QP : (i64)r; }
+
+int64_t orc_qp_digit(const orc_ctx* c, uint64_t res) {
+    const double inv_g = 1.0 / (double)orc_qp_gadget(c);
+    return (i64)rint((double)qp_centre(res) * inv_g);
+}
+
+static inline u64 qp_add(u64 a, u64 b) { u64 s = a + b; return s >= ORC_QP ? s - ORC_QP : s; }
+static inline u64 qp_sub(u64 a, u64 b) { return a >= b ? a - b : a + ORC_QP - b; }
+
+/* out = a (*) s over Z_q' for a binary polynomial s, through the transform */
+static void qp_mul_binary(const orc_ctx* c, const u64* a, const u64* s, u64* out) {
+    const u32 N = c->prm.poly_size;
+    u64* t = (u64*)malloc(sizeof(u64) * 2 * N);
+    u64* u = t + N;
+    memcpy(t, a, sizeof(u64) * N);
+    memcpy(u, s, sizeof(u64) * N);
+    ntt_fwd(&c->qp, t, N); ntt_fwd(&c->qp, u, N);
+    for (u32 j = 0; j < N; ++j) t[j] = mont_mul(&c->qp.m, t[j], to_mont(&c->qp.m, u[j]));
+    ntt_inv(&c->qp, t, N);
+    memcpy(out, t, sizeof(u64) * N);
+    free(t);
+}
+
+void orc_gen_bsk_qp(const orc_ctx* c, const uint64_t* lwe_sk, const uint64_t* glwe_sk, orc_rng* r, uint64_t* bsk) {
+    const orc_params* P = &c->prm;
+    const u32 N = P->poly_size, k = P->glwe_dim;
+    const u64 G = orc_qp_gadget(c);
+    const u64 E = orc_qp_noise_bound(c);
+    u64* tmp = (u64*)malloc(sizeof(u64) * N);
+    u64* row = bsk;
+    for (u32 i = 0; i < P->lwe_dim; ++i)
+        for (u32 rr = 0; rr <= k; ++rr, row += (size_t)(k + 1) * N) {
+            u64* body = row + (size_t)k * N;
+            for (u32 j = 0; j < N; ++j) {
+                const u64 e = orc_rng_u64(r) % (2 * E + 1);          /* uniform in [-E, E] */
+                body[j] = e >= E ? e - E : e + ORC_QP - E;
+            }
+            for (u32 q = 0; q < k; ++q) {
+                u64* a = row + (size_t)q * N;
+                for (u32 j = 0; j < N; ++j) a[j] = (u64)(((u128)orc_rng_u64(r) * ORC_QP) >> 64);
+                qp_mul_binary(c, a, glwe_sk + (size_t)q * N, tmp);
+                for (u32 j = 0; j < N; ++j) body[j] = qp_add(body[j], tmp[j]);
+            }
+            if (lwe_sk[i]) row[(size_t)rr * N] = qp_add(row[(size_t)rr * N], G % ORC_QP);
+        }
+    free(tmp);
+}
+
+/* NTT-domain image of one GGSW over q': hat[row][poly][N], Montgomery form */
+static void ggsw_qp_to_hat(const orc_ctx* c, const u64* ggsw, u64* hat) {
+    const u32 N = c->prm.poly_size, k1 = c->prm.glwe_dim + 1;
+    for (size_t q = 0; q < (size_t)k1 * k1; ++q) {
+        u64* h = hat + q * N;
+        memcpy(h, ggsw + q * N, sizeof(u64) * N);
+        ntt_fwd(&c->qp, h, N);
+        for (u32 j = 0; j < N; ++j) h[j] = to_mont(&c->qp.m, h[j]);
+    }
+}
+
+static void external_product_qp_hat(const orc_ctx* c, const u64* hat, const u64* glwe, u64* out) {
+    const u32 N = c->prm.poly_size, k1 = c->prm.glwe_dim + 1;
+    u64* acc = (u64*)calloc((size_t)k1 * N, sizeof(u64));
+    u64* d = (u64*)malloc(sizeof(u64) * N);
+    for (u32 rr = 0; rr < k1; ++rr) {
+        for (u32 j = 0; j < N; ++j) {
+            const i64 dg = orc_qp_digit(c, glwe[(size_t)rr * N + j]);
+            d[j] = dg < 0 ? (u64)(dg + (i64)ORC_QP) : (u64)dg;
+        }
+        ntt_fwd(&c->qp, d, N);
+        for (u32 cc = 0; cc < k1; ++cc) {
+            const u64* h = hat + ((size_t)rr * k1 + cc) * N;
+            u64* a = acc + (size_t)cc * N;
+            for (u32 j = 0; j < N; ++j) a[j] = qp_add(a[j], mont_mul(&c->qp.m, d[j], h[j]));
+        }
+    }
+    for (u32 cc = 0; cc < k1; ++cc) {
+        ntt_inv(&c->qp, acc + (size_t)cc * N, N);
+        memcpy(out + (size_t)cc * N, acc + (size_t)cc * N, sizeof(u64) * N);
+    }
+    free(acc); free(d);
+}
+
+void orc_external_product_qp(const orc_ctx* c, const uint64_t* ggsw, const uint64_t* glwe, uint64_t* out) {
+    const u32 N = c->prm.poly_size, k1 = c->prm.glwe_dim + 1;
+    u64* hat = (u64*)malloc(sizeof(u64) * (size_t)k1 * k1 * N);
+    ggsw_qp_to_hat(c, ggsw, hat);
+    external_product_qp_hat(c, hat, glwe, out);
+    free(hat);
+}
+
+orc_prepared_bsk* orc_bsk_qp_prepare(const orc_ctx* c, const uint64_t* bsk) {
+    const orc_params* P = &c->prm;
+    const size_t per = (size_t)(P->glwe_dim + 1) * (P->glwe_dim + 1) * P->poly_size;
+    orc_prepared_bsk* b = (orc_prepared_bsk*)malloc(sizeof *b);
+    b->per_ggsw = per;
+    b->hat = (u64*)malloc(sizeof(u64) * per * P->lwe_dim);
+    for (u32 i = 0; i < P->lwe_dim; ++i) ggsw_qp_to_hat(c, bsk + (size_t)i * per, b->hat + (size_t)i * per);
+    return b;
+}
+
+/* X^rot * in over Z_q' */
+static void qp_monomial_mul(u64* out, const u64* in, u32 rot, u32 N) {
+    for (u32 j = 0; j < N; ++j) {
+        u32 k = j + rot;
+        if (k >= 2 * N) k -= 2 * N;
+        if (k < N) out[k] = in[j]; else out[k - N] = in[j] ? ORC_QP - in[j] : 0;
+    }
+}
+
+void orc_blind_rotate_qp(const orc_ctx* c, const orc_prepared_bsk* pb, const uint64_t* lwe_small,
+                         const uint64_t* lut, uint64_t* acc) {
+    const orc_params* P = &c->prm;
+    const u32 N = P->poly_size, k1 = P->glwe_dim + 1, n = P->lwe_dim;
+    const u32 log2n = c->logN + 1;
+    u64* tmp = (u64*)malloc(sizeof(u64) * (size_t)k1 * N * 3);
+    u64 *diff = tmp + (size_t)k1 * N, *prod = tmp + (size_t)2 * k1 * N;
+    for (size_t j = 0; j < (size_t)k1 * N; ++j) tmp[j] = orc_to_qp(lut[j]);
+    const u32 bt = orc_modswitch(lwe_small[n], log2n);
+    for (u32 q = 0; q < k1; ++q)
+        qp_monomial_mul(acc + (size_t)q * N, tmp + (size_t)q * N, (2 * N - bt) % (2 * N), N);
+    for (u32 i = 0; i < n; ++i) {
+        const u32 at = orc_modswitch(lwe_small[i], log2n);
+        if (at == 0) continue;
+        for (u32 q = 0; q < k1; ++q) {
+            qp_monomial_mul(diff + (size_t)q * N, acc + (size_t)q * N, at, N);
+            for (u32 j = 0; j < N; ++j)
+                diff[(size_t)q * N + j] = qp_sub(diff[(size_t)q * N + j], acc[(size_t)q * N + j]);
+        }
+        external_product_qp_hat(c, pb->hat + (size_t)i * pb->per_ggsw, diff, prod);
+        for (size_t j = 0; j < (size_t)k1 * N; ++j) acc[j] = qp_add(acc[j], prod[j]);
+    }
+    free(tmp);
+}
+
+void orc_pbs_qp(const orc_ctx* c, const uint64_t* ksk, const orc_prepared_bsk* pb, const uint64_t* lwe_big,
+                const uint64_t* lut, uint64_t* out_big) {
+    const orc_params* P = &c->prm;
+    const size_t big = (size_t)P->glwe_dim * P->poly_size;
+    u64* small = (u64*)malloc(sizeof(u64) * (P->lwe_dim + 1));
+    u64* acc = (u64*)malloc(sizeof(u64) * (size_t)(P->glwe_dim + 1) * P->poly_size);
+    orc_keyswitch(c, ksk, lwe_big, small);
+    if (c->ms_zeros) orc_ms_noise_reduce(c, &c->ms, c->ms_zeros, small);
+    orc_blind_rotate_qp(c, pb, small, lut, acc);
+    /* sample extraction over q' (negation is modular), then every word back to 2^64 */
+    for (u32 i = 0; i < P->glwe_dim; ++i) {
+        const u64* a = acc + (size_t)i * P->poly_size;
+        u64* o = out_big + (size_t)i * P->poly_size;
+        o[0] = orc_from_qp(a[0]);
+        for (u32 j = 1; j < P->poly_size; ++j) o[j] = orc_from_qp(a[P->poly_size - j] ? ORC_QP - a[P->poly_size - j] : 0);
+    }
+    out_big[big] = orc_from_qp(acc[big]);
+    free(small); free(acc);
+}
+
+void orc_pbs_batch_qp(const orc_ctx* c, const uint64_t* ksk, const orc_prepared_bsk* pb, const uint64_t* in,
+                      const uint64_t* luts, const uint32_t* lut_index, uint64_t* out, size_t count, int nthreads) {
+    const orc_params* P = &c->prm;
+    const size_t big1 = (size_t)P->glwe_dim * P->poly_size + 1;
+    const size_t lut_len = (size_t)(P->glwe_dim + 1) * P->poly_size;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+    for (long i = 0; i < (long)count; ++i)
+        orc_pbs_qp(c, ksk, pb, in + (size_t)i * big1, luts + (size_t)(lut_index ? lut_index[i] : 0) * lut_len,
+                   out + (size_t)i * big1);
 }
 
 /* ------------------------------------------------------------------------------------------- */

@@ -172,6 +172,39 @@ void orc_pbs_batch_prepared(const orc_ctx* c, const uint64_t* ksk, const orc_pre
                             const uint64_t* in, const uint64_t* luts, const uint32_t* lut_index,
                             uint64_t* out, size_t count, int nthreads);
 
+/* ---- bootstrap over a prime ring modulus ----
+ * Variant of the blind rotation in which the bootstrapping key and the accumulator live in
+ * Z_q'[X]/(X^N+1) for the NTT-friendly prime q' = 703687441727489 (5*2^47 - 49151, 1 mod 8192)
+ * instead of q = 2^64: one exact transform per polynomial, no residue system, no lift.  The LWE
+ * ciphertexts on both sides keep q = 2^64 (the construction of tfhe-rs' NTT bootstrap,
+ * programmable_bootstrap_ntt64_lwe_ciphertext: modulus switch in, switch back out).  Relative to
+ * its modulus everything keeps the parameter set's proportions:
+ *   gadget   G  = round(q' / 2^pbs_base_log)                    (83886080 = 5*2^24 for base 2^23)
+ *   digit    d  = rint(c * fl(1/G)) in IEEE double, c the centred residue in (-q'/2, q'/2)
+ *   noise    e  uniform in [-E, E], E = round(2^glwe_noise_log2 * q' / 2^64)          (5 for 2^17)
+ *   LUT      round(v * q' / 2^64) of the 2^64-scale accumulator body
+ *   output   round(r * 2^64 / q') of every word of the sample-extracted ciphertext
+ * pbs_level must be 1.  PARITY UNPINNED against the reference (no engine in the tree). */
+uint64_t orc_qp(void);
+uint64_t orc_qp_gadget(const orc_ctx* c);
+uint32_t orc_qp_noise_bound(const orc_ctx* c);
+uint64_t orc_to_qp(uint64_t torus);   /* Z_{2^64} -> Z_q', rounding */
+uint64_t orc_from_qp(uint64_t res);   /* Z_q' -> Z_{2^64}, rounding */
+int64_t orc_qp_digit(const orc_ctx* c, uint64_t res);
+/* bsk[i][row][poly][N], residues in [0, q'): GGSW(s_i) = Z + s_i G */
+void orc_gen_bsk_qp(const orc_ctx* c, const uint64_t* lwe_sk, const uint64_t* glwe_sk, orc_rng* r, uint64_t* bsk);
+/* out = ggsw [.] glwe over Z_q' (both residues in [0, q')) */
+void orc_external_product_qp(const orc_ctx* c, const uint64_t* ggsw, const uint64_t* glwe, uint64_t* out);
+orc_prepared_bsk* orc_bsk_qp_prepare(const orc_ctx* c, const uint64_t* bsk);
+/* lut: the 2^64-scale accumulator ((k+1) polys); acc_out: (k+1) polys of residues in [0, q') */
+void orc_blind_rotate_qp(const orc_ctx* c, const orc_prepared_bsk* pb, const uint64_t* lwe_small,
+                         const uint64_t* lut, uint64_t* acc_out);
+/* KS -> (noise reduction) -> MS -> BR over q' -> SE -> switch to 2^64 */
+void orc_pbs_qp(const orc_ctx* c, const uint64_t* ksk, const orc_prepared_bsk* pb, const uint64_t* lwe_big,
+                const uint64_t* lut, uint64_t* out_big);
+void orc_pbs_batch_qp(const orc_ctx* c, const uint64_t* ksk, const orc_prepared_bsk* pb, const uint64_t* in,
+                      const uint64_t* luts, const uint32_t* lut_index, uint64_t* out, size_t count, int nthreads);
+
 /* ---- shortint encoding ---- */
 /* accumulator for f given as a table over [0, message_modulus*carry_modulus) */
 void orc_make_lut(const orc_ctx* c, const uint64_t* table, uint64_t* lut);

@@ -191,11 +191,100 @@ def test_ms_noise_reduction_bit_exact(full):
         c2.close()
 
 
-def test_library_keygen_round_trip():
-    """Keys made by the library itself: encrypt -> bootstrap -> decrypt, and the oracle decrypts
-    library ciphertexts with the exported secret key."""
+# ---- bootstrap over the prime ring modulus (bootstrapping key and accumulator in Z_q') ------------
+def _mk_prime(n, seed, ms_zeros=0):
+    from fhe_amd.native import Context, Params, default_params, BSK_MODULUS_PRIME
+    op = OParams(lwe_dim=n)
+    orc = Oracle(op)
+    lwe_sk, glwe_sk, _, ksk = orc.gen_keys(seed_bytes(seed))
+    bskq = orc.gen_bsk_qp(lwe_sk, glwe_sk, seed_bytes(seed))
+    p = Params(**{k: getattr(op, k) for k in op.__dataclass_fields__})
+    p.bsk_modulus = BSK_MODULUS_PRIME
+    zeros = None
+    if ms_zeros:
+        d = default_params()
+        p.ms_zeros_count, p.ms_bound_log2 = ms_zeros, d.ms_bound_log2
+        p.ms_r_sigma_factor, p.ms_input_variance = d.ms_r_sigma_factor, d.ms_input_variance
+        zeros = orc.gen_ms_zeros(lwe_sk, seed_bytes(seed), ms_zeros)
+        orc.set_ms(zeros)
+    ctx = Context(seed=seed_bytes(100 + seed), params=p)
+    ctx.import_server_keys_raw(bskq, ksk, zeros)
+    ctx.import_client_keys_raw(lwe_sk, glwe_sk)
+    return orc, (lwe_sk, glwe_sk, bskq, ksk), ctx
+
+
+def test_prime_modulus_external_product_and_blind_rotation_bit_exact():
+    orc, keys, ctx = _mk_prime(12, seed=4)
+    try:
+        lwe_sk, glwe_sk, bskq, ksk = keys
+        q = orc.qp
+        assert orc.qp_gadget() == 83886080 and orc.qp_noise_bound() == 5
+        W = orc.ggsw_words()
+        r = Rng(seed_bytes(27))
+        glwe = np.stack([r.u64s(2 * N) % np.uint64(q) for _ in range(5)])
+        glwe[3][:] = q // 2                        # largest positive centred value: digit +2^22
+        glwe[4][:] = q // 2 + 1                    # most negative
+        glwe[2][::2] = 83886080 // 2               # ties of the digit rounding
+        idx = np.array([0, 3, 7, 11, 5], dtype=np.uint32)
+        got = ctx.external_product(idx, glwe)
+        for c in range(len(idx)):
+            want = orc.external_product_qp(bskq[idx[c] * W:(idx[c] + 1) * W], glwe[c])
+            assert np.array_equal(got[c].reshape(-1), want), c
+        pb = orc.prepare_bsk_qp(bskq)
+        f = [lambda x: x, lambda x: (3 * x + 1) % 16]
+        luts_o = [orc.make_lut(g) for g in f]
+        luts_g = np.stack([ctx.make_lut(g) for g in f])
+        smalls = np.stack([r.u64s(orc.n + 1) for _ in range(4)])
+        smalls[3][:] = 0
+        li = np.array([0, 1, 1, 0], dtype=np.uint32)
+        got = ctx.blind_rotate(smalls, luts_g, li)
+        for c in range(4):
+            assert np.array_equal(got[c].reshape(-1), orc.blind_rotate_qp(pb, smalls[c], luts_o[li[c]])), c
+        cts = np.stack([orc.encrypt_block(glwe_sk, m, r) for m in range(16)])
+        li = np.array([m % 2 for m in range(16)], dtype=np.uint32)
+        out = ctx.pbs_batch(cts, luts_g, li)
+        for m in range(16):
+            assert np.array_equal(out[m], orc.pbs_qp(ksk, pb, cts[m], luts_o[li[m]])), m
+            assert orc.decrypt_block(glwe_sk, out[m]) == f[li[m]](m) % 16
+    finally:
+        ctx.close()
+
+
+def test_prime_modulus_pbs_full_parameters():
+    """n = 918 with the noise reduction on: outputs decrypt to f(m), a subsample is bit-identical
+    to the oracle, the output noise stays far below half a message step."""
+    orc, keys, ctx = _mk_prime(918, seed=5, ms_zeros=1449)
+    try:
+        lwe_sk, glwe_sk, bskq, ksk = keys
+        pb = orc.prepare_bsk_qp(bskq)
+        r = Rng(seed_bytes(28))
+        f = [lambda x: x, lambda x: (x * x + 3) % 16]
+        luts_o = [orc.make_lut(g) for g in f]
+        luts_g = np.stack([ctx.make_lut(g) for g in f])
+        B = 64
+        msgs = [int(r.u64() % 16) for _ in range(B)]
+        cts = np.stack([orc.encrypt_block(glwe_sk, m, r) for m in msgs])
+        idx = np.array([i % 2 for i in range(B)], dtype=np.uint32)
+        out = ctx.pbs_batch(cts, luts_g, idx)
+        worst = 0
+        for i in range(B):
+            want = f[idx[i]](msgs[i]) % 16
+            assert orc.decrypt_block(glwe_sk, out[i]) == want, i
+            e = (orc.lwe_phase(glwe_sk, out[i]) - orc.encode(want)) % (1 << 64)
+            worst = max(worst, min(e, (1 << 64) - e))
+        assert worst < 1 << 53            # half a message step is 2^58
+        for i in (0, 1, 33, 63):
+            assert np.array_equal(out[i], orc.pbs_qp(ksk, pb, cts[i], luts_o[idx[i]])), i
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("params_id", [1, 2])
+def test_library_keygen_round_trip(params_id):
+    """Keys made by the library itself (both bootstrapping-key moduli): encrypt -> bootstrap ->
+    decrypt, and the oracle decrypts library ciphertexts with the exported secret key."""
     from fhe_amd.native import Context, KEY_CLIENT
-    ctx = Context(seed=seed_bytes(77))
+    ctx = Context(seed=seed_bytes(77), params_id=params_id)
     try:
         ctx.keygen()
         blob = ctx.export_keys(KEY_CLIENT)
