@@ -28,8 +28,9 @@ N = 2048
 # 3672 length-2048 transforms * 11264 butterflies + 918*4*2048 point-wise multiply-accumulates
 MODMUL_PER_PBS = 3672 * 11264 + 918 * 4 * 2048
 # register-resident calibration on MI355X (profiles/r01/valu_rates_8wg_per_cu.txt): 4748 G/s exact
-# f64 butterflies per prime, two primes per logical modular product
-PEAK_GMODMUL = 4748.0 / 2
+# f64 butterflies (modular multiply + add + sub) per prime.  Over q = 2^64 a logical modular product
+# costs one butterfly in each of two primes; over the prime ring modulus it costs one.
+PEAK_GBFLY_PER_PRIME = 4748.0
 # algorithmic bytes of one batch launch: both keys once + one ciphertext in and out per bootstrap
 BSK_BYTES, KSK_BYTES, CT_BYTES = 60162048, 60227584, 16392
 
@@ -78,8 +79,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--bsk-modulus", choices=["q64", "prime"], default="q64",
-                    help="ring modulus of the bootstrapping key: 2^64 (two-prime transform + lift) or the NTT prime")
+    ap.add_argument("--bsk-modulus", choices=["q64", "prime"], default="prime",
+                    help="ring modulus of the bootstrapping key and accumulator: the NTT prime (one transform per "
+                         "polynomial) or 2^64 (two-prime transform + CRT lift)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the second leg with the other ring modulus")
     args = ap.parse_args()
 
     import torch
@@ -102,82 +105,104 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     seed = bytes((7 * i + 3) & 0xFF for i in range(32))
-    prime = args.bsk_modulus == "prime"
-    ctx = Context(seed=seed, device=local, params_id=2 if prime else 1)
-    keep = []  # tensors whose memory the context points at
-    if rank == 0:
-        ctx.keygen()
-        client_blob = ctx.export_keys(KEY_CLIENT)
-    if world > 1:
-        # one broadcast per key image, straight out of / into device memory
-        bsk_bytes, ksk_bytes = ctx.device_keys_size()
+
+    def make_context(prime: bool):
+        """Context with keys on every rank: generated on rank 0, device images broadcast once."""
+        ctx = Context(seed=seed, device=local, params_id=2 if prime else 1)
+        keep = []  # tensors whose memory the context points at
+        client_blob = None
         if rank == 0:
-            bp, _, kp, _ = ctx.device_keys()
-            tb = torch.as_tensor(_DevMem(bp, bsk_bytes), device=dev)
-            tk = torch.as_tensor(_DevMem(kp, ksk_bytes), device=dev)
-        else:
-            tb = torch.empty(bsk_bytes, dtype=torch.uint8, device=dev)
-            tk = torch.empty(ksk_bytes, dtype=torch.uint8, device=dev)
-        replicate(dist, [tb, tk])
-        torch.cuda.synchronize()
-        if rank != 0:
-            ctx.attach_device_keys(tb.data_ptr(), tk.data_ptr())
-            keep += [tb, tk]
-        blob = replicate_blob(dist, client_blob if rank == 0 else None)
-        if rank != 0:
-            ctx.import_keys(KEY_CLIENT, blob)
+            ctx.keygen()
+            client_blob = ctx.export_keys(KEY_CLIENT)
+        if world > 1:
+            # one broadcast per key image, straight out of / into device memory
+            bsk_bytes, ksk_bytes = ctx.device_keys_size()
+            if rank == 0:
+                bp, _, kp, _ = ctx.device_keys()
+                tb = torch.as_tensor(_DevMem(bp, bsk_bytes), device=dev)
+                tk = torch.as_tensor(_DevMem(kp, ksk_bytes), device=dev)
+            else:
+                tb = torch.empty(bsk_bytes, dtype=torch.uint8, device=dev)
+                tk = torch.empty(ksk_bytes, dtype=torch.uint8, device=dev)
+            replicate(dist, [tb, tk])
+            torch.cuda.synchronize()
+            if rank != 0:
+                ctx.attach_device_keys(tb.data_ptr(), tk.data_ptr())
+                keep += [tb, tk]
+            blob = replicate_blob(dist, client_blob if rank == 0 else None)
+            if rank != 0:
+                ctx.import_keys(KEY_CLIENT, blob)
+        return ctx, keep
 
-    # synthetic inputs: batch blocks = batch/4 euint8 values, fresh encryptions, distinct per rank
     B = args.batch
-    rng = np.random.default_rng(1234 + rank)
-    vals = rng.integers(0, 256, size=(B + 3) // 4)
-    blocks = np.concatenate([np.frombuffer(ctx.encrypt(int(v), 8)[16:], dtype=np.uint64).reshape(4, N + 1)
-                             for v in vals])[:B]
-    msgs = np.array([(int(vals[i // 4]) >> (2 * (i % 4))) & 3 for i in range(B)])
     f = [lambda x: x, lambda x: (5 * x + 3) % 16]
-    luts = np.stack([ctx.make_lut(g) for g in f])
     idx = (np.arange(B) % 2).astype(np.uint32)
-    d_in = torch.from_numpy(blocks.view(np.int64)).to(dev)
-    d_luts = torch.from_numpy(luts.view(np.int64)).to(dev)
-    d_idx = torch.from_numpy(idx.view(np.int32)).to(dev)
-    d_out = torch.zeros_like(d_in)
-    torch.cuda.synchronize()
 
-    def step(iters):
-        return ctx.pbs_batch_device_timed(B, d_in.data_ptr(), d_luts.data_ptr(), d_idx.data_ptr(),
-                                          d_out.data_ptr(), iters)
+    def run_leg(prime: bool, steps: int, warmup: int):
+        """K timed passes over this rank's B blocks; returns (elapsed s, ks ms, br ms, verified)."""
+        ctx, keep = make_context(prime)
+        # synthetic inputs: batch blocks = batch/4 euint8 values, fresh encryptions, distinct per rank
+        rng = np.random.default_rng(1234 + rank)
+        vals = rng.integers(0, 256, size=(B + 3) // 4)
+        blocks = np.concatenate([np.frombuffer(ctx.encrypt(int(v), 8)[16:], dtype=np.uint64).reshape(4, N + 1)
+                                 for v in vals])[:B]
+        msgs = np.array([(int(vals[i // 4]) >> (2 * (i % 4))) & 3 for i in range(B)])
+        luts = np.stack([ctx.make_lut(g) for g in f])
+        d_in = torch.from_numpy(blocks.view(np.int64)).to(dev)
+        d_luts = torch.from_numpy(luts.view(np.int64)).to(dev)
+        d_idx = torch.from_numpy(idx.view(np.int32)).to(dev)
+        d_out = torch.zeros_like(d_in)
+        torch.cuda.synchronize()
 
-    if args.warmup > 0:
-        step(args.warmup)
-    ctx.sync()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    ks_ms, br_ms = step(args.steps)   # K back-to-back passes, each kernel bracketed by HIP events
-    ctx.sync()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        elapsed = max_over_ranks(dist, elapsed, dev)
+        def step(iters):
+            return ctx.pbs_batch_device_timed(B, d_in.data_ptr(), d_luts.data_ptr(), d_idx.data_ptr(),
+                                              d_out.data_ptr(), iters)
 
-    # correctness of what was timed: every sampled output decrypts to f(m)
-    out = d_out.cpu().numpy().view(np.uint64)
-    sample = list(range(0, B, max(1, B // 128)))
-    got = ctx.decrypt_blocks(out[sample])
-    ok = all(g == f[idx[i]](int(msgs[i])) % 16 for g, i in zip(got, sample))
-    if dist is not None:
-        flag = torch.tensor([1 if ok else 0], device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        ok = bool(flag.item())
+        if warmup > 0:
+            step(warmup)
+        ctx.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        ks_ms, br_ms = step(steps)   # K back-to-back passes, each kernel bracketed by HIP events
+        ctx.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            elapsed = max_over_ranks(dist, elapsed, dev)
+        # correctness of what was timed: every sampled output decrypts to f(m)
+        out = d_out.cpu().numpy().view(np.uint64)
+        sample = list(range(0, B, max(1, B // 128)))
+        got = ctx.decrypt_blocks(out[sample])
+        ok = all(g == f[idx[i]](int(msgs[i])) % 16 for g, i in zip(got, sample))
+        if dist is not None:
+            flag = torch.tensor([1 if ok else 0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = bool(flag.item())
+        ctx.close()
+        del keep
+        return elapsed, ks_ms, br_ms, ok
+
+    prime = args.bsk_modulus == "prime"
+    elapsed, ks_ms, br_ms, ok = run_leg(prime, args.steps, args.warmup)
+    alt = None
+    if not args.no_alt:
+        a_steps = max(1, min(args.steps, 3))
+        a_el, a_ks, a_br, a_ok = run_leg(not prime, a_steps, 1)
+        ok = ok and a_ok
+        alt = {"bsk_modulus": "2^64" if prime else "703687441727489 (NTT prime)",
+               "value": B * a_steps * world / a_el, "unit": "PBS/s", "steps": a_steps,
+               "kernel_ms": {"keyswitch_and_ms_noise_reduction": a_ks, "blind_rotate": a_br}, "verified": a_ok}
 
     if rank == 0:
         total = B * args.steps * world
         value = total / elapsed
         br_s = br_ms * 1e-3
         achieved = B * MODMUL_PER_PBS / br_s / 1e9
+        peak = PEAK_GBFLY_PER_PRIME if prime else PEAK_GBFLY_PER_PRIME / 2
         algo_bytes = BSK_BYTES + KSK_BYTES + 2 * CT_BYTES * B
         res = {
             "metric": "programmable bootstraps/sec (node)",
@@ -198,18 +223,19 @@ def main():
                        "batch_per_gpu": B, "parallelism": f"batch-shard x{world}, keys broadcast once"},
             "verified": ok,
             "kernel_ms": {"keyswitch_and_ms_noise_reduction": ks_ms, "blind_rotate": br_ms},
-            "roofline": {"bound": "valu", "kernel": "k_blind_rotate_q" if prime else "k_blind_rotate", "achieved": achieved, "peak": PEAK_GMODMUL,
-                         "unit": "Gmodmul/s", "frac": achieved / PEAK_GMODMUL, "traffic": None,
+            "roofline": {"bound": "valu", "kernel": "k_blind_rotate_q" if prime else "k_blind_rotate", "achieved": achieved, "peak": peak,
+                         "unit": "Gmodmul/s", "frac": achieved / peak, "traffic": None,
                          "hbm": {"achieved": algo_bytes / ((ks_ms + br_ms) * 1e-3) / 1e9, "peak": 8000.0,
                                  "unit": "GB/s", "algorithmic_bytes": algo_bytes}},
         }
+        if alt is not None:
+            res["alt_ring_modulus"] = alt
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(prime_bsk=prime)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
     if not ok:
         raise SystemExit("verification failed")
 

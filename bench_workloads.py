@@ -26,9 +26,10 @@ def main():
     ap.add_argument("--transfers", type=int, default=512)
     ap.add_argument("--bids", type=int, default=1000)
     ap.add_argument("--mul-batch", type=int, default=64)
+    ap.add_argument("--bsk-modulus", choices=["q64", "prime"], default="prime")
     args = ap.parse_args()
     from fhe_amd.native import Context
-    ctx = Context(seed=bytes((11 * i + 5) & 0xFF for i in range(32)))
+    ctx = Context(seed=bytes((11 * i + 5) & 0xFF for i in range(32)), params_id=2 if args.bsk_modulus == "prime" else 1)
     ctx.keygen()
     rnd = random.Random(2026)
     M64 = (1 << 64) - 1

@@ -381,6 +381,7 @@ __global__ void __launch_bounds__(NT, LFHE_BRQ_WAVES) k_blind_rotate_q(Tables T,
         ct_radix8(s.x[1], T.tw_fwd[0], 1, P);
         __syncthreads();
         st_o1p12(acc_lds[0], tt, s.x[0]); st_o1p12(acc_lds[1], tt, s.x[1]);
+        load_tw8(T.tw_fwd[0], base2(tt), s.tw);   // twiddles of the next pass, one phase ahead
         __syncthreads();
         epq_run_from1(s, lds_dyn, t, T, bsk + (size_t)i * BSKQ_ROW, std::make_integer_sequence<int, EPQ_PHASES - 1>{});
         // a thread's last-pass reads and its accumulator writes hit the same LDS words: no barrier between

@@ -123,34 +123,61 @@ LFHE_HD unsigned pad12(unsigned e) { return e; }
 LFHE_HD unsigned pad23(unsigned e) { return e + 4 * (e >> 5); }
 LFHE_HD unsigned pad34(unsigned e) { return e + (e >> 3); }
 
-// Radix-8 Cooley-Tukey on the 8 registers of one pass.  tw is the bit-reversed table
-// (tw[m + i] = psi^bitrev(m + i)), b the table index of the pass's first stage.
+// Twiddles of one pass, loaded ahead of the pass (the loads are issued a phase early so that
+// their latency is covered by the barrier and the LDS exchange in between).
+//   radix-8 pass with first-stage table index b: w[0] = tw[b], w[1..2] = tw[2b..2b+1], w[3..6] = tw[4b..4b+3]
+//   last pass (strides 2 and 1):                 w[0..1] = tw[512+2t..], w[2..5] = tw[1024+4t..]
+LFHE_HD void load_tw8(const double* __restrict__ tw, unsigned b, double (&w)[7]) {
+    w[0] = ldtw(tw, b);
+    w[1] = ldtw(tw, 2 * b); w[2] = ldtw(tw, 2 * b + 1);
+#pragma unroll
+    for (unsigned k = 0; k < 4; ++k) w[3 + k] = ldtw(tw, 4 * b + k);
+}
+LFHE_HD void load_tw4x2(const double* __restrict__ tw, unsigned t, double (&w)[7]) {
+    w[0] = ldtw(tw, 512 + 2 * t); w[1] = ldtw(tw, 512 + 2 * t + 1);
+#pragma unroll
+    for (unsigned k = 0; k < 4; ++k) w[2 + k] = ldtw(tw, 1024 + 4 * t + k);
+}
+
+// Radix-8 Cooley-Tukey on the 8 registers of one pass (tw is the bit-reversed table,
+// tw[m + i] = psi^bitrev(m + i)).
+LFHE_HD void ct_radix8(double (&x)[8], const double (&w)[7], const Prime& P) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ct_bfly(x[j], x[j + 4], w[0], P);
+    ct_bfly(x[0], x[2], w[1], P); ct_bfly(x[1], x[3], w[1], P);
+    ct_bfly(x[4], x[6], w[2], P); ct_bfly(x[5], x[7], w[2], P);
+#pragma unroll
+    for (unsigned k = 0; k < 4; ++k) ct_bfly(x[2 * k], x[2 * k + 1], w[3 + k], P);
+}
 LFHE_HD void ct_radix8(double (&x)[8], const double* __restrict__ tw, unsigned b, const Prime& P) {
-    const double w1 = ldtw(tw, b);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ct_bfly(x[j], x[j + 4], w1, P);
-    const double w2a = ldtw(tw, 2 * b), w2b = ldtw(tw, 2 * b + 1);
-    ct_bfly(x[0], x[2], w2a, P); ct_bfly(x[1], x[3], w2a, P);
-    ct_bfly(x[4], x[6], w2b, P); ct_bfly(x[5], x[7], w2b, P);
-#pragma unroll
-    for (unsigned k = 0; k < 4; ++k) ct_bfly(x[2 * k], x[2 * k + 1], ldtw(tw, 4 * b + k), P);
+    double w[7];
+    load_tw8(tw, b, w);
+    ct_radix8(x, w, P);
 }
 
 // last forward pass: strides 2 and 1 on 8 consecutive coefficients
-LFHE_HD void ct_radix4x2(double (&x)[8], const double* __restrict__ tw, unsigned t, const Prime& P) {
-    const double wa = ldtw(tw, 512 + 2 * t), wb = ldtw(tw, 512 + 2 * t + 1);
-    ct_bfly(x[0], x[2], wa, P); ct_bfly(x[1], x[3], wa, P);
-    ct_bfly(x[4], x[6], wb, P); ct_bfly(x[5], x[7], wb, P);
+LFHE_HD void ct_radix4x2(double (&x)[8], const double (&w)[7], const Prime& P) {
+    ct_bfly(x[0], x[2], w[0], P); ct_bfly(x[1], x[3], w[0], P);
+    ct_bfly(x[4], x[6], w[1], P); ct_bfly(x[5], x[7], w[1], P);
 #pragma unroll
-    for (unsigned k = 0; k < 4; ++k) ct_bfly(x[2 * k], x[2 * k + 1], ldtw(tw, 1024 + 4 * t + k), P);
+    for (unsigned k = 0; k < 4; ++k) ct_bfly(x[2 * k], x[2 * k + 1], w[2 + k], P);
+}
+LFHE_HD void ct_radix4x2(double (&x)[8], const double* __restrict__ tw, unsigned t, const Prime& P) {
+    double w[7];
+    load_tw4x2(tw, t, w);
+    ct_radix4x2(x, w, P);
 }
 
-LFHE_HD void gs_radix4x2(double (&x)[8], const double* __restrict__ tw, unsigned t, const Prime& P) {
+LFHE_HD void gs_radix4x2(double (&x)[8], const double (&w)[7], const Prime& P) {
 #pragma unroll
-    for (unsigned k = 0; k < 4; ++k) gs_bfly(x[2 * k], x[2 * k + 1], ldtw(tw, 1024 + 4 * t + k), P);
-    const double wa = ldtw(tw, 512 + 2 * t), wb = ldtw(tw, 512 + 2 * t + 1);
-    gs_bfly(x[0], x[2], wa, P); gs_bfly(x[1], x[3], wa, P);
-    gs_bfly(x[4], x[6], wb, P); gs_bfly(x[5], x[7], wb, P);
+    for (unsigned k = 0; k < 4; ++k) gs_bfly(x[2 * k], x[2 * k + 1], w[2 + k], P);
+    gs_bfly(x[0], x[2], w[0], P); gs_bfly(x[1], x[3], w[0], P);
+    gs_bfly(x[4], x[6], w[1], P); gs_bfly(x[5], x[7], w[1], P);
+}
+LFHE_HD void gs_radix4x2(double (&x)[8], const double* __restrict__ tw, unsigned t, const Prime& P) {
+    double w[7];
+    load_tw4x2(tw, t, w);
+    gs_radix4x2(x, w, P);
 }
 
 LFHE_HD void norm8(double (&x)[8], const Prime& P) {
@@ -163,18 +190,22 @@ LFHE_HD void norm8(double (&x)[8], const Prime& P) {
 // may run before the sums (8 p) must be brought back; the inverse transform places its three
 // normalisations after stages 2, 6 and 10 of 11.
 template <int NORM_AFTER = 0>
-LFHE_HD void gs_radix8(double (&x)[8], const double* __restrict__ tw, unsigned b, const Prime& P) {
+LFHE_HD void gs_radix8(double (&x)[8], const double (&w)[7], const Prime& P) {
 #pragma unroll
-    for (unsigned k = 0; k < 4; ++k) gs_bfly(x[2 * k], x[2 * k + 1], ldtw(tw, 4 * b + k), P);
+    for (unsigned k = 0; k < 4; ++k) gs_bfly(x[2 * k], x[2 * k + 1], w[3 + k], P);
     if (NORM_AFTER == 1) norm8(x, P);
-    const double w2a = ldtw(tw, 2 * b), w2b = ldtw(tw, 2 * b + 1);
-    gs_bfly(x[0], x[2], w2a, P); gs_bfly(x[1], x[3], w2a, P);
-    gs_bfly(x[4], x[6], w2b, P); gs_bfly(x[5], x[7], w2b, P);
+    gs_bfly(x[0], x[2], w[1], P); gs_bfly(x[1], x[3], w[1], P);
+    gs_bfly(x[4], x[6], w[2], P); gs_bfly(x[5], x[7], w[2], P);
     if (NORM_AFTER == 2) norm8(x, P);
-    const double w1 = ldtw(tw, b);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) gs_bfly(x[j], x[j + 4], w1, P);
+    for (int j = 0; j < 4; ++j) gs_bfly(x[j], x[j + 4], w[0], P);
     if (NORM_AFTER == 3) norm8(x, P);
+}
+template <int NORM_AFTER = 0>
+LFHE_HD void gs_radix8(double (&x)[8], const double* __restrict__ tw, unsigned b, const Prime& P) {
+    double w[7];
+    load_tw8(tw, b, w);
+    gs_radix8<NORM_AFTER>(x, w, P);
 }
 
 // table index of the first stage of each radix-8 pass

@@ -25,6 +25,7 @@ constexpr int BSK_ROW = 2 * 4 * BSK_POLY;   // doubles per i
 LFHE_HD unsigned bsk_off(unsigned r, unsigned q, unsigned c4, unsigned t) { return ((r * 4 + q) * 4 + c4) * (NT * 2) + t * 2; }
 
 struct EpState {
+    double tw[7];      // twiddles of the next pass, loaded one phase ahead
     int dig[2][E];     // in: decomposition digits, pass-1 ownership
     double x[2][E];    // working residues
     double y0[2][E];   // prime-0 result, pass-1 ownership
@@ -81,19 +82,23 @@ LFHE_HD void ep_phase(EpState& s, double* lds, unsigned t, const Tables& T, cons
             ct_radix8(s.x[q], twf, 1, P);
         }
         st_o1p12(b0, t, s.x[0]); st_o1p12(b1, t, s.x[1]);
+        load_tw8(twf, base2(t), s.tw);
     } else if constexpr (ph == 1) {
         ld_o2p12(b0, t, s.x[0]); ld_o2p12(b1, t, s.x[1]);
-        ct_radix8(s.x[0], twf, base2(t), P); ct_radix8(s.x[1], twf, base2(t), P);
+        ct_radix8(s.x[0], s.tw, P); ct_radix8(s.x[1], s.tw, P);
     } else if constexpr (ph == 2) {
         st_o2p23(b0, t, s.x[0]); st_o2p23(b1, t, s.x[1]);
+        load_tw8(twf, base3(t), s.tw);
     } else if constexpr (ph == 3) {
         ld_o3p23(b0, t, s.x[0]); ld_o3p23(b1, t, s.x[1]);
-        ct_radix8(s.x[0], twf, base3(t), P); ct_radix8(s.x[1], twf, base3(t), P);
+        ct_radix8(s.x[0], s.tw, P); ct_radix8(s.x[1], s.tw, P);
     } else if constexpr (ph == 4) {
         st_o3p34(b0, t, s.x[0]); st_o3p34(b1, t, s.x[1]);
+        load_tw4x2(twf, t, s.tw);
     } else if constexpr (ph == 5) {  // forward pass 4, point-wise with the key row, inverse pass 4
         ld_o4p34(b0, t, s.x[0]); ld_o4p34(b1, t, s.x[1]);
-        ct_radix4x2(s.x[0], twf, t, P); ct_radix4x2(s.x[1], twf, t, P);
+        ct_radix4x2(s.x[0], s.tw, P); ct_radix4x2(s.x[1], s.tw, P);
+        load_tw4x2(twi, t, s.tw);   // for the inverse pass below: in flight during the point-wise stage
         // key row, two coefficients (one 16-byte load per polynomial) at a time, the next chunk's
         // loads in flight while this one is multiplied; the fences keep the compiler from hoisting
         // all sixteen loads (64 registers) to the top of the phase
@@ -119,18 +124,20 @@ LFHE_HD void ep_phase(EpState& s, double* lds, unsigned t, const Tables& T, cons
 #pragma unroll
             for (int q = 0; q < 4; ++q) { kc[q][0] = kn[q][0]; kc[q][1] = kn[q][1]; }
         }
-        gs_radix4x2(s.x[0], twi, t, P); gs_radix4x2(s.x[1], twi, t, P);
+        gs_radix4x2(s.x[0], s.tw, P); gs_radix4x2(s.x[1], s.tw, P);
         norm8(s.x[0], P); norm8(s.x[1], P);
     } else if constexpr (ph == 6) {
         st_o4p34(b0, t, s.x[0]); st_o4p34(b1, t, s.x[1]);
+        load_tw8(twi, base3(t), s.tw);
     } else if constexpr (ph == 7) {
         ld_o3p34(b0, t, s.x[0]); ld_o3p34(b1, t, s.x[1]);
-        gs_radix8(s.x[0], twi, base3(t), P); gs_radix8(s.x[1], twi, base3(t), P);                 // stages 3-5
+        gs_radix8(s.x[0], s.tw, P); gs_radix8(s.x[1], s.tw, P);                 // stages 3-5
     } else if constexpr (ph == 8) {
         st_o3p23(b0, t, s.x[0]); st_o3p23(b1, t, s.x[1]);
+        load_tw8(twi, base2(t), s.tw);
     } else if constexpr (ph == 9) {
         ld_o2p23(b0, t, s.x[0]); ld_o2p23(b1, t, s.x[1]);
-        gs_radix8<1>(s.x[0], twi, base2(t), P); gs_radix8<1>(s.x[1], twi, base2(t), P);           // 6 | 7-8
+        gs_radix8<1>(s.x[0], s.tw, P); gs_radix8<1>(s.x[1], s.tw, P);           // 6 | 7-8
     } else if constexpr (ph == 10) {
         st_o2p12(b0, t, s.x[0]); st_o2p12(b1, t, s.x[1]);
     } else {  // ph == 11: inverse pass 1, then keep (prime 0) or lift (prime 1)

@@ -19,10 +19,11 @@ GPU_OPS = {"add", "sub", "mul", "eq", "ne", "ge", "gt", "le", "lt", "min", "max"
 SPECIALISED = {"shl", "shr", "rotl", "rotr", "div", "rem"}
 
 
-@pytest.fixture(scope="module")
-def ctx():
+@pytest.fixture(scope="module", params=[1, 2], ids=["bsk_q64", "bsk_prime"])
+def ctx(request):
+    """Library-generated keys, once per ring modulus of the bootstrapping key."""
     from fhe_amd.native import Context
-    c = Context(seed=bytes(range(32)))
+    c = Context(seed=bytes(range(32)), params_id=request.param)
     c.keygen()
     yield c
     c.close()
