@@ -471,6 +471,9 @@ __global__ void __launch_bounds__(256) k_ksk_colsum(const u64* __restrict__ ksk,
     colsum[col] = s * (u64)half_base;
 }
 
+// gridDim.z > 1 splits the input coefficients between workgroups (small batches would otherwise
+// run a few workgroups through 8192 key rows each): every slice then adds its share into `out`,
+// which the launcher has zeroed, with 64-bit atomics; wrapping sums do not depend on the order.
 __global__ void __launch_bounds__(256) k_keyswitch(const u64* __restrict__ ksk,
                                                    const u64* __restrict__ colsum,
                                                    const u64* __restrict__ in, u64* __restrict__ out,
@@ -480,22 +483,26 @@ __global__ void __launch_bounds__(256) k_keyswitch(const u64* __restrict__ ksk,
     const int cols = n + 1;
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
     const int ct0 = blockIdx.y * KS_CT;
+    const int chunks = (big + KS_CHUNK - 1) / KS_CHUNK;
+    const int per = (chunks + gridDim.z - 1) / gridDim.z;
+    const int i_begin = blockIdx.z * per * KS_CHUNK;
+    const int i_end = min(big, i_begin + per * KS_CHUNK);
     u64 acc[KS_CT];
 #pragma unroll
     for (int c = 0; c < KS_CT; ++c) acc[c] = 0;
-    for (int i0 = 0; i0 < big; i0 += KS_CHUNK) {
+    for (int i0 = i_begin; i0 < i_end; i0 += KS_CHUNK) {
         __syncthreads();
         for (int k = threadIdx.x; k < KS_CT * KS_CHUNK; k += blockDim.x) {
             const int c = k / KS_CHUNK, ii = k % KS_CHUNK;
             const int ct = ct0 + c;
             u32 pk = 0;
-            if (ct < count && i0 + ii < big)
+            if (ct < count && i0 + ii < i_end)
                 pk = ks_digits_packed(in[imap.block(ct) * (size_t)(big + 1) + i0 + ii], base_log, levels);
             dig[c][ii] = pk;
         }
         __syncthreads();
         if (col < cols) {
-            const int lim = (big - i0) < KS_CHUNK ? (big - i0) : KS_CHUNK;
+            const int lim = (i_end - i0) < KS_CHUNK ? (i_end - i0) : KS_CHUNK;
             for (int ii = 0; ii < lim; ++ii) {
                 for (int lv = 0; lv < levels; ++lv) {
                     const u64 k = ksk[((size_t)(i0 + ii) * levels + lv) * cols + col];
@@ -509,13 +516,17 @@ __global__ void __launch_bounds__(256) k_keyswitch(const u64* __restrict__ ksk,
         }
     }
     if (col < cols) {
-        const u64 cs = colsum[col];
+        // the shifted digits overcount by (B/2) * sum of the slice's key rows: colsum covers all rows
+        // and is added once, by slice 0
+        const u64 cs = blockIdx.z == 0 ? colsum[col] : 0;
 #pragma unroll
         for (int c = 0; c < KS_CT; ++c) {
             const int ct = ct0 + c;
             if (ct < count) {
-                const u64 b = (col == n) ? in[imap.block(ct) * (size_t)(big + 1) + big] : 0;
-                out[(size_t)ct * cols + col] = b - acc[c] + cs;
+                const u64 b = (col == n && blockIdx.z == 0) ? in[imap.block(ct) * (size_t)(big + 1) + big] : 0;
+                const u64 v = b - acc[c] + cs;
+                if (gridDim.z == 1) out[(size_t)ct * cols + col] = v;
+                else atomicAdd(reinterpret_cast<unsigned long long*>(out + (size_t)ct * cols + col), (unsigned long long)v);
             }
         }
     }
@@ -561,9 +572,14 @@ void launch_ksk_colsum(const u64* ksk, int rows, int cols, int half_base, u64* c
 }
 void launch_keyswitch(const u64* ksk, const u64* colsum, const u64* in, u64* out, size_t count, int big, int n,
                       int base_log, int levels, const BlockMap& imap, hipStream_t st) {
-    dim3 grid((n + 1 + 255) / 256, (unsigned)((count + KS_CT - 1) / KS_CT));
-    hipLaunchKernelGGL(k_keyswitch, grid, dim3(256), 0, st, ksk, colsum, in, out, (int)count, big, n, base_log, levels,
-                       imap);
+    const unsigned colblocks = (unsigned)((n + 1 + 255) / 256), groups = (unsigned)((count + KS_CT - 1) / KS_CT);
+    // enough workgroups to cover the GPU a few times over; a slice is a whole number of chunks
+    unsigned split = 1;
+    const unsigned chunks = (unsigned)((big + KS_CHUNK - 1) / KS_CHUNK);
+    while (split * 2 <= chunks && colblocks * groups * split < 1024) split *= 2;
+    if (split > 1) (void)hipMemsetAsync(out, 0, count * (size_t)(n + 1) * sizeof(u64), st);
+    hipLaunchKernelGGL(k_keyswitch, dim3(colblocks, groups, split), dim3(256), 0, st, ksk, colsum, in, out, (int)count,
+                       big, n, base_log, levels, imap);
 }
 
 // ------------------------------------------------------------------------------------------------
