@@ -1,6 +1,7 @@
 #include "engine.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <stdexcept>
 #include <vector>
 
@@ -33,6 +34,11 @@ Engine::Engine(int device, const EngineParams& p) : device_(device), prm_(p) {
     if (device < 0 || device >= ndev) throw std::runtime_error("device index out of range");
     HC(hipSetDevice(device_));
     HC(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    hipDeviceProp_t prop;
+    HC(hipGetDeviceProperties(&prop, device_));
+    cu_count_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    wide_below_ = 2 * cu_count_;
+    if (const char* e = std::getenv("LFHE_WIDE_BELOW")) wide_below_ = std::atoi(e);   // tuning / A-B runs
 
     HostTables H;
     build_host_tables(H);
@@ -197,7 +203,7 @@ void Engine::blind_rotate(const u64* lwe_small, const u64* luts, const u32* lut_
     u64* ws = acc_scratch(count);
     if (single_modulus())
         launch_blind_rotate_q(T_, d_bsk_, lwe_small, (int)prm_.lwe_dim, luts, lut_index, reinterpret_cast<double*>(ws),
-                              glwe_out, lwe_out, count, omap, 1.0 / (double)qp_gadget(), stream_);
+                              glwe_out, lwe_out, count, omap, 1.0 / (double)qp_gadget(), wide_below_, stream_);
     else
         launch_blind_rotate(T_, d_bsk_, lwe_small, (int)prm_.lwe_dim, luts, lut_index, ws, glwe_out, lwe_out, count,
                             omap, stream_);

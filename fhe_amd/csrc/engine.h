@@ -54,7 +54,7 @@ void launch_external_product_q(const Tables& T, const double* bsk, const u32* id
                                size_t count, double inv_g, hipStream_t st);
 void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
                            const u32* lut_index, double* acc_ws, u64* glwe_out, u64* lwe_out, size_t count,
-                           const BlockMap& omap, double inv_g, hipStream_t st);
+                           const BlockMap& omap, double inv_g, int wide_below, hipStream_t st);
 void launch_lin_batch(u64* arena, const LinOp* ops, int nops, size_t instances, size_t inst_stride_blocks, u64 delta,
                       hipStream_t st);
 void launch_ksk_colsum(const u64* ksk, int rows, int cols, int half_base, u64* colsum, hipStream_t st);
@@ -139,6 +139,8 @@ private:
     u64* d_acc_ = nullptr;
     size_t acc_cap_ = 0;
     MsParams ms_{};
+    int cu_count_ = 256;
+    int wide_below_ = -1;   // launches of at most this many ciphertexts use 512 threads each
     void set_ms_params(u32 zcount);
     u64* ms_zeros_dev() const { return d_ksk_ + ksk_words() + prm_.lwe_dim + 1 + 1; }
 };

@@ -420,6 +420,137 @@ __global__ void __launch_bounds__(NT, LFHE_BRQ_WAVES) k_blind_rotate_q(Tables T,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same blind rotation for launches too small to fill the GPU (one operation's bootstrap layer
+// is often a few dozen ciphertexts): 512 threads per ciphertext, threads 0-255 own the mask
+// polynomial, 256-511 the body polynomial.  Each half decomposes, transforms and inverse-transforms
+// its own polynomial in its own LDS buffer; the only coupling is the point-wise stage, where each
+// half publishes its transformed digits and reads the other half's.  A step has half the
+// instructions per thread of k_blind_rotate_q and one more barrier.  Results are bit-identical.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q_wide(Tables T, const double* __restrict__ bsk,
+                                                                   const u64* __restrict__ lwe_small, int n,
+                                                                   const u64* __restrict__ luts,
+                                                                   const u32* __restrict__ lut_index,
+                                                                   double* __restrict__ acc_ws,
+                                                                   u64* __restrict__ glwe_out,
+                                                                   u64* __restrict__ lwe_out, BlockMap omap,
+                                                                   double inv_g) {
+    const unsigned h = threadIdx.x >> 8;   // polynomial of this half (wave-uniform)
+    const unsigned t0 = threadIdx.x & (NT - 1);
+    const size_t ct = blockIdx.x;
+    const Prime P = T.pr[0];
+    const u64* __restrict__ lwe = lwe_small + ct * (size_t)(n + 1);
+    const u64* __restrict__ lut = luts + (size_t)(lut_index ? lut_index[omap.ops ? ct % omap.ops : ct] : 0) * N;
+    double* mine = lds_dyn + h * POLY_STRIDE;
+    double* theirs = lds_dyn + (1 - h) * POLY_STRIDE;
+    const double* __restrict__ twf = T.tw_fwd[0];
+    const double* __restrict__ twi = T.tw_inv[0];
+
+    double acc[E], x[E], w[7];
+    {
+        const unsigned bt = modswitch_2n(lwe[n]);
+        const unsigned a = (2 * N - bt) & (2 * N - 1);  // multiply by X^-b~
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const unsigned e = own1(t0, j);
+            bool neg;
+            const double v = torus_to_qp(lut[rot_index(e, a, neg)]);
+            acc[j] = h ? (neg ? -v : v) : 0.0;
+            mine[e] = acc[j];
+        }
+    }
+    __syncthreads();
+
+    for (int i = 0; i < n; ++i) {
+        const unsigned a = modswitch_2n(lwe[i]);
+        if (a == 0) continue;
+        unsigned t = t0;
+        asm volatile("" : "+v"(t));  // addresses are recomputed per step instead of living in registers
+        // this step's key row goes into registers now: with few workgroups in flight nobody else has
+        // pulled it into L2 yet, and the point-wise stage is half a step away
+        double kx[E], ky[E];
+        {
+            const double* __restrict__ row = bsk + (size_t)i * BSKQ_ROW;
+#pragma unroll
+            for (unsigned c4 = 0; c4 < 4; ++c4) {
+                const unsigned o0 = bsk_off(0, 3 * h, c4, t), o1 = bsk_off(0, 2 - h, c4, t);
+#pragma unroll
+                for (unsigned k = 0; k < 2; ++k) { kx[2 * c4 + k] = ldt(row, o0 + k); ky[2 * c4 + k] = ldt(row, o1 + k); }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            bool neg;
+            const double r = mine[rot_index(own1(t, j), a, neg)];
+            x[j] = __builtin_rint(qp_canon((neg ? -r : r) - acc[j], P) * inv_g);
+        }
+        ct_radix8(x, twf, 1, P);
+        __syncthreads();                      // rotated reads done before the buffer is reused
+        st_o1p12(mine, t, x); load_tw8(twf, base2(t), w);
+        __syncthreads();
+        ld_o2p12(mine, t, x); ct_radix8(x, w, P);
+        __syncthreads();
+        st_o2p23(mine, t, x); load_tw8(twf, base3(t), w);
+        __syncthreads();
+        ld_o3p23(mine, t, x); ct_radix8(x, w, P);
+        __syncthreads();
+        st_o3p34(mine, t, x); load_tw4x2(twf, t, w);
+        __syncthreads();
+        ld_o4p34(mine, t, x); ct_radix4x2(x, w, P);
+        // publish the transformed digits (a thread rewrites the words it has just read) and fetch
+        // the other polynomial's
+        st_o4p34(mine, t, x); load_tw4x2(twi, t, w);
+        __syncthreads();
+        {
+            double y[E];
+            ld_o4p34(theirs, t, y);
+            // out_h = D_h K[h][h] + D_(1-h) K[1-h][h]; key polynomial index q = j_in * 2 + c_out
+            double o[E];
+#pragma unroll
+            for (int j = 0; j < E; ++j) o[j] = mmul(x[j], kx[j], P) + mmul(y[j], ky[j], P);
+#pragma unroll
+            for (int j = 0; j < E; ++j) x[j] = o[j];
+        }
+        gs_radix4x2(x, w, P); norm8(x, P);
+        __syncthreads();                      // the other half has read this buffer
+        st_o4p34(mine, t, x); load_tw8(twi, base3(t), w);
+        __syncthreads();
+        ld_o3p34(mine, t, x); gs_radix8(x, w, P);
+        __syncthreads();
+        st_o3p23(mine, t, x); load_tw8(twi, base2(t), w);
+        __syncthreads();
+        ld_o2p23(mine, t, x); gs_radix8<1>(x, w, P);
+        __syncthreads();
+        st_o2p12(mine, t, x);
+        __syncthreads();
+        ld_o1p12(mine, t, x); gs_radix8<2>(x, twi, 1, P);
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            acc[j] = qp_canon(acc[j] + x[j], P);
+            mine[own1(t, j)] = acc[j];
+        }
+        __syncthreads();
+    }
+
+    double* ws = acc_ws + ct * (size_t)(2 * N) + h * N;
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const double c = acc[j];
+        if (glwe_out) glwe_out[(ct * 2 + h) * N + own1(t0, j)] = c < 0 ? QP_U - (u64)(-c) : (u64)c;
+        ws[own1(t0, j)] = c;
+    }
+    if (lwe_out) {  // sample extraction of coefficient 0, every word switched back to 2^64
+        u64* o = lwe_out + omap.block(ct) * (size_t)(N + 1);
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const unsigned e = own1(t0, j);
+            if (h == 0) o[e == 0 ? 0 : N - e] = qp_to_torus(e == 0 ? acc[j] : -acc[j]);
+            else if (e == 0) o[N] = qp_to_torus(acc[j]);
+        }
+    }
+}
+
 void launch_bskq_prepare(const Tables& T, const u64* in, double* out, size_t polys, hipStream_t st) {
     hipLaunchKernelGGL(k_bskq_prepare, dim3((unsigned)polys), dim3(NT), LDS_BYTES, st, T, in, out);
 }
@@ -430,9 +561,14 @@ void launch_external_product_q(const Tables& T, const double* bsk, const u32* id
 }
 void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
                            const u32* lut_index, double* acc_ws, u64* glwe_out, u64* lwe_out, size_t count,
-                           const BlockMap& omap, double inv_g, hipStream_t st) {
-    hipLaunchKernelGGL(k_blind_rotate_q, dim3((unsigned)count), dim3(NT), LDS_BYTES, st, T, bsk, lwe_small, n, luts,
-                       lut_index, acc_ws, glwe_out, lwe_out, omap, inv_g);
+                           const BlockMap& omap, double inv_g, int wide_below, hipStream_t st) {
+    // up to two ciphertexts per CU: latency matters more than throughput, use 512 threads each
+    if (count <= (size_t)wide_below)
+        hipLaunchKernelGGL(k_blind_rotate_q_wide, dim3((unsigned)count), dim3(2 * NT), LDS_BYTES, st, T, bsk, lwe_small,
+                           n, luts, lut_index, acc_ws, glwe_out, lwe_out, omap, inv_g);
+    else
+        hipLaunchKernelGGL(k_blind_rotate_q, dim3((unsigned)count), dim3(NT), LDS_BYTES, st, T, bsk, lwe_small, n, luts,
+                           lut_index, acc_ws, glwe_out, lwe_out, omap, inv_g);
 }
 
 // ------------------------------------------------------------------------------------------------

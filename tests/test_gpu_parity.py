@@ -192,8 +192,14 @@ def test_ms_noise_reduction_bit_exact(full):
 
 
 # ---- bootstrap over the prime ring modulus (bootstrapping key and accumulator in Z_q') ------------
-def _mk_prime(n, seed, ms_zeros=0):
+def _mk_prime(n, seed, ms_zeros=0, wide=True):
+    """wide=False forces the 256-thread blind rotation for small launches too (by default launches
+    of up to two ciphertexts per CU take the 512-thread kernel)."""
+    import os
     from fhe_amd.native import Context, Params, default_params, BSK_MODULUS_PRIME
+    os.environ.pop("LFHE_WIDE_BELOW", None)
+    if not wide:
+        os.environ["LFHE_WIDE_BELOW"] = "0"
     op = OParams(lwe_dim=n)
     orc = Oracle(op)
     lwe_sk, glwe_sk, _, ksk = orc.gen_keys(seed_bytes(seed))
@@ -208,13 +214,15 @@ def _mk_prime(n, seed, ms_zeros=0):
         zeros = orc.gen_ms_zeros(lwe_sk, seed_bytes(seed), ms_zeros)
         orc.set_ms(zeros)
     ctx = Context(seed=seed_bytes(100 + seed), params=p)
+    os.environ.pop("LFHE_WIDE_BELOW", None)
     ctx.import_server_keys_raw(bskq, ksk, zeros)
     ctx.import_client_keys_raw(lwe_sk, glwe_sk)
     return orc, (lwe_sk, glwe_sk, bskq, ksk), ctx
 
 
-def test_prime_modulus_external_product_and_blind_rotation_bit_exact():
-    orc, keys, ctx = _mk_prime(12, seed=4)
+@pytest.mark.parametrize("wide", [True, False], ids=["512-thread", "256-thread"])
+def test_prime_modulus_external_product_and_blind_rotation_bit_exact(wide):
+    orc, keys, ctx = _mk_prime(12, seed=4, wide=wide)
     try:
         lwe_sk, glwe_sk, bskq, ksk = keys
         q = orc.qp
@@ -250,10 +258,11 @@ def test_prime_modulus_external_product_and_blind_rotation_bit_exact():
         ctx.close()
 
 
-def test_prime_modulus_pbs_full_parameters():
+@pytest.mark.parametrize("wide", [True, False], ids=["512-thread", "256-thread"])
+def test_prime_modulus_pbs_full_parameters(wide):
     """n = 918 with the noise reduction on: outputs decrypt to f(m), a subsample is bit-identical
     to the oracle, the output noise stays far below half a message step."""
-    orc, keys, ctx = _mk_prime(918, seed=5, ms_zeros=1449)
+    orc, keys, ctx = _mk_prime(918, seed=5, ms_zeros=1449, wide=wide)
     try:
         lwe_sk, glwe_sk, bskq, ksk = keys
         pb = orc.prepare_bsk_qp(bskq)
