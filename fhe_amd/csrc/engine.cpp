@@ -62,6 +62,7 @@ Engine::~Engine() {
     if (own_keys_) { (void)hipFree(d_bsk_); (void)hipFree(d_ksk_); }
     (void)hipFree(d_tw_);
     (void)hipFree(d_small_);
+    (void)hipFree(d_ksdig_);
     (void)hipFree(d_acc_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -172,7 +173,15 @@ void Engine::keyswitch(const u64* lwe_in, u64* lwe_small_out, size_t count, cons
     if (!d_ksk_) throw std::runtime_error("no key-switching key loaded");
     if (!count) return;
     HC(hipSetDevice(device_));
-    launch_keyswitch(d_ksk_, d_ksk_ + ksk_words(), lwe_in, lwe_small_out, count, N, (int)prm_.lwe_dim,
+    const size_t need = keyswitch_scratch_words(count, N);
+    if (need > ksdig_cap_) {
+        HC(hipStreamSynchronize(stream_));
+        (void)hipFree(d_ksdig_);
+        d_ksdig_ = nullptr;
+        HC(hipMalloc(&d_ksdig_, need * sizeof(u32)));
+        ksdig_cap_ = need;
+    }
+    launch_keyswitch(d_ksk_, d_ksk_ + ksk_words(), lwe_in, d_ksdig_, lwe_small_out, count, N, (int)prm_.lwe_dim,
                      (int)prm_.ks_base_log, (int)prm_.ks_level, imap, stream_);
     HC(hipGetLastError());
 }

@@ -58,8 +58,10 @@ void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_sm
 void launch_lin_batch(u64* arena, const LinOp* ops, int nops, size_t instances, size_t inst_stride_blocks, u64 delta,
                       hipStream_t st);
 void launch_ksk_colsum(const u64* ksk, int rows, int cols, int half_base, u64* colsum, hipStream_t st);
-void launch_keyswitch(const u64* ksk, const u64* colsum, const u64* in, u64* out, size_t count, int big, int n,
-                      int base_log, int levels, const BlockMap& imap, hipStream_t st);
+// dig_scratch: keyswitch_scratch_words(count, big) 32-bit words of device memory
+void launch_keyswitch(const u64* ksk, const u64* colsum, const u64* in, u32* dig_scratch, u64* out, size_t count,
+                      int big, int n, int base_log, int levels, const BlockMap& imap, hipStream_t st);
+size_t keyswitch_scratch_words(size_t count, int big);
 void launch_ms_noise_reduce(u64* lwe_small, int n, const u64* zeros, const MsParams& m, int* chosen, size_t count,
                             hipStream_t st);
 void launch_lwe_linear(const u64* a, const u64* b, u64* out, size_t count, int dim1, u64 ca, u64 cb, u64 add_body,
@@ -136,6 +138,8 @@ private:
     bool own_keys_ = false;
     u64* d_small_ = nullptr;
     size_t small_cap_ = 0;
+    u32* d_ksdig_ = nullptr;   // packed key-switch digits of the launch in flight
+    size_t ksdig_cap_ = 0;
     u64* d_acc_ = nullptr;
     size_t acc_cap_ = 0;
     MsParams ms_{};

@@ -577,8 +577,8 @@ void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_sm
 // (B/2) * sum KSK is precomputed per column (colsum).  One thread per output column (coalesced
 // key reads), KS_CT ciphertexts per workgroup share every key word read.
 // ------------------------------------------------------------------------------------------------
-constexpr int KS_CT = 16;      // ciphertexts per workgroup
-constexpr int KS_CHUNK = 64;   // input coefficients whose digits are staged in LDS at a time
+constexpr int KS_CT = 16;      // ciphertexts per workgroup: every key word read serves this many
+
 
 __device__ __forceinline__ u32 ks_digits_packed(u64 x, int base_log, int levels) {
     // shifted digits u = d + B/2, one per byte, level lv in byte lv (lv = 0 most significant)
@@ -607,60 +607,84 @@ __global__ void __launch_bounds__(256) k_ksk_colsum(const u64* __restrict__ ksk,
     colsum[col] = s * (u64)half_base;
 }
 
-// gridDim.z > 1 splits the input coefficients between workgroups (small batches would otherwise
-// run a few workgroups through 8192 key rows each): every slice then adds its share into `out`,
-// which the launcher has zeroed, with 64-bit atomics; wrapping sums do not depend on the order.
+// Stage 1: the shifted digits of every input coefficient, packed one per byte, laid out
+// [coefficient][group of KS_CT ciphertexts][KS_CT] so that stage 2 fetches the sixteen words of a
+// (coefficient, group) pair with one scalar load.
+__global__ void __launch_bounds__(256) k_ks_digits(const u64* __restrict__ in, u32* __restrict__ dig, int count,
+                                                   int big, int base_log, int levels, BlockMap imap) {
+    const int groups = (count + KS_CT - 1) / KS_CT;
+    const size_t total = (size_t)groups * KS_CT * big;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(k % big);            // consecutive threads read consecutive coefficients
+        const int ct = (int)(k / big);
+        u32 pk = 0;
+        if (ct < count) pk = ks_digits_packed(in[imap.block(ct) * (size_t)(big + 1) + i], base_log, levels);
+        dig[((size_t)i * groups + ct / KS_CT) * KS_CT + ct % KS_CT] = pk;
+    }
+}
+
+// Stage 2: one thread per output column, KS_CT ciphertexts per workgroup.  The digits are
+// wave-uniform, so they live in scalar registers and their extraction runs on the scalar unit;
+// the vector unit is left with two 32x32->64 multiply-adds per 64-bit product (low and high key
+// half, recombined at the end).  gridDim.z > 1 splits the input coefficients between workgroups
+// (small batches would otherwise run a few workgroups through 8192 key rows each): every slice
+// then adds its share into `out`, which the launcher has zeroed, with 64-bit atomics; wrapping
+// sums do not depend on the order.
+template <int LEVELS>
 __global__ void __launch_bounds__(256) k_keyswitch(const u64* __restrict__ ksk,
                                                    const u64* __restrict__ colsum,
-                                                   const u64* __restrict__ in, u64* __restrict__ out,
-                                                   int count, int big, int n, int base_log, int levels,
+                                                   const u64* __restrict__ in, const u32* __restrict__ dig,
+                                                   u64* __restrict__ out, int count, int big, int n,
                                                    BlockMap imap) {
-    __shared__ u32 dig[KS_CT][KS_CHUNK];
     const int cols = n + 1;
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    const int colc = col < cols ? col : cols - 1;   // lanes past the last column repeat it and drop the result
     const int ct0 = blockIdx.y * KS_CT;
-    const int chunks = (big + KS_CHUNK - 1) / KS_CHUNK;
-    const int per = (chunks + gridDim.z - 1) / gridDim.z;
-    const int i_begin = blockIdx.z * per * KS_CHUNK;
-    const int i_end = min(big, i_begin + per * KS_CHUNK);
-    u64 acc[KS_CT];
+    const int groups = gridDim.y;
+    const int per = (big + gridDim.z - 1) / gridDim.z;
+    const int i_begin = blockIdx.z * per;
+    const int i_end = min(big, i_begin + per);
+    u64 lo[KS_CT], hi[KS_CT];
 #pragma unroll
-    for (int c = 0; c < KS_CT; ++c) acc[c] = 0;
-    for (int i0 = i_begin; i0 < i_end; i0 += KS_CHUNK) {
-        __syncthreads();
-        for (int k = threadIdx.x; k < KS_CT * KS_CHUNK; k += blockDim.x) {
-            const int c = k / KS_CHUNK, ii = k % KS_CHUNK;
-            const int ct = ct0 + c;
-            u32 pk = 0;
-            if (ct < count && i0 + ii < i_end)
-                pk = ks_digits_packed(in[imap.block(ct) * (size_t)(big + 1) + i0 + ii], base_log, levels);
-            dig[c][ii] = pk;
+    for (int c = 0; c < KS_CT; ++c) { lo[c] = 0; hi[c] = 0; }
+    // key words of the next coefficient are in flight while this one is multiplied
+    u64 kn[LEVELS];
+    if (i_begin < i_end) {
+#pragma unroll
+        for (int lv = 0; lv < LEVELS; ++lv) kn[lv] = ksk[((size_t)i_begin * LEVELS + lv) * cols + colc];
+    }
+    for (int i = i_begin; i < i_end; ++i) {
+        u64 k[LEVELS];
+#pragma unroll
+        for (int lv = 0; lv < LEVELS; ++lv) k[lv] = kn[lv];
+        if (i + 1 < i_end) {
+#pragma unroll
+            for (int lv = 0; lv < LEVELS; ++lv) kn[lv] = ksk[((size_t)(i + 1) * LEVELS + lv) * cols + colc];
         }
-        __syncthreads();
-        if (col < cols) {
-            const int lim = (i_end - i0) < KS_CHUNK ? (i_end - i0) : KS_CHUNK;
-            for (int ii = 0; ii < lim; ++ii) {
-                for (int lv = 0; lv < levels; ++lv) {
-                    const u64 k = ksk[((size_t)(i0 + ii) * levels + lv) * cols + col];
+        const u32* __restrict__ d = dig + ((size_t)i * groups + blockIdx.y) * KS_CT;
+        u32 w[KS_CT];
 #pragma unroll
-                    for (int c = 0; c < KS_CT; ++c) {
-                        const u32 u = (dig[c][ii] >> (8 * lv)) & 0xffu;
-                        acc[c] += (u64)u * k;
-                    }
-                }
+        for (int c = 0; c < KS_CT; ++c) w[c] = d[c];
+#pragma unroll
+        for (int lv = 0; lv < LEVELS; ++lv) {
+            const u32 klo = (u32)k[lv], khi = (u32)(k[lv] >> 32);
+#pragma unroll
+            for (int c = 0; c < KS_CT; ++c) {
+                const u32 u = (w[c] >> (8 * lv)) & 0xffu;
+                lo[c] += (u64)u * klo;
+                hi[c] += (u64)u * khi;
             }
         }
     }
     if (col < cols) {
-        // the shifted digits overcount by (B/2) * sum of the slice's key rows: colsum covers all rows
-        // and is added once, by slice 0
+        // the shifted digits overcount by (B/2) * sum of all key rows: added once, by slice 0
         const u64 cs = blockIdx.z == 0 ? colsum[col] : 0;
 #pragma unroll
         for (int c = 0; c < KS_CT; ++c) {
             const int ct = ct0 + c;
             if (ct < count) {
                 const u64 b = (col == n && blockIdx.z == 0) ? in[imap.block(ct) * (size_t)(big + 1) + big] : 0;
-                const u64 v = b - acc[c] + cs;
+                const u64 v = b - (lo[c] + (hi[c] << 32)) + cs;
                 if (gridDim.z == 1) out[(size_t)ct * cols + col] = v;
                 else atomicAdd(reinterpret_cast<unsigned long long*>(out + (size_t)ct * cols + col), (unsigned long long)v);
             }
@@ -706,17 +730,27 @@ void launch_blind_rotate(const Tables& T, const double* bsk, const u64* lwe_smal
 void launch_ksk_colsum(const u64* ksk, int rows, int cols, int half_base, u64* colsum, hipStream_t st) {
     hipLaunchKernelGGL(k_ksk_colsum, dim3((cols + 255) / 256), dim3(256), 0, st, ksk, rows, cols, half_base, colsum);
 }
-void launch_keyswitch(const u64* ksk, const u64* colsum, const u64* in, u64* out, size_t count, int big, int n,
-                      int base_log, int levels, const BlockMap& imap, hipStream_t st) {
+void launch_keyswitch(const u64* ksk, const u64* colsum, const u64* in, u32* dig_scratch, u64* out, size_t count,
+                      int big, int n, int base_log, int levels, const BlockMap& imap, hipStream_t st) {
     const unsigned colblocks = (unsigned)((n + 1 + 255) / 256), groups = (unsigned)((count + KS_CT - 1) / KS_CT);
-    // enough workgroups to cover the GPU a few times over; a slice is a whole number of chunks
+    const size_t total = (size_t)groups * KS_CT * big;
+    unsigned dblocks = (unsigned)((total + 255) / 256);
+    if (dblocks > 8192) dblocks = 8192;
+    hipLaunchKernelGGL(k_ks_digits, dim3(dblocks), dim3(256), 0, st, in, dig_scratch, (int)count, big, base_log, levels,
+                       imap);
+    // enough workgroups to cover the GPU a few times over
     unsigned split = 1;
-    const unsigned chunks = (unsigned)((big + KS_CHUNK - 1) / KS_CHUNK);
-    while (split * 2 <= chunks && colblocks * groups * split < 1024) split *= 2;
+    while (split * 2 <= 64 && colblocks * groups * split < 1024) split *= 2;
     if (split > 1) (void)hipMemsetAsync(out, 0, count * (size_t)(n + 1) * sizeof(u64), st);
-    hipLaunchKernelGGL(k_keyswitch, dim3(colblocks, groups, split), dim3(256), 0, st, ksk, colsum, in, out, (int)count,
-                       big, n, base_log, levels, imap);
+    const dim3 grid(colblocks, groups, split);
+    switch (levels) {
+        case 1: hipLaunchKernelGGL(k_keyswitch<1>, grid, dim3(256), 0, st, ksk, colsum, in, dig_scratch, out, (int)count, big, n, imap); break;
+        case 2: hipLaunchKernelGGL(k_keyswitch<2>, grid, dim3(256), 0, st, ksk, colsum, in, dig_scratch, out, (int)count, big, n, imap); break;
+        case 3: hipLaunchKernelGGL(k_keyswitch<3>, grid, dim3(256), 0, st, ksk, colsum, in, dig_scratch, out, (int)count, big, n, imap); break;
+        default: hipLaunchKernelGGL(k_keyswitch<4>, grid, dim3(256), 0, st, ksk, colsum, in, dig_scratch, out, (int)count, big, n, imap); break;
+    }
 }
+size_t keyswitch_scratch_words(size_t count, int big) { return ((count + KS_CT - 1) / KS_CT) * KS_CT * (size_t)big; }
 
 // ------------------------------------------------------------------------------------------------
 // linear layer of a radix program: for every instance and every LinOp,
