@@ -31,6 +31,9 @@ MODMUL_PER_PBS = 3672 * 11264 + 918 * 4 * 2048
 # f64 butterflies (modular multiply + add + sub) per prime.  Over q = 2^64 a logical modular product
 # costs one butterfly in each of two primes; over the prime ring modulus it costs one.
 PEAK_GBFLY_PER_PRIME = 4748.0
+# memory-side traffic of one 4096-ciphertext blind-rotation launch, from separate rocprofv3 --pmc passes
+# (profiles/r01/pmc_hbm_v5.txt): (2 * FETCH_SIZE + WRITE_SIZE) * 1024, Infinity-Cache hits included
+TRAFFIC_BYTES_4096 = {"prime": (2 * 3808307 + 196800) * 1024, "q64": (2 * 7909668 + 196739) * 1024}
 # algorithmic bytes of one batch launch: both keys once + one ciphertext in and out per bootstrap
 BSK_BYTES, KSK_BYTES, CT_BYTES = 60162048, 60227584, 16392
 
@@ -224,7 +227,8 @@ def main():
             "verified": ok,
             "kernel_ms": {"keyswitch_and_ms_noise_reduction": ks_ms, "blind_rotate": br_ms},
             "roofline": {"bound": "valu", "kernel": "k_blind_rotate_q" if prime else "k_blind_rotate", "achieved": achieved, "peak": peak,
-                         "unit": "Gmodmul/s", "frac": achieved / peak, "traffic": None,
+                         "unit": "Gmodmul/s", "frac": achieved / peak,
+                         "traffic": TRAFFIC_BYTES_4096[args.bsk_modulus] if B == BATCH else None,
                          "hbm": {"achieved": algo_bytes / ((ks_ms + br_ms) * 1e-3) / 1e9, "peak": 8000.0,
                                  "unit": "GB/s", "algorithmic_bytes": algo_bytes}},
         }
