@@ -1,0 +1,146 @@
+'use strict';
+/*
+ * In-process replacement for the HTTP engine the reference's SDK talks to.
+ *
+ * NativeEngine wraps the N-API addon (lfhe_napi.node -> liblfhe.so).  LuxFHEClient keeps the method
+ * names of the reference class (packages/luxfhejs/src/index.ts:42-141: initialize, getPublicKey,
+ * encrypt_uint8 ... encrypt_uint256, encrypt_address) and of the hardhat plugin
+ * (packages/hardhat-plugin/src/index.ts:57-87: encrypt, decrypt, getPublicKey), and adds
+ * evaluate(), which the reference only reaches over POST /evaluate (e2e/test/fhe.test.ts:105-175).
+ * Unlike the reference's encrypt_uint64/128/256, BigInt values are not squeezed through Number().
+ */
+const path = require('path');
+const native = require('./lfhe_napi.node');
+
+const PARAMS = { Q64: 1, PRIME_BSK: 2 };
+const KEY = { CLIENT: 1, SERVER: 2 };
+const COMPARISONS = new Set(['eq', 'ne', 'ge', 'gt', 'le', 'lt']);
+const WIDTHS = new Set([1, 8, 16, 32, 64, 128, 160, 256]);
+
+function toLE32(value) {
+  let v = BigInt(value);
+  if (v < 0n) throw new RangeError('value must be non-negative');
+  const out = Buffer.alloc(32);
+  for (let i = 0; i < 32; i++) { out[i] = Number(v & 0xffn); v >>= 8n; }
+  if (v !== 0n) throw new RangeError('value does not fit 256 bits');
+  return out;
+}
+
+function fromLE32(buf) {
+  let v = 0n;
+  for (let i = 31; i >= 0; i--) v = (v << 8n) | BigInt(buf[i]);
+  return v;
+}
+
+let opened = false;
+function openLibrary(libPath) {
+  if (opened) return;
+  const p = libPath || process.env.LFHE_LIB || path.join(__dirname, '..', '..', 'fhe_amd', 'liblfhe.so');
+  native.open(p);
+  opened = true;
+}
+
+class NativeEngine {
+  /**
+   * @param {{seed?: Uint8Array, device?: number, params?: number, libPath?: string, keygen?: boolean}} opts
+   */
+  constructor(opts) {
+    const o = opts || {};
+    openLibrary(o.libPath);
+    const seed = o.seed ? Buffer.from(o.seed) : Buffer.alloc(32);
+    if (seed.length !== 32) throw new RangeError('seed must be 32 bytes');
+    this.handle = native.createContext(seed, o.device || 0, o.params || PARAMS.PRIME_BSK);
+    if (o.keygen !== false) native.keygen(this.handle);
+  }
+
+  health() { return JSON.parse(native.health(this.handle)); }
+  publicKey() { return native.publicKey(this.handle); }
+  exportKeys(which) { return native.keysExport(this.handle, which); }
+  importKeys(which, blob) { native.keysImport(this.handle, which, Buffer.from(blob)); }
+
+  encrypt(value, bitWidth) {
+    if (!WIDTHS.has(bitWidth)) throw new Error(`Encryption failed: unsupported bitWidth ${bitWidth}`);
+    const m = (1n << BigInt(bitWidth)) - 1n;
+    return native.encrypt(this.handle, toLE32(BigInt(value) & m), bitWidth, 0);
+  }
+
+  trivialEncrypt(value, bitWidth) {
+    const m = (1n << BigInt(bitWidth)) - 1n;
+    return native.encrypt(this.handle, toLE32(BigInt(value) & m), bitWidth, 1);
+  }
+
+  encryptPublic(publicKey, value, bitWidth) {
+    const m = (1n << BigInt(bitWidth)) - 1n;
+    return native.encryptPublic(this.handle, Buffer.from(publicKey), toLE32(BigInt(value) & m), bitWidth);
+  }
+
+  /** @returns {bigint} */
+  decrypt(ciphertext) { return fromLE32(native.decrypt(this.handle, Buffer.from(ciphertext)).value); }
+
+  /**
+   * right: ciphertext bytes, or a number / bigint / decimal string for a clear operand.
+   * cond: ebool ciphertext, only for op 'select'.
+   */
+  evaluate(op, bitWidth, left, right, cond) {
+    const code = native.opFromName(op);
+    if (code < 0) throw new Error(`unknown operation ${op}`);
+    const scalar = typeof right === 'number' || typeof right === 'bigint' || typeof right === 'string';
+    const rhs = right === undefined || right === null ? null : scalar ? toLE32(right) : Buffer.from(right);
+    return native.evaluate(this.handle, code, bitWidth, Buffer.from(left), rhs, scalar, cond ? Buffer.from(cond) : null);
+  }
+
+  /** n independent instances bootstrapped together; operands are arrays of ciphertexts (or of clear values). */
+  evaluateBatch(op, bitWidth, lefts, rights, conds) {
+    const code = native.opFromName(op);
+    if (code < 0) throw new Error(`unknown operation ${op}`);
+    const n = lefts.length;
+    if (n === 0) return [];
+    const scalar = rights && rights.length && (typeof rights[0] !== 'object');
+    const L = Buffer.concat(lefts.map((b) => Buffer.from(b)));
+    const R = rights ? Buffer.concat(rights.map((r) => (scalar ? toLE32(r) : Buffer.from(r)))) : null;
+    const C = conds ? Buffer.concat(conds.map((b) => Buffer.from(b))) : null;
+    const outBits = COMPARISONS.has(op) ? 1 : bitWidth;
+    const all = native.evaluateBatch(this.handle, code, bitWidth, n, L, R, !!scalar, C, outBits);
+    const sz = all.length / n;
+    const out = [];
+    for (let i = 0; i < n; i++) out.push(all.slice(i * sz, (i + 1) * sz));
+    return out;
+  }
+
+  pbsCount() { return native.pbsCount(this.handle); }
+  close() { if (this.handle) { native.destroy(this.handle); this.handle = null; } }
+}
+
+class LuxFHEClient {
+  /** @param {{engine?: NativeEngine, provider?: any, seed?: Uint8Array, device?: number}} config */
+  constructor(config) {
+    const c = config || {};
+    this.provider = c.provider;
+    this.engine = c.engine || new NativeEngine({ seed: c.seed, device: c.device });
+    this._publicKey = null;
+  }
+
+  async initialize() { await this.getPublicKey(); }
+
+  async getPublicKey() {
+    if (!this._publicKey) this._publicKey = new Uint8Array(this.engine.publicKey());
+    return this._publicKey;
+  }
+
+  async encrypt_uint8(value) { return this.encrypt(value, 8); }
+  async encrypt_uint16(value) { return this.encrypt(value, 16); }
+  async encrypt_uint32(value) { return this.encrypt(value, 32); }
+  async encrypt_uint64(value) { return this.encrypt(value, 64); }
+  async encrypt_uint128(value) { return this.encrypt(value, 128); }
+  async encrypt_uint256(value) { return this.encrypt(value, 256); }
+  async encrypt_address(address) { return this.encrypt(BigInt(address), 160); }
+  async encrypt_bool(value) { return this.encrypt(value ? 1 : 0, 1); }
+
+  async encrypt(value, bitWidth) { return new Uint8Array(this.engine.encrypt(value, bitWidth)); }
+  async decrypt(ciphertext) { return this.engine.decrypt(ciphertext); }
+  async evaluate(op, left, right, bitWidth, cond) {
+    return new Uint8Array(this.engine.evaluate(op, bitWidth, left, right, cond));
+  }
+}
+
+module.exports = { NativeEngine, LuxFHEClient, PARAMS, KEY, toLE32, fromLE32, native };

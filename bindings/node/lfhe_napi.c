@@ -1,0 +1,430 @@
+/*
+ * lfhe_napi.c -- Node N-API addon over the C ABI of liblfhe (include/lfhe.h).
+ *
+ * This is the binding the reference's TypeScript host layer needs to call the GPU backend in
+ * process instead of over HTTP: packages/luxfhejs/src/index.ts:63-141 (getPublicKey, encrypt_*)
+ * and packages/hardhat-plugin/src/index.ts:57-87 (encrypt, decrypt, getPublicKey) map one to one
+ * onto the functions exported here; index.js next to this file wraps them in a class with the
+ * SDK's method names.
+ *
+ * The library is opened with dlopen when the addon is first used, so loading the addon itself
+ * needs neither a GPU nor the library; creating a context without a GPU throws.
+ * Calls are synchronous and a context is single-threaded: run a context on one worker.
+ * Values cross the boundary as 32-byte little-endian buffers (index.js converts BigInt).
+ */
+#define NAPI_VERSION 6
+#include <dlfcn.h>
+#include <node_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/lfhe.h"
+
+/* ---- the C ABI, resolved at run time ---- */
+static void* g_lib;
+#define FN(ret, name, args) static ret(*p_##name) args;
+FN(int32_t, lfhe_ctx_create, (lfhe_ctx**, uint32_t, int32_t, const uint8_t*))
+FN(void, lfhe_ctx_destroy, (lfhe_ctx*))
+FN(const char*, lfhe_last_error, (const lfhe_ctx*))
+FN(const char*, lfhe_version, (void))
+FN(int32_t, lfhe_health, (lfhe_ctx*, char*, uint64_t*))
+FN(int32_t, lfhe_keygen, (lfhe_ctx*))
+FN(int32_t, lfhe_keys_export, (lfhe_ctx*, uint32_t, uint8_t*, uint64_t*))
+FN(int32_t, lfhe_keys_import, (lfhe_ctx*, uint32_t, const uint8_t*, uint64_t))
+FN(int32_t, lfhe_public_key, (lfhe_ctx*, uint8_t*, uint64_t*))
+FN(int32_t, lfhe_encrypt, (lfhe_ctx*, const uint8_t*, uint32_t, uint8_t*, uint64_t*))
+FN(int32_t, lfhe_trivial_encrypt, (lfhe_ctx*, const uint8_t*, uint32_t, uint8_t*, uint64_t*))
+FN(int32_t, lfhe_encrypt_public, (lfhe_ctx*, const uint8_t*, uint64_t, const uint8_t*, uint32_t, uint8_t*, uint64_t*))
+FN(int32_t, lfhe_decrypt, (lfhe_ctx*, const uint8_t*, uint64_t, uint8_t*, uint32_t*))
+FN(int32_t, lfhe_ciphertext_size, (const lfhe_ctx*, uint32_t, uint64_t*))
+FN(int32_t, lfhe_op_from_name, (const char*))
+FN(int32_t, lfhe_evaluate, (lfhe_ctx*, uint32_t, uint32_t, const uint8_t*, uint64_t, const uint8_t*, uint64_t, int32_t,
+                            const uint8_t*, uint64_t, uint8_t*, uint64_t*))
+FN(int32_t, lfhe_evaluate_batch, (lfhe_ctx*, uint32_t, uint32_t, uint64_t, const uint8_t*, const uint8_t*, int32_t,
+                                  const uint8_t*, uint8_t*))
+FN(int32_t, lfhe_pbs_count, (const lfhe_ctx*, uint64_t*))
+#undef FN
+
+static napi_value throw_msg(napi_env env, const char* msg) {
+    napi_throw_error(env, NULL, msg);
+    return NULL;
+}
+
+static int resolve_all(napi_env env, const char* path) {
+    if (g_lib) return 1;
+    g_lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!g_lib) {
+        char buf[768];
+        snprintf(buf, sizeof buf, "cannot load the lfhe library (%s): %s", path, dlerror());
+        throw_msg(env, buf);
+        return 0;
+    }
+#define GET(name)                                               \
+    *(void**)(&p_##name) = dlsym(g_lib, #name);                 \
+    if (!p_##name) {                                            \
+        throw_msg(env, "symbol missing from the library: " #name); \
+        dlclose(g_lib); g_lib = NULL;                           \
+        return 0;                                               \
+    }
+    GET(lfhe_ctx_create) GET(lfhe_ctx_destroy) GET(lfhe_last_error) GET(lfhe_version) GET(lfhe_health)
+    GET(lfhe_keygen) GET(lfhe_keys_export) GET(lfhe_keys_import) GET(lfhe_public_key) GET(lfhe_encrypt)
+    GET(lfhe_trivial_encrypt) GET(lfhe_encrypt_public) GET(lfhe_decrypt) GET(lfhe_ciphertext_size)
+    GET(lfhe_op_from_name) GET(lfhe_evaluate) GET(lfhe_evaluate_batch) GET(lfhe_pbs_count)
+#undef GET
+    return 1;
+}
+
+#define NEED_LIB() if (!g_lib) return throw_msg(env, "call open(path) first")
+
+/* ---- argument helpers ---- */
+static int get_args(napi_env env, napi_callback_info info, size_t want, napi_value* argv) {
+    size_t argc = want;
+    if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok || argc < want) {
+        throw_msg(env, "wrong number of arguments");
+        return 0;
+    }
+    return 1;
+}
+
+static lfhe_ctx* get_ctx(napi_env env, napi_value v) {
+    void* p = NULL;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
+        throw_msg(env, "not a context handle");
+        return NULL;
+    }
+    lfhe_ctx** slot = (lfhe_ctx**)p;
+    if (!*slot) throw_msg(env, "context was destroyed");
+    return *slot;
+}
+
+/* Buffer / Uint8Array -> pointer + length; null/undefined -> (NULL, 0) */
+static int get_bytes(napi_env env, napi_value v, const uint8_t** data, size_t* len) {
+    napi_valuetype t;
+    napi_typeof(env, v, &t);
+    if (t == napi_null || t == napi_undefined) { *data = NULL; *len = 0; return 1; }
+    bool is_buf = false, is_ta = false;
+    napi_is_buffer(env, v, &is_buf);
+    if (is_buf) {
+        void* p;
+        napi_get_buffer_info(env, v, &p, len);
+        *data = (const uint8_t*)p;
+        return 1;
+    }
+    napi_is_typedarray(env, v, &is_ta);
+    if (is_ta) {
+        napi_typedarray_type tt;
+        void* p;
+        napi_value ab;
+        size_t off;
+        napi_get_typedarray_info(env, v, &tt, len, &p, &ab, &off);
+        if (tt == napi_uint8_array) { *data = (const uint8_t*)p; return 1; }
+    }
+    throw_msg(env, "expected a Buffer or Uint8Array");
+    return 0;
+}
+
+static napi_value fail(napi_env env, lfhe_ctx* c, int32_t rc, const char* what) {
+    char buf[640];
+    snprintf(buf, sizeof buf, "%s failed (%d): %s", what, rc, c ? p_lfhe_last_error(c) : "no context");
+    return throw_msg(env, buf);
+}
+
+static napi_value make_buffer(napi_env env, const uint8_t* src, size_t len) {
+    napi_value out;
+    void* dst;
+    if (napi_create_buffer_copy(env, len, src, &dst, &out) != napi_ok) return throw_msg(env, "out of memory");
+    return out;
+}
+
+static void finalize_ctx(napi_env env, void* data, void* hint) {
+    (void)env; (void)hint;
+    lfhe_ctx** slot = (lfhe_ctx**)data;
+    if (*slot && p_lfhe_ctx_destroy) p_lfhe_ctx_destroy(*slot);
+    free(slot);
+}
+
+/* ---- exported functions ---- */
+static napi_value js_open(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    char path[512];
+    size_t n;
+    if (napi_get_value_string_utf8(env, argv[0], path, sizeof path, &n) != napi_ok) return throw_msg(env, "path expected");
+    if (!resolve_all(env, path)) return NULL;
+    napi_value v;
+    napi_create_string_utf8(env, p_lfhe_version(), NAPI_AUTO_LENGTH, &v);
+    return v;
+}
+
+static napi_value js_create(napi_env env, napi_callback_info info) {
+    NEED_LIB();
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return NULL;
+    const uint8_t* seed; size_t slen;
+    if (!get_bytes(env, argv[0], &seed, &slen)) return NULL;
+    if (slen != 32) return throw_msg(env, "seed must be 32 bytes");
+    int32_t device; uint32_t params;
+    napi_get_value_int32(env, argv[1], &device);
+    napi_get_value_uint32(env, argv[2], &params);
+    lfhe_ctx* c = NULL;
+    const int32_t rc = p_lfhe_ctx_create(&c, params, device, seed);
+    if (rc != LFHE_OK) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "lfhe_ctx_create failed (%d): no usable GPU or unsupported parameters", rc);
+        return throw_msg(env, buf);
+    }
+    lfhe_ctx** slot = (lfhe_ctx**)malloc(sizeof *slot);
+    *slot = c;
+    napi_value ext;
+    napi_create_external(env, slot, finalize_ctx, NULL, &ext);
+    return ext;
+}
+
+static napi_value js_destroy(napi_env env, napi_callback_info info) {
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    void* p = NULL;
+    if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
+        lfhe_ctx** slot = (lfhe_ctx**)p;
+        if (*slot) { p_lfhe_ctx_destroy(*slot); *slot = NULL; }
+    }
+    return NULL;
+}
+
+static napi_value js_keygen(napi_env env, napi_callback_info info) {
+    NEED_LIB();
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    lfhe_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return NULL;
+    const int32_t rc = p_lfhe_keygen(c);
+    if (rc != LFHE_OK) return fail(env, c, rc, "lfhe_keygen");
+    return NULL;
+}
+
+static napi_value js_health(napi_env env, napi_callback_info info) {
+    NEED_LIB();
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    lfhe_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return NULL;
+    char buf[512];
+    uint64_t n = sizeof buf;
+    const int32_t rc = p_lfhe_health(c, buf, &n);
+    if (rc != LFHE_OK) return fail(env, c, rc, "lfhe_health");
+    napi_value v;
+    napi_create_string_utf8(env, buf, NAPI_AUTO_LENGTH, &v);
+    return v;
+}
+
+/* size-query pattern shared by the blob getters */
+typedef int32_t (*blob_fn)(lfhe_ctx*, uint32_t, uint8_t*, uint64_t*);
+static napi_value blob_out(napi_env env, lfhe_ctx* c, blob_fn fn, uint32_t which, const char* what) {
+    uint64_t n = 0;
+    int32_t rc = fn(c, which, NULL, &n);
+    if (rc != LFHE_OK) return fail(env, c, rc, what);
+    uint8_t* tmp = (uint8_t*)malloc(n ? n : 1);
+    rc = fn(c, which, tmp, &n);
+    napi_value out = rc == LFHE_OK ? make_buffer(env, tmp, n) : fail(env, c, rc, what);
+    free(tmp);
+    return out;
+}
+static int32_t pk_adapter(lfhe_ctx* c, uint32_t which, uint8_t* out, uint64_t* n) { (void)which; return p_lfhe_public_key(c, out, n); }
+
+static napi_value js_public_key(napi_env env, napi_callback_info info) {
+    NEED_LIB();
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    lfhe_ctx* c = get_ctx(env, argv[0]);
+    return c ? blob_out(env, c, pk_adapter, 0, "lfhe_public_key") : NULL;
+}
+
+static napi_value js_keys_export(napi_env env, napi_callback_info info) {
+    NEED_LIB();
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return NULL;
+    lfhe_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return NULL;
+    uint32_t which;
+    napi_get_value_uint32(env, argv[1], &which);
+    return blob_out(env, c, p_lfhe_keys_export, which, "lfhe_keys_export");
+}
+
+static napi_value js_keys_import(napi_env env, napi_callback_info info) {
+    NEED_LIB();
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return NULL;
+    lfhe_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return NULL;
+    uint32_t which;
+    napi_get_value_uint32(env, argv[1], &which);
+    const uint8_t* d; size_t n;
+    if (!get_bytes(env, argv[2], &d, &n)) return NULL;
+    const int32_t rc = p_lfhe_keys_import(c, which, d, n);
+    if (rc != LFHE_OK) return fail(env, c, rc, "lfhe_keys_import");
+    return NULL;
+}
+
+/* encrypt(ctx, valueLE32, bits, mode) mode: 0 secret key, 1 trivial */
+static napi_value js_encrypt(napi_env env, napi_callback_info info) {
+    NEED_LIB();
+    napi_value argv[4];
+    if (!get_args(env, info, 4, argv)) return NULL;
+    lfhe_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return NULL;
+    const uint8_t* v; size_t vl;
+    if (!get_bytes(env, argv[1], &v, &vl)) return NULL;
+    if (vl != 32) return throw_msg(env, "value must be 32 little-endian bytes");
+    uint32_t bits, mode;
+    napi_get_value_uint32(env, argv[2], &bits);
+    napi_get_value_uint32(env, argv[3], &mode);
+    uint64_t n = 0;
+    int32_t rc = p_lfhe_ciphertext_size(c, bits, &n);
+    if (rc != LFHE_OK) return throw_msg(env, "Encryption failed: unsupported bit width");
+    uint8_t* tmp = (uint8_t*)malloc(n);
+    rc = mode ? p_lfhe_trivial_encrypt(c, v, bits, tmp, &n) : p_lfhe_encrypt(c, v, bits, tmp, &n);
+    napi_value out = rc == LFHE_OK ? make_buffer(env, tmp, n) : fail(env, c, rc, "Encryption");
+    free(tmp);
+    return out;
+}
+
+static napi_value js_encrypt_public(napi_env env, napi_callback_info info) {
+    NEED_LIB();
+    napi_value argv[4];
+    if (!get_args(env, info, 4, argv)) return NULL;
+    lfhe_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return NULL;
+    const uint8_t *pk, *v; size_t pl, vl;
+    if (!get_bytes(env, argv[1], &pk, &pl) || !get_bytes(env, argv[2], &v, &vl)) return NULL;
+    if (vl != 32) return throw_msg(env, "value must be 32 little-endian bytes");
+    uint32_t bits;
+    napi_get_value_uint32(env, argv[3], &bits);
+    uint64_t n = 0;
+    if (p_lfhe_ciphertext_size(c, bits, &n) != LFHE_OK) return throw_msg(env, "Encryption failed: unsupported bit width");
+    uint8_t* tmp = (uint8_t*)malloc(n);
+    const int32_t rc = p_lfhe_encrypt_public(c, pk, pl, v, bits, tmp, &n);
+    napi_value out = rc == LFHE_OK ? make_buffer(env, tmp, n) : fail(env, c, rc, "Encryption");
+    free(tmp);
+    return out;
+}
+
+/* decrypt(ctx, ct) -> {value: Buffer(32) little-endian, bitWidth} */
+static napi_value js_decrypt(napi_env env, napi_callback_info info) {
+    NEED_LIB();
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return NULL;
+    lfhe_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return NULL;
+    const uint8_t* ct; size_t n;
+    if (!get_bytes(env, argv[1], &ct, &n)) return NULL;
+    uint8_t val[32];
+    uint32_t bits = 0;
+    const int32_t rc = p_lfhe_decrypt(c, ct, n, val, &bits);
+    if (rc != LFHE_OK) return fail(env, c, rc, "Decryption");
+    napi_value obj, b, w;
+    napi_create_object(env, &obj);
+    b = make_buffer(env, val, 32);
+    napi_create_uint32(env, bits, &w);
+    napi_set_named_property(env, obj, "value", b);
+    napi_set_named_property(env, obj, "bitWidth", w);
+    return obj;
+}
+
+static napi_value js_op_from_name(napi_env env, napi_callback_info info) {
+    NEED_LIB();
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    char name[32];
+    size_t n;
+    if (napi_get_value_string_utf8(env, argv[0], name, sizeof name, &n) != napi_ok) return throw_msg(env, "name expected");
+    napi_value v;
+    napi_create_int32(env, p_lfhe_op_from_name(name), &v);
+    return v;
+}
+
+/* evaluate(ctx, op, bits, lhs, rhs|null, rhsIsScalar, cond|null) -> Buffer */
+static napi_value js_evaluate(napi_env env, napi_callback_info info) {
+    NEED_LIB();
+    napi_value argv[7];
+    if (!get_args(env, info, 7, argv)) return NULL;
+    lfhe_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return NULL;
+    uint32_t op, bits;
+    napi_get_value_uint32(env, argv[1], &op);
+    napi_get_value_uint32(env, argv[2], &bits);
+    const uint8_t *l, *r, *cd; size_t ll, rl, cl;
+    if (!get_bytes(env, argv[3], &l, &ll) || !get_bytes(env, argv[4], &r, &rl) || !get_bytes(env, argv[6], &cd, &cl)) return NULL;
+    bool scalar = false;
+    napi_get_value_bool(env, argv[5], &scalar);
+    uint64_t n = 0;
+    int32_t rc = p_lfhe_evaluate(c, op, bits, l, ll, r, rl, scalar, cd, cl, NULL, &n);
+    if (rc != LFHE_OK) return fail(env, c, rc, "Evaluation");
+    uint8_t* tmp = (uint8_t*)malloc(n);
+    rc = p_lfhe_evaluate(c, op, bits, l, ll, r, rl, scalar, cd, cl, tmp, &n);
+    napi_value out = rc == LFHE_OK ? make_buffer(env, tmp, n) : fail(env, c, rc, "Evaluation");
+    free(tmp);
+    return out;
+}
+
+/* evaluateBatch(ctx, op, bits, count, lhsAll, rhsAll|null, rhsIsScalar, condAll|null, outBits) -> Buffer (count results) */
+static napi_value js_evaluate_batch(napi_env env, napi_callback_info info) {
+    NEED_LIB();
+    napi_value argv[9];
+    if (!get_args(env, info, 9, argv)) return NULL;
+    lfhe_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return NULL;
+    uint32_t op, bits, count, out_bits;
+    napi_get_value_uint32(env, argv[1], &op);
+    napi_get_value_uint32(env, argv[2], &bits);
+    napi_get_value_uint32(env, argv[3], &count);
+    napi_get_value_uint32(env, argv[8], &out_bits);
+    const uint8_t *l, *r, *cd; size_t ll, rl, cl;
+    if (!get_bytes(env, argv[4], &l, &ll) || !get_bytes(env, argv[5], &r, &rl) || !get_bytes(env, argv[7], &cd, &cl)) return NULL;
+    bool scalar = false;
+    napi_get_value_bool(env, argv[6], &scalar);
+    uint64_t in_sz = 0, out_sz = 0, rhs_sz = 0, cond_sz = 0;
+    if (p_lfhe_ciphertext_size(c, bits, &in_sz) != LFHE_OK || p_lfhe_ciphertext_size(c, out_bits, &out_sz) != LFHE_OK)
+        return throw_msg(env, "unsupported bit width");
+    p_lfhe_ciphertext_size(c, 1, &cond_sz);
+    const int shift = op >= LFHE_OP_SHL && op <= LFHE_OP_ROTR;
+    if (shift) p_lfhe_ciphertext_size(c, 8, &rhs_sz); else rhs_sz = in_sz;
+    if (ll != (size_t)count * in_sz || (r && rl != (size_t)count * (scalar ? 32 : rhs_sz)) || (cd && cl != (size_t)count * cond_sz))
+        return throw_msg(env, "operand arrays do not hold `count` ciphertexts of the stated width");
+    uint8_t* tmp = (uint8_t*)malloc((size_t)count * out_sz + 1);
+    const int32_t rc = p_lfhe_evaluate_batch(c, op, bits, count, l, r, scalar, cd, tmp);
+    napi_value out = rc == LFHE_OK ? make_buffer(env, tmp, (size_t)count * out_sz) : fail(env, c, rc, "Evaluation");
+    free(tmp);
+    return out;
+}
+
+static napi_value js_pbs_count(napi_env env, napi_callback_info info) {
+    NEED_LIB();
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    lfhe_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return NULL;
+    uint64_t n = 0;
+    p_lfhe_pbs_count(c, &n);
+    napi_value v;
+    napi_create_double(env, (double)n, &v);
+    return v;
+}
+
+static napi_value init(napi_env env, napi_value exports) {
+    static const struct { const char* name; napi_callback fn; } tab[] = {
+        {"open", js_open}, {"createContext", js_create}, {"destroy", js_destroy}, {"keygen", js_keygen},
+        {"health", js_health}, {"publicKey", js_public_key}, {"keysExport", js_keys_export},
+        {"keysImport", js_keys_import}, {"encrypt", js_encrypt}, {"encryptPublic", js_encrypt_public},
+        {"decrypt", js_decrypt}, {"opFromName", js_op_from_name}, {"evaluate", js_evaluate},
+        {"evaluateBatch", js_evaluate_batch}, {"pbsCount", js_pbs_count}};
+    for (size_t i = 0; i < sizeof tab / sizeof tab[0]; ++i) {
+        napi_value f;
+        napi_create_function(env, tab[i].name, NAPI_AUTO_LENGTH, tab[i].fn, NULL, &f);
+        napi_set_named_property(env, exports, tab[i].name, f);
+    }
+    return exports;
+}
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, init)

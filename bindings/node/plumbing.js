@@ -1,0 +1,32 @@
+'use strict';
+// The reference's plumbing case through the in-process binding (e2e/test/fhe.test.ts:88-175,
+// local-dev/demo.ts:44-81): 42 and 17 as euint8 -> add / sub / lt / eq -> decrypt.
+// Prints one JSON line; exits non-zero on any mismatch.  Needs a GPU.
+const { LuxFHEClient, NativeEngine } = require('./index.js');
+
+(async () => {
+  const engine = new NativeEngine({ seed: Buffer.from(Array.from({ length: 32 }, (_, i) => (5 * i + 1) & 0xff)) });
+  const sdk = new LuxFHEClient({ engine });
+  await sdk.initialize();
+  const a = await sdk.encrypt_uint8(42);
+  const b = await sdk.encrypt_uint8(17);
+  const res = {
+    health: engine.health().status,
+    publicKeyBytes: (await sdk.getPublicKey()).length,
+    add: String(await sdk.decrypt(await sdk.evaluate('add', a, b, 8))),
+    sub: String(await sdk.decrypt(await sdk.evaluate('sub', a, b, 8))),
+    lt: String(await sdk.decrypt(await sdk.evaluate('lt', a, b, 8))),
+    eq: String(await sdk.decrypt(await sdk.evaluate('eq', a, await sdk.encrypt_uint8(42), 8))),
+    addScalar: String(await sdk.decrypt(await sdk.evaluate('add', a, 200, 8))),
+    shl: String(await sdk.decrypt(await sdk.evaluate('shl', a, 3, 8))),
+    mul64: String(await sdk.decrypt(await sdk.evaluate('mul', await sdk.encrypt_uint64(4293652672n), await sdk.encrypt_uint64(4293367238n), 64))),
+    batch: engine.evaluateBatch('gt', 8, [a, b], [b, a]).map((c) => String(engine.decrypt(c))),
+    pbs: engine.pbsCount(),
+  };
+  console.log(JSON.stringify(res));
+  const ok = res.health === 'ok' && res.add === '59' && res.sub === '25' && res.lt === '0' && res.eq === '1' &&
+    res.addScalar === '242' && res.shl === String((42 << 3) & 255) && res.mul64 === '18434227713315959936' &&
+    res.batch[0] === '1' && res.batch[1] === '0';
+  engine.close();
+  process.exit(ok ? 0 : 1);
+})().catch((e) => { console.error(e.message); process.exit(2); });

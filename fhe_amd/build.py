@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "liblfhe.so")
 SOURCES = ["kernels.hip", "engine.cpp", "host_tfhe.cpp", "api.cpp", "radix.cpp", "radix_program.cpp"]
-HEADERS = ["pbs_device.h", "pbs_phases.h", "tables.h", "engine.h", "host_tfhe.h", "ctx.h", "radix_program.h",
+HEADERS = ["pbs_device.h", "pbs_phases.h", "ms_noise.h", "tables.h", "engine.h", "host_tfhe.h", "ctx.h", "radix_program.h",
            os.path.join("..", "..", "include", "lfhe.h")]
 
 
@@ -35,5 +35,24 @@ def build(force: bool = False, verbose: bool = False, out: str = OUT, defines: t
     return out
 
 
+NODE_DIR = os.path.join(os.path.dirname(HERE), "bindings", "node")
+
+
+def build_node_addon(verbose: bool = False) -> str | None:
+    """The N-API addon over the C ABI (bindings/node/lfhe_napi.node), plain C against the Node
+    headers of the image.  Returns None when the headers are absent."""
+    inc = os.environ.get("NODE_INCLUDE", "/usr/include/node")
+    if not os.path.exists(os.path.join(inc, "node_api.h")):
+        return None
+    out = os.path.join(NODE_DIR, "lfhe_napi.node")
+    cmd = [os.environ.get("CC", "gcc"), "-O2", "-fPIC", "-shared", "-Wall", "-Wextra", f"-I{inc}",
+           "-DNODE_GYP_MODULE_NAME=lfhe_napi", "-o", out, os.path.join(NODE_DIR, "lfhe_napi.c"), "-ldl"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_node_addon(verbose=True))

@@ -63,7 +63,6 @@ Engine::~Engine() {
     (void)hipFree(d_tw_);
     (void)hipFree(d_small_);
     (void)hipFree(d_ksdig_);
-    (void)hipFree(d_acc_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -157,18 +156,6 @@ u64* Engine::small_scratch(size_t count) {
     return d_small_;
 }
 
-u64* Engine::acc_scratch(size_t count) {
-    if (count > acc_cap_) {
-        HC(hipSetDevice(device_));
-        HC(hipStreamSynchronize(stream_));
-        (void)hipFree(d_acc_);
-        d_acc_ = nullptr;
-        HC(hipMalloc(&d_acc_, count * 2 * N * sizeof(u64)));
-        acc_cap_ = count;
-    }
-    return d_acc_;
-}
-
 void Engine::keyswitch(const u64* lwe_in, u64* lwe_small_out, size_t count, const BlockMap& imap) {
     if (!d_ksk_) throw std::runtime_error("no key-switching key loaded");
     if (!count) return;
@@ -209,13 +196,12 @@ void Engine::blind_rotate(const u64* lwe_small, const u64* luts, const u32* lut_
     if (!d_bsk_) throw std::runtime_error("no bootstrapping key loaded");
     if (!count) return;
     HC(hipSetDevice(device_));
-    u64* ws = acc_scratch(count);
     if (single_modulus())
-        launch_blind_rotate_q(T_, d_bsk_, lwe_small, (int)prm_.lwe_dim, luts, lut_index, reinterpret_cast<double*>(ws),
-                              glwe_out, lwe_out, count, omap, 1.0 / (double)qp_gadget(), wide_below_, stream_);
+        launch_blind_rotate_q(T_, d_bsk_, lwe_small, (int)prm_.lwe_dim, luts, lut_index, glwe_out, lwe_out, count, omap,
+                              1.0 / (double)qp_gadget(), wide_below_, stream_);
     else
-        launch_blind_rotate(T_, d_bsk_, lwe_small, (int)prm_.lwe_dim, luts, lut_index, ws, glwe_out, lwe_out, count,
-                            omap, stream_);
+        launch_blind_rotate(T_, d_bsk_, lwe_small, (int)prm_.lwe_dim, luts, lut_index, glwe_out, lwe_out, count, omap,
+                            stream_);
     HC(hipGetLastError());
 }
 

@@ -47,13 +47,13 @@ void launch_ntt_inverse(const Tables& T, const double* in, u64* out, size_t poly
 void launch_external_product(const Tables& T, const double* bsk, const u32* idx, const u64* glwe, u64* out,
                              size_t count, hipStream_t st);
 void launch_blind_rotate(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
-                         const u32* lut_index, u64* acc_ws, u64* glwe_out, u64* lwe_out, size_t count,
+                         const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
                          const BlockMap& omap, hipStream_t st);
 void launch_bskq_prepare(const Tables& T, const u64* in, double* out, size_t polys, hipStream_t st);
 void launch_external_product_q(const Tables& T, const double* bsk, const u32* idx, const u64* glwe, u64* out,
                                size_t count, double inv_g, hipStream_t st);
 void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
-                           const u32* lut_index, double* acc_ws, u64* glwe_out, u64* lwe_out, size_t count,
+                           const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
                            const BlockMap& omap, double inv_g, int wide_below, hipStream_t st);
 void launch_lin_batch(u64* arena, const LinOp* ops, int nops, size_t instances, size_t inst_stride_blocks, u64 delta,
                       hipStream_t st);
@@ -122,10 +122,8 @@ public:
     void ntt_inverse(const double* in, u64* out, size_t count);
     void sync();
 
-    // scratch owned by the engine (grow-only): the small-LWE intermediate of pbs_batch and the
-    // accumulator workspace of the blind rotation (2N words per ciphertext)
+    // scratch owned by the engine (grow-only): the small-LWE intermediate of pbs_batch
     u64* small_scratch(size_t count);
-    u64* acc_scratch(size_t count);
 
 private:
     int device_;
@@ -140,8 +138,6 @@ private:
     size_t small_cap_ = 0;
     u32* d_ksdig_ = nullptr;   // packed key-switch digits of the launch in flight
     size_t ksdig_cap_ = 0;
-    u64* d_acc_ = nullptr;
-    size_t acc_cap_ = 0;
     MsParams ms_{};
     int cu_count_ = 256;
     int wide_below_ = -1;   // launches of at most this many ciphertexts use 512 threads each

@@ -163,14 +163,12 @@ __global__ void __launch_bounds__(NT, LFHE_BR_WAVES) k_blind_rotate(Tables T, co
                                                         const u64* __restrict__ lwe_small, int n,
                                                         const u64* __restrict__ luts,
                                                         const u32* __restrict__ lut_index,
-                                                        u64* __restrict__ acc_ws,
                                                         u64* __restrict__ glwe_out,
                                                         u64* __restrict__ lwe_out, BlockMap omap) {
     const unsigned t = threadIdx.x;
     const size_t ct = blockIdx.x;
     const u64* __restrict__ lwe = lwe_small + ct * (size_t)(n + 1);
     const u64* __restrict__ lut = luts + (size_t)(lut_index ? lut_index[omap.ops ? ct % omap.ops : ct] : 0) * N;
-    u64* ws = acc_ws + ct * (size_t)(2 * N);
 
     // The accumulator never leaves the CU: every thread keeps its own 16 coefficients in registers
     // (pass-1 ownership) and publishes them between steps in the LDS exchange buffer, which serves
@@ -219,25 +217,19 @@ __global__ void __launch_bounds__(NT, LFHE_BR_WAVES) k_blind_rotate(Tables T, co
             }
         __syncthreads();  // the new accumulator is visible to the whole workgroup before the next step
     }
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int j = 0; j < E; ++j) ws[q * N + own1(t, j)] = acc[q][j];
-    __syncthreads();
-
     if (glwe_out) {
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int j = 0; j < E; ++j) glwe_out[(ct * 2 + q) * N + own1(t, j)] = ws[q * N + own1(t, j)];
+            for (int j = 0; j < E; ++j) glwe_out[(ct * 2 + q) * N + own1(t, j)] = acc[q][j];
     }
-    if (lwe_out) {  // sample extraction of coefficient 0
+    if (lwe_out) {  // sample extraction of coefficient 0: every thread places its own coefficients
         u64* o = lwe_out + omap.block(ct) * (size_t)(N + 1);
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             const unsigned e = own1(t, j);
-            if (e == 0) { o[0] = ws[0]; o[N] = ws[N]; }
-            else o[N - e] = (u64)0 - ws[e];
+            if (e == 0) { o[0] = acc[0][j]; o[N] = acc[1][j]; }
+            else o[N - e] = (u64)0 - acc[0][j];
         }
     }
 }
@@ -328,7 +320,6 @@ __global__ void __launch_bounds__(NT, LFHE_BRQ_WAVES) k_blind_rotate_q(Tables T,
                                                                        const u64* __restrict__ lwe_small, int n,
                                                                        const u64* __restrict__ luts,
                                                                        const u32* __restrict__ lut_index,
-                                                                       double* __restrict__ acc_ws,
                                                                        u64* __restrict__ glwe_out,
                                                                        u64* __restrict__ lwe_out, BlockMap omap,
                                                                        double inv_g) {
@@ -337,7 +328,6 @@ __global__ void __launch_bounds__(NT, LFHE_BRQ_WAVES) k_blind_rotate_q(Tables T,
     const Prime P = T.pr[0];
     const u64* __restrict__ lwe = lwe_small + ct * (size_t)(n + 1);
     const u64* __restrict__ lut = luts + (size_t)(lut_index ? lut_index[omap.ops ? ct % omap.ops : ct] : 0) * N;
-    double* ws = acc_ws + ct * (size_t)(2 * N);
 
     // The accumulator never leaves the CU: every thread keeps its own 16 coefficients in registers
     // (pass-1 ownership) and publishes them between steps in the LDS exchange buffer, which serves
@@ -394,18 +384,12 @@ __global__ void __launch_bounds__(NT, LFHE_BRQ_WAVES) k_blind_rotate_q(Tables T,
             }
         __syncthreads();  // the new accumulator is visible to the whole workgroup before the next step
     }
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int j = 0; j < E; ++j) ws[q * N + own1(t, j)] = acc[q][j];
-    __syncthreads();
-
     if (glwe_out) {
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int j = 0; j < E; ++j) {
-                const double c = ws[q * N + own1(t, j)];
+                const double c = acc[q][j];
                 glwe_out[(ct * 2 + q) * N + own1(t, j)] = c < 0 ? QP_U - (u64)(-c) : (u64)c;
             }
     }
@@ -414,8 +398,8 @@ __global__ void __launch_bounds__(NT, LFHE_BRQ_WAVES) k_blind_rotate_q(Tables T,
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             const unsigned e = own1(t, j);
-            if (e == 0) { o[0] = qp_to_torus(ws[0]); o[N] = qp_to_torus(ws[N]); }
-            else o[N - e] = qp_to_torus(-ws[e]);
+            if (e == 0) { o[0] = qp_to_torus(acc[0][j]); o[N] = qp_to_torus(acc[1][j]); }
+            else o[N - e] = qp_to_torus(-acc[0][j]);
         }
     }
 }
@@ -432,7 +416,6 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q_wide(Tables T, con
                                                                    const u64* __restrict__ lwe_small, int n,
                                                                    const u64* __restrict__ luts,
                                                                    const u32* __restrict__ lut_index,
-                                                                   double* __restrict__ acc_ws,
                                                                    u64* __restrict__ glwe_out,
                                                                    u64* __restrict__ lwe_out, BlockMap omap,
                                                                    double inv_g) {
@@ -533,12 +516,12 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q_wide(Tables T, con
         __syncthreads();
     }
 
-    double* ws = acc_ws + ct * (size_t)(2 * N) + h * N;
+    if (glwe_out) {
 #pragma unroll
-    for (int j = 0; j < E; ++j) {
-        const double c = acc[j];
-        if (glwe_out) glwe_out[(ct * 2 + h) * N + own1(t0, j)] = c < 0 ? QP_U - (u64)(-c) : (u64)c;
-        ws[own1(t0, j)] = c;
+        for (int j = 0; j < E; ++j) {
+            const double c = acc[j];
+            glwe_out[(ct * 2 + h) * N + own1(t0, j)] = c < 0 ? QP_U - (u64)(-c) : (u64)c;
+        }
     }
     if (lwe_out) {  // sample extraction of coefficient 0, every word switched back to 2^64
         u64* o = lwe_out + omap.block(ct) * (size_t)(N + 1);
@@ -560,15 +543,15 @@ void launch_external_product_q(const Tables& T, const double* bsk, const u32* id
                        inv_g);
 }
 void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
-                           const u32* lut_index, double* acc_ws, u64* glwe_out, u64* lwe_out, size_t count,
+                           const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
                            const BlockMap& omap, double inv_g, int wide_below, hipStream_t st) {
     // up to two ciphertexts per CU: latency matters more than throughput, use 512 threads each
     if (count <= (size_t)wide_below)
         hipLaunchKernelGGL(k_blind_rotate_q_wide, dim3((unsigned)count), dim3(2 * NT), LDS_BYTES, st, T, bsk, lwe_small,
-                           n, luts, lut_index, acc_ws, glwe_out, lwe_out, omap, inv_g);
+                           n, luts, lut_index, glwe_out, lwe_out, omap, inv_g);
     else
         hipLaunchKernelGGL(k_blind_rotate_q, dim3((unsigned)count), dim3(NT), LDS_BYTES, st, T, bsk, lwe_small, n, luts,
-                           lut_index, acc_ws, glwe_out, lwe_out, omap, inv_g);
+                           lut_index, glwe_out, lwe_out, omap, inv_g);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -722,10 +705,10 @@ void launch_external_product(const Tables& T, const double* bsk, const u32* idx,
     hipLaunchKernelGGL(k_external_product, dim3((unsigned)count), dim3(NT), LDS_BYTES, st, T, bsk, idx, glwe, out);
 }
 void launch_blind_rotate(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
-                         const u32* lut_index, u64* acc_ws, u64* glwe_out, u64* lwe_out, size_t count,
+                         const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
                          const BlockMap& omap, hipStream_t st) {
     hipLaunchKernelGGL(k_blind_rotate, dim3((unsigned)count), dim3(NT), LDS_BYTES, st, T, bsk, lwe_small, n, luts,
-                       lut_index, acc_ws, glwe_out, lwe_out, omap);
+                       lut_index, glwe_out, lwe_out, omap);
 }
 void launch_ksk_colsum(const u64* ksk, int rows, int cols, int half_base, u64* colsum, hipStream_t st) {
     hipLaunchKernelGGL(k_ksk_colsum, dim3((cols + 255) / 256), dim3(256), 0, st, ksk, rows, cols, half_base, colsum);

@@ -1,0 +1,56 @@
+"""The Node N-API binding over the C ABI (bindings/node): the host-language side the reference's
+TypeScript SDK would call in process.  Runs first in the suite: its GPU case starts `node` as a
+child process, which must happen before this process has touched the GPU."""
+import json
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NODE_DIR = os.path.join(ROOT, "bindings", "node")
+ADDON = os.path.join(NODE_DIR, "lfhe_napi.node")
+
+needs_node = pytest.mark.skipif(shutil.which("node") is None or not os.path.exists(ADDON),
+                                reason="node or the built addon is missing")
+
+
+@needs_node
+def test_addon_loads_and_exports_the_engine_calls():
+    js = ("const m=require('./index.js');"
+          "console.log(JSON.stringify({fns:Object.keys(m.native).sort(),"
+          "sdk:Object.getOwnPropertyNames(m.LuxFHEClient.prototype).sort(),"
+          "rt:m.fromLE32(m.toLE32(18434227713315959936n)).toString()}))")
+    out = subprocess.run(["node", "-e", js], cwd=NODE_DIR, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    d = json.loads(out.stdout)
+    for fn in ("open", "createContext", "keygen", "publicKey", "encrypt", "decrypt", "evaluate", "evaluateBatch"):
+        assert fn in d["fns"]
+    # the reference SDK's method names (packages/luxfhejs/src/index.ts:56-122)
+    for m in ("initialize", "getPublicKey", "encrypt_uint8", "encrypt_uint16", "encrypt_uint32", "encrypt_uint64",
+              "encrypt_uint128", "encrypt_uint256", "encrypt_address"):
+        assert m in d["sdk"]
+    assert d["rt"] == "18434227713315959936"
+
+
+@needs_node
+def test_context_creation_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    js = "const m=require('./index.js'); try{new m.NativeEngine({});process.exit(3)}catch(e){console.log(e.message)}"
+    out = subprocess.run(["node", "-e", js], cwd=NODE_DIR, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "lfhe_ctx_create failed" in out.stdout
+
+
+@pytest.mark.gpu
+@needs_node
+def test_plumbing_case_through_node():
+    """42 and 17 as euint8 -> add/sub/lt/eq, a clear operand, a shift, the reference's euint64
+    product vector (fhevmOperations6.ts:647-660) and a batch, all from JavaScript."""
+    out = subprocess.run(["node", "plumbing.js"], cwd=NODE_DIR, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["add"] == "59" and d["sub"] == "25" and d["lt"] == "0" and d["eq"] == "1"
+    assert d["mul64"] == "18434227713315959936" and d["batch"] == ["1", "0"]
