@@ -1,0 +1,175 @@
+"""Event-driven operator boundary: the fhevm executor emits one event per operation with bytes32
+handles (tests/fhevm-suite/e2e/test/utils.ts:182-214); a coprocessor worker resolves the handles to
+ciphertexts, runs the operations and stores the results under the result handles.
+
+What this adds over calling the engine once per event: the events of a block are sorted into waves
+by data dependence, and within a wave all events of one (operation, type, scalar-ness) become ONE
+`evaluate_batch` call, so every bootstrap layer of that operation is one GPU launch for the lot.
+
+The type of a ciphertext is byte 30 of its handle (utils.ts:283-285, FhevmHandle.ts:213).
+VerifyCiphertext (input proofs) is outside this backend.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+# FheType ids (sdk/relayer/src/sdk/FheType.ts:17-27; tests/fhevm-suite/e2e/test/types.ts)
+TYPE_WIDTH = {0: 1, 2: 8, 3: 16, 4: 32, 5: 64, 6: 128, 7: 160, 8: 256}
+
+BINARY = {"FheAdd": "add", "FheSub": "sub", "FheMul": "mul", "FheDiv": "div", "FheRem": "rem",
+          "FheBitAnd": "and", "FheBitOr": "or", "FheBitXor": "xor", "FheShl": "shl", "FheShr": "shr",
+          "FheRotl": "rotl", "FheRotr": "rotr", "FheEq": "eq", "FheNe": "ne", "FheGe": "ge", "FheGt": "gt",
+          "FheLe": "le", "FheLt": "lt", "FheMin": "min", "FheMax": "max",
+          "FheEqBytes": "eq", "FheNeBytes": "ne"}
+UNARY = {"FheNeg": "neg", "FheNot": "not"}
+
+
+def handle_type(handle: bytes) -> int:
+    if len(handle) != 32:
+        raise ValueError("a handle is 32 bytes")
+    return handle[30]
+
+
+def handle_width(handle: bytes) -> int:
+    t = handle_type(handle)
+    if t not in TYPE_WIDTH:
+        raise ValueError(f"unsupported FheType {t}")
+    return TYPE_WIDTH[t]
+
+
+@dataclass
+class Event:
+    """One executor event: `name` as in the ABI, `args` by the ABI's argument names
+    (lhs, rhs, scalarByte, result, ct, toType, pt, control, ifTrue, ifFalse, randType, seed, upperBound)."""
+    name: str
+    args: dict = field(default_factory=dict)
+
+    def inputs(self) -> list:
+        a = self.args
+        if self.name in BINARY:
+            return [a["lhs"]] if _is_scalar(a) else [a["lhs"], a["rhs"]]
+        if self.name in UNARY or self.name == "Cast":
+            return [a["ct"]]
+        if self.name == "FheIfThenElse":
+            return [a["control"], a["ifTrue"], a["ifFalse"]]
+        return []
+
+
+def _is_scalar(a: dict) -> bool:
+    sb = a.get("scalarByte", b"\x00")
+    return (sb if isinstance(sb, int) else sb[0]) == 1
+
+
+def _clear(v) -> int:
+    return v if isinstance(v, int) else int.from_bytes(v, "big")
+
+
+class Coprocessor:
+    """backend: an object with evaluate_batch(op, width, lhs[], rhs[]|None, cond[]|None),
+    evaluate(op, width, lhs, rhs, cond), encrypt(value, width, trivial=True) and
+    rand(width, seed16, random_bits) -- fhe_amd.native.Context is one."""
+
+    def __init__(self, backend):
+        self.backend = backend
+        self.store: dict = {}
+        self.launches = 0          # evaluate_batch / single calls issued
+        self.executed = 0
+
+    def put(self, handle: bytes, ciphertext: bytes):
+        self.store[bytes(handle)] = ciphertext
+
+    def get(self, handle: bytes) -> bytes:
+        return self.store[bytes(handle)]
+
+    # ---- scheduling
+    def execute(self, events: list) -> int:
+        """Runs all events; returns the number of waves.  Raises KeyError if an input handle is
+        neither stored nor produced by another event of the list."""
+        pending = list(events)
+        waves = 0
+        while pending:
+            ready = [e for e in pending if all(bytes(h) in self.store for h in e.inputs())]
+            if not ready:
+                missing = next(h for e in pending for h in e.inputs() if bytes(h) not in self.store)
+                raise KeyError(f"handle {bytes(missing).hex()} is not available")
+            # results of this wave become visible only after the wave: a later event of the same
+            # wave never reads them (it would not be ready)
+            results = {}
+            groups: dict = {}
+            for e in ready:
+                groups.setdefault(self._group_key(e), []).append(e)
+            for key, evs in groups.items():
+                results.update(self._run_group(key, evs))
+            self.store.update(results)
+            done = set(map(id, ready))
+            pending = [e for e in pending if id(e) not in done]
+            self.executed += len(ready)
+            waves += 1
+        return waves
+
+    def _group_key(self, e: Event):
+        a = e.args
+        if e.name in BINARY:
+            return ("bin", BINARY[e.name], handle_width(a["lhs"]), _is_scalar(a))
+        if e.name in UNARY:
+            return ("un", UNARY[e.name], handle_width(a["ct"]))
+        if e.name == "FheIfThenElse":
+            return ("sel", handle_width(a["ifTrue"]))
+        return (e.name, id(e))     # executed one by one
+
+    def _run_group(self, key, evs) -> dict:
+        B = self.backend
+        out = {}
+        kind = key[0]
+        if kind == "bin":
+            _, op, width, scalar = key
+            lhs = [self.get(e.args["lhs"]) for e in evs]
+            rhs = [_clear(e.args["rhs"]) if scalar else self.get(e.args["rhs"]) for e in evs]
+            if not scalar and op in ("shl", "shr", "rotl", "rotr"):
+                for e in evs:
+                    if handle_width(e.args["rhs"]) != 8:
+                        raise ValueError("shift and rotation amounts are euint8")
+            res = B.evaluate_batch(op, width, lhs, rhs, None)
+            self.launches += 1
+            for e, r in zip(evs, res):
+                out[bytes(e.args["result"])] = r
+        elif kind == "un":
+            _, op, width = key
+            res = B.evaluate_batch(op, width, [self.get(e.args["ct"]) for e in evs], None, None)
+            self.launches += 1
+            for e, r in zip(evs, res):
+                out[bytes(e.args["result"])] = r
+        elif kind == "sel":
+            width = key[1]
+            res = B.evaluate_batch("select", width, [self.get(e.args["ifTrue"]) for e in evs],
+                                   [self.get(e.args["ifFalse"]) for e in evs],
+                                   [self.get(e.args["control"]) for e in evs])
+            self.launches += 1
+            for e, r in zip(evs, res):
+                out[bytes(e.args["result"])] = r
+        else:
+            (e,) = evs
+            out[bytes(e.args["result"])] = self._run_single(e)
+            self.launches += 1
+        return out
+
+    def _run_single(self, e: Event) -> bytes:
+        B, a = self.backend, e.args
+        if e.name in ("TrivialEncrypt", "TrivialEncryptBytes"):
+            return B.encrypt(_clear(a["pt"]), TYPE_WIDTH[a["toType"]], trivial=True)
+        if e.name == "Cast":
+            to_w = TYPE_WIDTH[a["toType"]]
+            src = self.get(a["ct"])
+            if to_w == 1 and handle_width(a["ct"]) != 1:        # integer -> ebool is "!= 0"
+                return B.evaluate("ne", handle_width(a["ct"]), src, 0, None)
+            return B.evaluate("cast", to_w, src, None, None)
+        if e.name == "FheRand":
+            w = TYPE_WIDTH[a["randType"]]
+            return B.rand(w, bytes(a["seed"]), w)
+        if e.name == "FheRandBounded":
+            w = TYPE_WIDTH[a["randType"]]
+            bound = _clear(a["upperBound"])
+            if bound < 2 or bound & (bound - 1) or bound.bit_length() - 1 > w:
+                raise ValueError("upperBound must be a power of two within the type")   # as contracts/Rand.sol requires
+            return B.rand(w, bytes(a["seed"]), bound.bit_length() - 1)
+        raise ValueError(f"event {e.name} is not handled by this backend")

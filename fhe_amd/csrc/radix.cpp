@@ -372,6 +372,63 @@ int32_t lfhe_encrypt_public(lfhe_ctx* ctx, const uint8_t* pk, uint64_t pk_len, c
     });
 }
 
+// Oblivious pseudo-random integers: every block starts as a ciphertext whose 2049 words come
+// straight from the seeded generator, so its phase is uniform and known to nobody; one bootstrap
+// maps the phase to its low message bits.  The table holds the odd multiples (2r - (2^b - 1)) of
+// half a message step, a set that the negacyclic sign flip of the padding-bit half maps onto
+// itself, and the constant (2^b - 1) / 2 steps is added afterwards: uniform over [0, 2^b).
+int32_t lfhe_rand(lfhe_ctx* ctx, uint32_t bit_width, const uint8_t seed[16], uint32_t random_bits, uint8_t* out,
+                  uint64_t* out_len) {
+    return guarded(ctx, [&]() -> int32_t {
+        if (!seed || !out_len) throw std::invalid_argument("null pointer");
+        if (!width_ok(bit_width)) throw std::invalid_argument("unsupported bit width");
+        if (random_bits == 0 || random_bits > bit_width) throw std::invalid_argument("random_bits outside 1..bit_width");
+        const uint64_t need = ct_bytes(bit_width);
+        if (!out) { *out_len = need; return LFHE_OK; }
+        if (*out_len < need) { *out_len = need; return LFHE_ERR_SIZE; }
+        if (!ctx->eng->has_keys()) throw std::logic_error("server keys not loaded");
+        Engine& E = *ctx->eng;
+        HC(hipSetDevice(E.device()));
+        const uint32_t nb = blocks_of(bit_width);
+        const uint32_t full = random_bits / 2, odd = random_bits & 1, live = full + odd;
+        uint8_t key[32] = {0};
+        std::memcpy(key, seed, 16);
+        ChaCha rng(key, 0x500000000ull);
+        std::vector<u64> in((size_t)live * BLK_WORDS), res((size_t)live * BLK_WORDS);
+        for (auto& w : in) w = rng.next();
+        // two tables: two random bits, one random bit (entries in units of half a message step)
+        const u64 half = ctx->delta() / 2;
+        std::vector<u64> bodies(2 * (size_t)N);
+        uint64_t tab[16];
+        for (int x = 0; x < 16; ++x) tab[x] = (u64)(i64)(2 * (x & 3) - 3);
+        make_lut_body(ctx->space(), half, tab, bodies.data());
+        for (int x = 0; x < 16; ++x) tab[x] = (u64)(i64)(2 * (x & 1) - 1);
+        make_lut_body(ctx->space(), half, tab, bodies.data() + N);
+        std::vector<u32> idx(live, 0);
+        if (odd) idx[live - 1] = 1;
+        DevBuf<u64> din(in.size()), dout(in.size()), dl(bodies.size());
+        DevBuf<u32> di(live);
+        hipStream_t st = E.stream();
+        HC(hipMemcpyAsync(din.p, in.data(), in.size() * 8, hipMemcpyHostToDevice, st));
+        HC(hipMemcpyAsync(dl.p, bodies.data(), bodies.size() * 8, hipMemcpyHostToDevice, st));
+        HC(hipMemcpyAsync(di.p, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, st));
+        E.pbs_batch(din.p, dl.p, di.p, dout.p, live);
+        HC(hipMemcpyAsync(res.data(), dout.p, res.size() * 8, hipMemcpyDeviceToHost, st));
+        E.sync();
+        ctx->pbs_count += live;
+        CtHeader h{CT_MAGIC, 1, (uint16_t)bit_width, nb, 1, (uint8_t)(bit_width == 1 ? 1 : 3), 0};
+        std::memcpy(out, &h, sizeof h);
+        std::memset(out + sizeof h, 0, (size_t)nb * BLK_BYTES);   // blocks above the random bits: trivial zeros
+        for (uint32_t b = 0; b < live; ++b) {
+            u64* blk = res.data() + (size_t)b * BLK_WORDS;
+            blk[N] += (odd && b == live - 1) ? half : 3 * half;
+            std::memcpy(out + sizeof h + (size_t)b * BLK_BYTES, blk, BLK_BYTES);
+        }
+        *out_len = need;
+        return LFHE_OK;
+    });
+}
+
 int32_t lfhe_op_from_name(const char* name) {
     if (!name) return -1;
     static const struct { const char* n; int op; } tab[] = {

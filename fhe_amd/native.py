@@ -85,6 +85,7 @@ def load():
         "lfhe_evaluate": (i32, [vp, u32, u32, vp, u64, vp, u64, i32, vp, u64, vp, pu64]),
         "lfhe_evaluate_batch": (i32, [vp, u32, u32, u64, vp, vp, i32, vp, vp]),
         "lfhe_program_dump": (i32, [u32, u32, i32, i32, i32, C.c_char_p, C.c_char_p, pu64]),
+        "lfhe_rand": (i32, [vp, u32, C.c_char_p, u32, vp, pu64]),
         "lfhe_pbs_count": (i32, [vp, pu64]),
         "lfhe_make_lut": (i32, [vp, vp, vp]),
         "lfhe_pbs_batch": (i32, [vp, u64, vp, vp, u32, vp, vp]),
@@ -303,6 +304,15 @@ class Context:
                                              _ptr(Cn), _ptr(out)))
         raw = out.tobytes()
         return [raw[i * sz:(i + 1) * sz] for i in range(n)]
+
+    def rand(self, bit_width: int, seed: bytes, random_bits: int | None = None) -> bytes:
+        """Oblivious pseudo-random ciphertext: uniform below 2^random_bits (default: the full width)."""
+        assert len(seed) == 16
+        n = C.c_uint64(self.ciphertext_size(bit_width))
+        buf = np.zeros(n.value, dtype=np.uint8)
+        self._ck(self._L.lfhe_rand(self._h, bit_width, seed, bit_width if random_bits is None else random_bits,
+                                   _ptr(buf), C.byref(n)))
+        return buf.tobytes()
 
     def pbs_count(self) -> int:
         n = C.c_uint64()

@@ -166,6 +166,13 @@ int32_t lfhe_evaluate_batch(lfhe_ctx* ctx, uint32_t op, uint32_t bit_width, uint
 int32_t lfhe_program_dump(uint32_t op, uint32_t bit_width, int32_t lhs_noise, int32_t rhs_noise, int32_t cond_noise,
                           const uint8_t* scalar /* 32 bytes or NULL: clear shift amount / divisor */, char* out,
                           uint64_t* out_len);
+/* Oblivious pseudo-random integer: the low random_bits bits uniform (1 <= random_bits <= bit_width),
+ * the rest zero, derived from `seed` with one bootstrap per two bits; the same seed gives the same
+ * plaintext under the same keys.  Replaces: the executor events FheRand(randType, seed) and
+ * FheRandBounded(upperBound = 2^random_bits, randType, seed)
+ * (tests/fhevm-suite/e2e/test/utils.ts:212-213, contracts/Rand.sol). */
+int32_t lfhe_rand(lfhe_ctx* ctx, uint32_t bit_width, const uint8_t seed[16], uint32_t random_bits, uint8_t* out,
+                  uint64_t* out_len);
 /* cumulative count of programmable bootstraps issued by this context */
 int32_t lfhe_pbs_count(const lfhe_ctx* ctx, uint64_t* out);
 

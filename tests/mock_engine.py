@@ -13,8 +13,8 @@ class MockBackend:
     def public_key(self):
         return b"mock-public-key"
 
-    def encrypt(self, value, width):
-        return json.dumps({"w": width, "v": str(value)}).encode()
+    def encrypt(self, value, width, trivial=False):
+        return json.dumps({"w": width, "v": str(value % (1 << width))}).encode()
 
     def decrypt(self, ct):
         return int(json.loads(ct)["v"])
@@ -23,7 +23,26 @@ class MockBackend:
         a = int(json.loads(left)["v"])
         b = right if isinstance(right, int) or right is None else int(json.loads(right)["v"])
         c = None if cond is None else int(json.loads(cond)["v"])
+        if op == "cast":
+            return self.encrypt(a, width)
         if json.loads(left)["w"] != width:
             raise ValueError("width mismatch")
         out_w = 1 if op in ("eq", "ne", "ge", "gt", "le", "lt") else width
         return self.encrypt(clear_op(op, width, a, b, c), out_w)
+
+    # ---- batch / coprocessor surface (fhe_amd.native.Context signatures)
+    def evaluate_batch(self, op, width, lhs, rhs=None, cond=None):
+        self.batches = getattr(self, "batches", 0) + 1
+        out = []
+        for i, l in enumerate(lhs):
+            r = None if rhs is None else rhs[i]
+            c = None if cond is None else cond[i]
+            if op in ("shl", "shr", "rotl", "rotr") and not isinstance(r, int):
+                assert json.loads(r)["w"] == 8
+            out.append(self.evaluate(op, width, l, r, c))
+        return out
+
+    def rand(self, width, seed, random_bits):
+        import hashlib
+        v = int.from_bytes(hashlib.sha256(seed).digest(), "big") & ((1 << random_bits) - 1)
+        return self.encrypt(v, width)

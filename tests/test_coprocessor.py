@@ -1,0 +1,161 @@
+"""Event-driven operator boundary (fhe_amd/coprocessor.py): dependency waves, batching of like
+events, scalar byte, handle types, casts, rand.  CPU: on the plaintext mock backend, replaying the
+reference's operator vectors as executor events; GPU: a block of ERC20-style transfers."""
+import json
+import os
+
+import pytest
+
+from fhe_amd.coprocessor import BINARY, Coprocessor, Event, TYPE_WIDTH, handle_type
+from oracle import radix
+from tests.mock_engine import MockBackend
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+KATS = json.load(open(os.path.join(GOLDEN, "fhevm_operator_kats.json")))["kats"]
+WIDTH_TYPE = {w: t for t, w in TYPE_WIDTH.items()}
+OP_EVENT = {}
+for _ev, _op in BINARY.items():
+    OP_EVENT.setdefault(_op, _ev)
+OP_EVENT.update({"neg": "FheNeg", "not": "FheNot"})
+
+
+def mk_handle(counter: int, width: int) -> bytes:
+    h = bytearray(32)
+    h[0:8] = counter.to_bytes(8, "big")
+    h[30] = WIDTH_TYPE[width]
+    return bytes(h)
+
+
+def kat_events(backend, cop, kats):
+    """Each vector as the events the fhevm library emits for it: operands promoted to the wider
+    type by Cast, clear right operands through scalarByte = 1, clear left operands trivially
+    encrypted (the library only has scalar-right overloads)."""
+    events, expect = [], []
+    n = 0
+    for k in kats:
+        op, w, ins, exp = radix.kat_case(k)
+        enc = [t.startswith("e") for t in k["types"]]
+        if op in ("shl", "shr", "rotl", "rotr", "div", "rem"):
+            w = radix.type_width(k["types"][0])
+        hs = []
+        for i, v in enumerate(ins):
+            wi = radix.type_width(k["types"][i])
+            if enc[i]:
+                n += 1
+                h = mk_handle(n, wi)
+                cop.put(h, backend.encrypt(v, wi))
+                tw = 8 if (i == 1 and op in ("shl", "shr", "rotl", "rotr")) else w
+                if wi != tw:
+                    n += 1
+                    h2 = mk_handle(n, tw)
+                    events.append(Event("Cast", {"ct": h, "toType": WIDTH_TYPE[tw], "result": h2}))
+                    h = h2
+                hs.append(h)
+            elif i == 0:
+                n += 1
+                h = mk_handle(n, w)
+                events.append(Event("TrivialEncrypt", {"pt": v, "toType": WIDTH_TYPE[w], "result": h}))
+                hs.append(h)
+            else:
+                hs.append(v)
+        n += 1
+        out_w = 1 if op in ("eq", "ne", "ge", "gt", "le", "lt") else w
+        res = mk_handle(n, out_w)
+        if len(ins) == 1:
+            events.append(Event(OP_EVENT[op], {"ct": hs[0], "result": res}))
+        else:
+            scalar = not enc[1]
+            rhs = hs[1].to_bytes(32, "big") if scalar else hs[1]
+            events.append(Event(OP_EVENT[op], {"lhs": hs[0], "rhs": rhs, "scalarByte": b"\x01" if scalar else b"\x00",
+                                               "result": res}))
+        expect.append((res, exp))
+    return events, expect
+
+
+def test_every_reference_vector_as_executor_events():
+    backend = MockBackend()
+    cop = Coprocessor(backend)
+    events, expect = kat_events(backend, cop, KATS)
+    waves = cop.execute(events)
+    assert waves <= 3                                  # trivial encryptions / casts, then the operators
+    for h, exp in expect:
+        assert backend.decrypt(cop.get(h)) == exp
+        assert handle_type(h) in TYPE_WIDTH
+    # like events were batched: far fewer engine calls than events
+    assert cop.executed == len(events) and backend.batches < 400 < len(KATS)
+
+
+def test_dependency_waves_select_cast_and_rand():
+    backend = MockBackend()
+    cop = Coprocessor(backend)
+    H = lambda i, w: mk_handle(i, w)
+    cop.put(H(1, 64), backend.encrypt(10000, 64))      # balance
+    cop.put(H(2, 64), backend.encrypt(1337, 64))       # amount
+    cop.put(H(3, 64), backend.encrypt(5, 64))          # recipient balance
+    ev = [
+        # deliberately out of order: the scheduler sorts by availability of the inputs
+        Event("FheSub", {"lhs": H(1, 64), "rhs": H(5, 64), "scalarByte": b"\x00", "result": H(6, 64)}),
+        Event("FheIfThenElse", {"control": H(4, 1), "ifTrue": H(2, 64), "ifFalse": H(9, 64), "result": H(5, 64)}),
+        Event("FheLe", {"lhs": H(2, 64), "rhs": H(1, 64), "scalarByte": b"\x00", "result": H(4, 1)}),
+        Event("TrivialEncrypt", {"pt": 0, "toType": 5, "result": H(9, 64)}),
+        Event("FheAdd", {"lhs": H(3, 64), "rhs": H(5, 64), "scalarByte": b"\x00", "result": H(7, 64)}),
+        Event("Cast", {"ct": H(7, 64), "toType": 4, "result": H(8, 32)}),
+        Event("Cast", {"ct": H(7, 64), "toType": 0, "result": H(10, 1)}),
+        Event("FheRandBounded", {"upperBound": 1 << 10, "randType": 3, "seed": bytes(16), "result": H(11, 16)}),
+        Event("FheRand", {"randType": 2, "seed": bytes(range(16)), "result": H(12, 8)}),
+    ]
+    waves = cop.execute(ev)
+    assert waves == 4                                  # le|trivial|rand -> select -> sub|add -> casts
+    d = lambda h: backend.decrypt(cop.get(h))
+    assert (d(H(6, 64)), d(H(7, 64)), d(H(8, 32)), d(H(10, 1))) == (10000 - 1337, 1342, 1342, 1)
+    assert d(H(11, 16)) < 1 << 10
+    with pytest.raises(KeyError):
+        cop.execute([Event("FheNeg", {"ct": H(99, 8), "result": H(100, 8)})])
+    with pytest.raises(ValueError):
+        cop.execute([Event("FheRandBounded", {"upperBound": 1000, "randType": 3, "seed": bytes(16), "result": H(13, 16)})])
+
+
+@pytest.mark.gpu
+def test_block_of_transfers_and_rand_on_gpu():
+    """A block of transfers (le, select, sub, add per transfer: EncryptedERC20.sol:87-93,208-220)
+    as executor events: four waves, one batched engine call per (wave, operation)."""
+    from fhe_amd.native import Context
+    ctx = Context(seed=bytes(range(32)), params_id=2)
+    ctx.keygen()
+    try:
+        cop = Coprocessor(ctx)
+        n, c = 6, 0
+        plain, ev, outs = [], [], []
+
+        def new(w):
+            nonlocal c
+            c += 1
+            return mk_handle(c, w)
+        zero = new(64)
+        ev.append(Event("TrivialEncrypt", {"pt": 0, "toType": 5, "result": zero}))
+        for i in range(n):
+            bal, to, amt = 1000 + 37 * i, 5 * i, (400 * i) % 1500
+            hb, ht, ha = new(64), new(64), new(64)
+            cop.put(hb, ctx.encrypt(bal, 64)); cop.put(ht, ctx.encrypt(to, 64)); cop.put(ha, ctx.encrypt(amt, 64))
+            ok, v, nb, nt = new(1), new(64), new(64), new(64)
+            ev += [Event("FheLe", {"lhs": ha, "rhs": hb, "scalarByte": b"\x00", "result": ok}),
+                   Event("FheIfThenElse", {"control": ok, "ifTrue": ha, "ifFalse": zero, "result": v}),
+                   Event("FheSub", {"lhs": hb, "rhs": v, "scalarByte": b"\x00", "result": nb}),
+                   Event("FheAdd", {"lhs": ht, "rhs": v, "scalarByte": b"\x00", "result": nt})]
+            moved = amt if amt <= bal else 0
+            plain.append((bal - moved, to + moved))
+            outs.append((nb, nt))
+        before = cop.launches
+        assert cop.execute(ev) == 3
+        assert cop.launches - before == 5              # trivial, le, select, sub, add
+        assert [(ctx.decrypt(cop.get(a)), ctx.decrypt(cop.get(b))) for a, b in outs] == plain
+        # oblivious randoms: deterministic in the seed, inside the bound, not constant
+        r1 = ctx.decrypt(ctx.rand(64, bytes(range(16))))
+        assert r1 == ctx.decrypt(ctx.rand(64, bytes(range(16))))
+        vals = [ctx.decrypt(ctx.rand(16, bytes([i]) * 16, 11)) for i in range(24)]
+        assert all(v < 1 << 11 for v in vals) and len(set(vals)) > 12
+        ones = sum(bin(v).count("1") for v in vals)
+        assert 24 * 11 * 0.3 < ones < 24 * 11 * 0.7
+        assert ctx.decrypt(ctx.rand(1, bytes(16))) in (0, 1)
+    finally:
+        ctx.close()
