@@ -169,6 +169,22 @@ int32_t lfhe_keygen(lfhe_ctx* ctx) {
     });
 }
 
+int32_t lfhe_keygen_server(lfhe_ctx* ctx) {
+    return guarded(ctx, [&]() -> int32_t {
+        if (!ctx->have_client) throw std::logic_error("no client keys: import them first");
+        const EngineParams& p = ctx->prm;
+        ctx->bsk.resize(ctx->eng->bsk_raw_words());
+        ctx->ksk.resize(ctx->eng->ksk_words());
+        if (p.bsk_modulus) gen_bsk_qp(p, ctx->lwe_sk.data(), ctx->glwe_sk.data(), ctx->seed, ctx->bsk.data(), host_threads());
+        else gen_bsk(p, ctx->lwe_sk.data(), ctx->glwe_sk.data(), ctx->seed, ctx->bsk.data(), host_threads());
+        gen_ksk(p, ctx->glwe_sk.data(), ctx->lwe_sk.data(), ctx->seed, ctx->ksk.data(), host_threads());
+        ctx->ms_zeros.resize(ctx->eng->ms_zeros_words());
+        gen_ms_zeros(p, ctx->lwe_sk.data(), ctx->seed, ctx->ms_zeros.data(), host_threads());
+        upload_server_keys(ctx);
+        return LFHE_OK;
+    });
+}
+
 int32_t lfhe_server_keys_import_raw(lfhe_ctx* ctx, const uint64_t* bsk, uint64_t bsk_words, const uint64_t* ksk,
                                     uint64_t ksk_words, const uint64_t* ms_zeros, uint64_t ms_words) {
     return guarded(ctx, [&]() -> int32_t {

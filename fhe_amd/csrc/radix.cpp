@@ -1,6 +1,7 @@
 // Integer operators on radix ciphertexts (euint8 ... euint256, ebool): serialisation, encryption,
 // decryption and the executor that replays an operator's Program (radix_program.h) for a batch of
 // independent instances, layer by layer, on the GPU.
+#include <algorithm>
 #include <array>
 #include <cstring>
 #include <map>
@@ -325,7 +326,9 @@ int32_t lfhe_decrypt(lfhe_ctx* ctx, const uint8_t* ct, uint64_t ct_len, uint8_t 
 
 namespace {
 constexpr uint32_t PK_MAGIC = 0x4b50464cu;  // "LFPK"
-struct PkHeader { uint32_t magic, poly_size, noise_log2, reserved; };
+// flags bit 0: the key polynomial is the secret key in reversed coefficient order (body = mask (*) rev(s)
+// + e), the convention of tfhe-rs compact public keys; blocks are then emitted with reversed masks
+struct PkHeader { uint32_t magic, poly_size, noise_log2, flags; };
 constexpr uint64_t PK_BYTES = sizeof(PkHeader) + 2ull * N * 8;
 }  // namespace
 
@@ -366,6 +369,8 @@ int32_t lfhe_encrypt_public(lfhe_ctx* ctx, const uint8_t* pk, uint64_t pk_len, c
         std::memcpy(out, &ch, sizeof ch);
         std::vector<uint64_t> blocks((size_t)nb * BLK_WORDS);
         pk_encrypt_blocks(ctx->prm, key.data(), pt.data(), nb, ctx->enc_rng, blocks.data());
+        if (h.flags & 1u)   // LWE under rev(s) -> LWE under s
+            for (uint32_t i = 0; i < nb; ++i) std::reverse(blocks.data() + (size_t)i * BLK_WORDS, blocks.data() + (size_t)i * BLK_WORDS + N);
         std::memcpy(out + sizeof ch, blocks.data(), blocks.size() * 8);
         *out_len = need;
         return LFHE_OK;

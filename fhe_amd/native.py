@@ -68,6 +68,7 @@ def load():
         "lfhe_get_params": (i32, [vp, C.POINTER(Params)]),
         "lfhe_health": (i32, [vp, C.c_char_p, pu64]),
         "lfhe_keygen": (i32, [vp]),
+        "lfhe_keygen_server": (i32, [vp]),
         "lfhe_keys_export": (i32, [vp, u32, vp, pu64]),
         "lfhe_keys_import": (i32, [vp, u32, vp, u64]),
         "lfhe_server_keys_import_raw": (i32, [vp, vp, u64, vp, u64, vp, u64]),
@@ -180,6 +181,10 @@ class Context:
     # ---- keys
     def keygen(self):
         self._ck(self._L.lfhe_keygen(self._h))
+
+    def keygen_server(self):
+        """Server keys for the client keys this context holds (after an import)."""
+        self._ck(self._L.lfhe_keygen_server(self._h))
 
     def import_server_keys_raw(self, bsk: np.ndarray, ksk: np.ndarray, ms_zeros: np.ndarray | None = None):
         """ms_zeros: the encryptions of zero of the modulus-switch noise reduction, or None for a

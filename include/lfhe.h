@@ -90,6 +90,9 @@ int32_t lfhe_health(lfhe_ctx* ctx, char* out, uint64_t* out_len);
  * (packages/luxfhejs/src/index.ts:63-72, packages/hardhat-plugin/src/index.ts:80-87);
  * client-side generateKeys (sdk/relayer/generateKeys.js:20-66). */
 int32_t lfhe_keygen(lfhe_ctx* ctx);
+/* server keys (bootstrapping key, key-switching key, noise-reduction zeros) for client keys that
+ * were imported, e.g. the secret keys of a ClientKey made by the reference's generateKeys.js */
+int32_t lfhe_keygen_server(lfhe_ctx* ctx);
 #define LFHE_KEY_CLIENT 1u /* secret keys */
 #define LFHE_KEY_SERVER 2u /* bootstrapping + key-switching keys (coefficient domain) */
 int32_t lfhe_keys_export(lfhe_ctx* ctx, uint32_t which, uint8_t* out, uint64_t* out_len);

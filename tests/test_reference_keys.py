@@ -1,0 +1,93 @@
+"""The key blobs of the reference's SDK (sdk/relayer/src/test/keys/{privateKey,publicKey}.bin, copies
+under tests/golden/; made by sdk/relayer/generateKeys.js with node-tfhe 1.4.0-alpha.3) drive the
+backend: the parameter set and the secret keys are read from the ClientKey, server keys are
+generated for them on the GPU box, and the reference's compact public key encrypts values that its
+own secret key decrypts."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from fhe_amd import tfhers_wire as W
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _blobs():
+    return (open(os.path.join(GOLDEN, "privateKey.bin"), "rb").read(),
+            open(os.path.join(GOLDEN, "publicKey.bin"), "rb").read())
+
+
+def test_client_key_blob_is_read():
+    priv, pub = _blobs()
+    k = W.parse_client_key(priv)
+    p = k["params"]
+    assert (p["lwe_dim"], p["glwe_dim"], p["poly_size"]) == (918, 1, 2048)
+    assert (p["pbs_base_log"], p["pbs_level"], p["ks_base_log"], p["ks_level"]) == (23, 1, 4, 4)
+    assert (p["message_modulus"], p["carry_modulus"], p["max_noise_level"]) == (4, 4, 5)
+    assert (p["lwe_noise_log2"], p["glwe_noise_log2"]) == (45, 17)
+    assert p["ms_zeros_count"] == 1449 and p["ms_bound"] == 2.0 ** 58
+    # Hamming weights of the three binary keys of the fixture
+    assert (int(k["glwe_sk"].sum()), int(k["lwe_sk"].sum()), int(k["pke_sk"].sum())) == (996, 460, 975)
+    mask, body = W.parse_compact_public_key(pub)
+    assert len(mask) == len(body) == 2048
+    # the library's default parameters are exactly the blob's
+    from fhe_amd.native import default_params
+    d = default_params()
+    for name in ("lwe_dim", "glwe_dim", "poly_size", "pbs_base_log", "pbs_level", "ks_base_log", "ks_level",
+                 "message_modulus", "carry_modulus", "lwe_noise_log2", "glwe_noise_log2", "ms_zeros_count"):
+        assert getattr(d, name) == p[name], name
+    assert 2.0 ** d.ms_bound_log2 == p["ms_bound"] and d.ms_r_sigma_factor == p["ms_r_sigma_factor"]
+    assert d.ms_input_variance == p["ms_input_variance"]
+    with pytest.raises(ValueError):
+        W.parse_client_key(bytes(5000))
+    lfpk = W.compact_public_key_to_lfpk(pub)
+    assert struct.unpack("<IIII", lfpk[:16]) == (0x4B50464C, 2048, 17, 1) and len(lfpk) == 16 + 2 * 2048 * 8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("params_id", [1, 2])
+def test_reference_client_key_drives_the_backend(params_id):
+    from fhe_amd.native import Context
+    from oracle.oracle import Oracle
+    priv, _ = _blobs()
+    k = W.parse_client_key(priv)
+    ctx = Context(seed=bytes(range(32)), params_id=params_id)
+    try:
+        ctx.import_client_keys_raw(k["lwe_sk"], k["glwe_sk"])
+        ctx.keygen_server()
+        a, b = ctx.encrypt(0xC0FFEE, 32), ctx.encrypt(0x123456, 32)
+        out = ctx.evaluate("mul", 32, a, b)
+        assert ctx.decrypt(out) == (0xC0FFEE * 0x123456) & 0xFFFFFFFF
+        assert ctx.decrypt(ctx.evaluate("gt", 32, a, b)) == 1
+        # an independent decryption of the result with the blob's key
+        orc = Oracle()
+        blocks = np.frombuffer(out[16:], dtype=np.uint64).reshape(-1, 2049)
+        digits = [orc.decrypt_block(k["glwe_sk"], blk) for blk in blocks]
+        assert sum((d & 3) << (2 * i) for i, d in enumerate(digits)) == (0xC0FFEE * 0x123456) & 0xFFFFFFFF
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_reference_public_key_encrypts_for_its_secret_key():
+    """publicKey.bin (tfhe-rs) -> lfhe_encrypt_public -> decryption with the secret key stored in
+    privateKey.bin (tfhe-rs): the public-key encryption is checked against keys this code did not make."""
+    from fhe_amd.native import Context, LfheError
+    priv, pub = _blobs()
+    k = W.parse_client_key(priv)
+    lfpk = W.compact_public_key_to_lfpk(pub)
+    ctx = Context(seed=bytes(range(32)))
+    try:
+        ctx.import_client_keys_raw(k["lwe_sk"], k["pke_sk"])       # the PKE secret as the decryption key
+        for v, w in ((0xA7, 8), (0xDEADBEEFCAFEF00D, 64), (1, 1), ((1 << 256) - 12345, 256)):
+            ct = ctx.encrypt_public(lfpk, v, w)
+            assert ctx.decrypt(ct) == v, (v, w)
+        # without the reversed-key flag the same words decrypt to noise
+        plain = lfpk[:12] + struct.pack("<I", 0) + lfpk[16:]
+        assert ctx.decrypt(ctx.encrypt_public(plain, 0xDEADBEEFCAFEF00D, 64)) != 0xDEADBEEFCAFEF00D
+        with pytest.raises(LfheError):
+            ctx.encrypt_public(lfpk[:100], 1, 8)
+    finally:
+        ctx.close()
