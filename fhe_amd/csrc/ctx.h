@@ -20,6 +20,7 @@ struct lfhe_ctx {
     std::vector<uint64_t> bsk, ksk;  // host copies of the server keys (coefficient domain)
     std::vector<uint64_t> ms_zeros;  // [ms_zeros_count][n+1], empty when the key set has none
     bool have_server = false;
+    std::vector<uint64_t> pke_sk;    // secret key of public-key encryptions made elsewhere (N words), optional
     uint64_t pbs_count = 0;
     std::unique_ptr<struct lfhe_radix> radix;  // operator layer state (radix.cpp)
 

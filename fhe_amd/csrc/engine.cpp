@@ -60,6 +60,7 @@ Engine::~Engine() {
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
     if (own_keys_) { (void)hipFree(d_bsk_); (void)hipFree(d_ksk_); }
+    (void)hipFree(d_cast_ksk_);
     (void)hipFree(d_tw_);
     (void)hipFree(d_small_);
     (void)hipFree(d_ksdig_);
@@ -156,8 +157,28 @@ u64* Engine::small_scratch(size_t count) {
     return d_small_;
 }
 
-void Engine::keyswitch(const u64* lwe_in, u64* lwe_small_out, size_t count, const BlockMap& imap) {
-    if (!d_ksk_) throw std::runtime_error("no key-switching key loaded");
+void Engine::load_cast_ksk(const u64* host_ksk) {
+    HC(hipSetDevice(device_));
+    if (!d_cast_ksk_) HC(hipMalloc(&d_cast_ksk_, (ksk_words() + prm_.lwe_dim + 1) * sizeof(u64)));
+    HC(hipMemcpyAsync(d_cast_ksk_, host_ksk, ksk_words() * sizeof(u64), hipMemcpyHostToDevice, stream_));
+    launch_ksk_colsum(d_cast_ksk_, N * (int)prm_.ks_level, (int)prm_.lwe_dim + 1, 1 << (prm_.ks_base_log - 1),
+                      d_cast_ksk_ + ksk_words(), stream_);
+    HC(hipGetLastError());
+    HC(hipStreamSynchronize(stream_));
+}
+
+void Engine::cast_batch(const u64* lwe_in, const u64* identity_lut, u64* lwe_out, size_t count) {
+    if (!count) return;
+    if (!d_cast_ksk_) throw std::runtime_error("no cast key loaded");
+    u64* small = small_scratch(count);
+    keyswitch(lwe_in, small, count, BlockMap(), true);
+    ms_noise_reduce(small, count);
+    blind_rotate(small, identity_lut, nullptr, nullptr, lwe_out, count);
+}
+
+void Engine::keyswitch(const u64* lwe_in, u64* lwe_small_out, size_t count, const BlockMap& imap, bool with_cast_key) {
+    const u64* key = with_cast_key ? d_cast_ksk_ : d_ksk_;
+    if (!key) throw std::runtime_error("no key-switching key loaded");
     if (!count) return;
     HC(hipSetDevice(device_));
     const size_t need = keyswitch_scratch_words(count, N);
@@ -168,7 +189,7 @@ void Engine::keyswitch(const u64* lwe_in, u64* lwe_small_out, size_t count, cons
         HC(hipMalloc(&d_ksdig_, need * sizeof(u32)));
         ksdig_cap_ = need;
     }
-    launch_keyswitch(d_ksk_, d_ksk_ + ksk_words(), lwe_in, d_ksdig_, lwe_small_out, count, N, (int)prm_.lwe_dim,
+    launch_keyswitch(key, key + ksk_words(), lwe_in, d_ksdig_, lwe_small_out, count, N, (int)prm_.lwe_dim,
                      (int)prm_.ks_base_log, (int)prm_.ks_level, imap, stream_);
     HC(hipGetLastError());
 }

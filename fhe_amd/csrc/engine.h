@@ -99,6 +99,12 @@ public:
     // or attach images that already sit in device memory (e.g. received by a broadcast);
     // the engine does not take ownership
     void attach_device_keys(double* bsk_dev, u64* ksk_dev_image);
+    // a second key-switching key, from the secret key of public-key encryptions to the small key
+    // (same decomposition); used only by cast_batch, local to this engine
+    void load_cast_ksk(const u64* host_ksk);
+    bool has_cast_key() const { return d_cast_ksk_ != nullptr; }
+    // count blocks under the public-key secret -> blocks under the compute key, values kept
+    void cast_batch(const u64* lwe_in, const u64* identity_lut, u64* lwe_out, size_t count);
     double* bsk_dev() const { return d_bsk_; }
     u64* ksk_dev() const { return d_ksk_; }
     bool has_ms_zeros() const { return ms_.zcount != 0; }
@@ -106,7 +112,8 @@ public:
     // ---- device-pointer operations, asynchronous on stream()
     // count bootstraps: lwe_in [count][N+1], luts [nluts][N] body polynomials, lut_index [count] or null
     void pbs_batch(const u64* lwe_in, const u64* luts, const u32* lut_index, u64* lwe_out, size_t count);
-    void keyswitch(const u64* lwe_in, u64* lwe_small_out, size_t count, const BlockMap& imap = BlockMap());
+    void keyswitch(const u64* lwe_in, u64* lwe_small_out, size_t count, const BlockMap& imap = BlockMap(),
+                   bool with_cast_key = false);
     // in place on [count][n+1] small ciphertexts; a no-op without encryptions of zero;
     // chosen [count] (device, may be null) receives the candidate taken (-1: none added)
     void ms_noise_reduce(u64* lwe_small, size_t count, int* chosen = nullptr);
@@ -133,6 +140,7 @@ private:
     double* d_tw_ = nullptr;
     double* d_bsk_ = nullptr;
     u64* d_ksk_ = nullptr;
+    u64* d_cast_ksk_ = nullptr;   // key words followed by the n+1 column sums
     bool own_keys_ = false;
     u64* d_small_ = nullptr;
     size_t small_cap_ = 0;

@@ -150,10 +150,10 @@ void gen_bsk_qp(const EngineParams& p, const uint64_t* lwe_sk, const uint64_t* g
 }
 
 void gen_ksk(const EngineParams& p, const uint64_t* glwe_sk, const uint64_t* lwe_sk, const uint8_t seed[32],
-             uint64_t* ksk, int threads) {
+             uint64_t* ksk, int threads, uint64_t stream_base) {
     const size_t n1 = (size_t)p.lwe_dim + 1;
     parallel_for((size_t)N, threads, [&](size_t i) {
-        ChaCha r(seed, 0x200000000ull + i);
+        ChaCha r(seed, stream_base + i);
         for (uint32_t lv = 0; lv < p.ks_level; ++lv)
             lwe_encrypt(lwe_sk, p.lwe_dim, glwe_sk[i] << (64 - p.ks_base_log * (lv + 1)), p.lwe_noise_log2, r,
                         ksk + (i * p.ks_level + lv) * n1);

@@ -39,8 +39,9 @@ void gen_bsk(const EngineParams& p, const uint64_t* lwe_sk, const uint64_t* glwe
 // the bootstrapping key over the prime ring modulus (EngineParams::bsk_modulus), same layout
 void gen_bsk_qp(const EngineParams& p, const uint64_t* lwe_sk, const uint64_t* glwe_sk, const uint8_t seed[32],
                 uint64_t* bsk, int threads);
+// stream_base separates the generator streams of different keys made from one seed
 void gen_ksk(const EngineParams& p, const uint64_t* glwe_sk, const uint64_t* lwe_sk, const uint8_t seed[32],
-             uint64_t* ksk, int threads);
+             uint64_t* ksk, int threads, uint64_t stream_base = 0x200000000ull);
 
 // encryptions of zero under the small key for the modulus-switch noise reduction:
 // zeros[ms_zeros_count][n+1]

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <map>
 #include <stdexcept>
+#include <thread>
 #include <tuple>
 
 #include "ctx.h"
@@ -430,6 +431,58 @@ int32_t lfhe_rand(lfhe_ctx* ctx, uint32_t bit_width, const uint8_t seed[16], uin
             std::memcpy(out + sizeof h + (size_t)b * BLK_BYTES, blk, BLK_BYTES);
         }
         *out_len = need;
+        return LFHE_OK;
+    });
+}
+
+// ---- ciphertexts made under a separate public-key secret (tfhe-rs: dedicated compact public key
+// parameters + a key-switching key towards the compute parameters) ---------------------------------
+int32_t lfhe_pke_key_set(lfhe_ctx* ctx, const uint64_t* pke_sk) {
+    return guarded(ctx, [&]() -> int32_t {
+        if (!pke_sk) throw std::invalid_argument("null key pointer");
+        if (!ctx->have_client) throw std::logic_error("no client keys: the cast key encrypts under the small key");
+        for (int i = 0; i < N; ++i)
+            if (pke_sk[i] > 1) throw std::invalid_argument("secret key words must be 0 or 1");
+        ctx->pke_sk.assign(pke_sk, pke_sk + N);
+        std::vector<uint64_t> ksk(ctx->eng->ksk_words());
+        unsigned hc = std::thread::hardware_concurrency();
+        gen_ksk(ctx->prm, ctx->pke_sk.data(), ctx->lwe_sk.data(), ctx->seed, ksk.data(), (int)(hc ? (hc > 16 ? 16 : hc) : 4),
+                0x600000000ull);
+        ctx->eng->load_cast_ksk(ksk.data());
+        return LFHE_OK;
+    });
+}
+
+int32_t lfhe_cast_from_pke(lfhe_ctx* ctx, const uint8_t* ct, uint64_t ct_len, uint8_t* out, uint64_t* out_len) {
+    return guarded(ctx, [&]() -> int32_t {
+        if (!ct || !out_len) throw std::invalid_argument("null pointer");
+        CtHeader h;
+        if (ct_len < sizeof h) throw std::invalid_argument("ciphertext too short");
+        std::memcpy(&h, ct, sizeof h);
+        if (h.magic != CT_MAGIC || h.version != 1 || !width_ok(h.bit_width) || h.nblocks != blocks_of(h.bit_width) ||
+            ct_len != ct_bytes(h.bit_width))
+            throw std::invalid_argument("malformed ciphertext");
+        if (!out) { *out_len = ct_len; return LFHE_OK; }
+        if (*out_len < ct_len) { *out_len = ct_len; return LFHE_ERR_SIZE; }
+        Engine& E = *ctx->eng;
+        if (!E.has_keys() || !E.has_cast_key()) throw std::logic_error("server keys or cast key not loaded");
+        HC(hipSetDevice(E.device()));
+        const size_t words = (size_t)h.nblocks * BLK_WORDS;
+        std::vector<u64> lut(N);
+        uint64_t tab[16];
+        for (int x = 0; x < 16; ++x) tab[x] = (uint64_t)x;
+        make_lut_body(ctx->space(), ctx->delta(), tab, lut.data());
+        DevBuf<u64> din(words), dout(words), dl(N);
+        hipStream_t st = E.stream();
+        HC(hipMemcpyAsync(din.p, ct + sizeof h, words * 8, hipMemcpyHostToDevice, st));
+        HC(hipMemcpyAsync(dl.p, lut.data(), (size_t)N * 8, hipMemcpyHostToDevice, st));
+        E.cast_batch(din.p, dl.p, dout.p, h.nblocks);
+        HC(hipMemcpyAsync(out + sizeof h, dout.p, words * 8, hipMemcpyDeviceToHost, st));
+        E.sync();
+        ctx->pbs_count += h.nblocks;
+        h.noise_level = 1;
+        std::memcpy(out, &h, sizeof h);
+        *out_len = ct_len;
         return LFHE_OK;
     });
 }

@@ -82,6 +82,8 @@ def load():
         "lfhe_encrypt_public": (i32, [vp, vp, u64, C.c_char_p, u32, vp, pu64]),
         "lfhe_decrypt": (i32, [vp, vp, u64, vp, pu32]),
         "lfhe_ciphertext_size": (i32, [vp, u32, pu64]),
+        "lfhe_pke_key_set": (i32, [vp, vp]),
+        "lfhe_cast_from_pke": (i32, [vp, vp, u64, vp, pu64]),
         "lfhe_op_from_name": (i32, [C.c_char_p]),
         "lfhe_evaluate": (i32, [vp, u32, u32, vp, u64, vp, u64, i32, vp, u64, vp, pu64]),
         "lfhe_evaluate_batch": (i32, [vp, u32, u32, u64, vp, vp, i32, vp, vp]),
@@ -261,6 +263,20 @@ class Context:
         self._ck(self._L.lfhe_encrypt_public(self._h, _ptr(key), key.size, le32(value % (1 << max(bit_width, 1))),
                                              bit_width, _ptr(buf), C.byref(n)))
         return buf.tobytes()
+
+    def set_pke_key(self, pke_sk: np.ndarray):
+        """Secret key of public-key encryptions made elsewhere; builds the cast key."""
+        k = _u64(pke_sk)
+        assert k.size == self.N
+        self._ck(self._L.lfhe_pke_key_set(self._h, _ptr(k)))
+
+    def cast_from_pke(self, ct: bytes) -> bytes:
+        """Ciphertext under the public-key secret -> same values under the compute key."""
+        buf = np.frombuffer(ct, dtype=np.uint8)
+        n = C.c_uint64(buf.size)
+        out = np.zeros(buf.size, dtype=np.uint8)
+        self._ck(self._L.lfhe_cast_from_pke(self._h, _ptr(buf), buf.size, _ptr(out), C.byref(n)))
+        return out.tobytes()
 
     def decrypt(self, ct: bytes) -> int:
         buf = np.frombuffer(ct, dtype=np.uint8)

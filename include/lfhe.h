@@ -128,6 +128,14 @@ int32_t lfhe_trivial_encrypt(lfhe_ctx* ctx, const uint8_t value_le[32], uint32_t
 int32_t lfhe_encrypt_public(lfhe_ctx* ctx, const uint8_t* pk, uint64_t pk_len, const uint8_t value_le[32],
                             uint32_t bit_width, uint8_t* out, uint64_t* out_len);
 int32_t lfhe_decrypt(lfhe_ctx* ctx, const uint8_t* ct, uint64_t ct_len, uint8_t value_le[32], uint32_t* bit_width);
+/* Inputs encrypted under a dedicated public-key secret (the reference encrypts user inputs with
+ * V1_0_PARAM_PKE_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128 keys and casts them to the compute
+ * parameters, sdk/relayer/src/tfhe.ts:14-19, sdk/relayer/src/sdk/encrypt.ts:54-196).
+ * lfhe_pke_key_set: that secret (N words of 0/1); builds the cast key towards the small key with the
+ * set's key-switch decomposition.  lfhe_cast_from_pke: a ciphertext under the public-key secret
+ * -> the same values under the compute key, one key switch + bootstrap per block. */
+int32_t lfhe_pke_key_set(lfhe_ctx* ctx, const uint64_t* pke_sk);
+int32_t lfhe_cast_from_pke(lfhe_ctx* ctx, const uint8_t* ct, uint64_t ct_len, uint8_t* out, uint64_t* out_len);
 int32_t lfhe_ciphertext_size(const lfhe_ctx* ctx, uint32_t bit_width, uint64_t* out_len);
 
 /* ---- operators ----------------------------------------------------------------------------------

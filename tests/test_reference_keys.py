@@ -91,3 +91,27 @@ def test_reference_public_key_encrypts_for_its_secret_key():
             ctx.encrypt_public(lfpk[:100], 1, 8)
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_inputs_under_the_reference_public_key_are_cast_and_computed_on():
+    """The reference's flow for user inputs: encrypt with the compact public key, cast to the compute
+    key on the server, operate, decrypt with the compute secret key -- all three keys from the blobs."""
+    from fhe_amd.native import Context
+    priv, pub = _blobs()
+    k = W.parse_client_key(priv)
+    lfpk = W.compact_public_key_to_lfpk(pub)
+    ctx = Context(seed=bytes(range(32)), params_id=2)
+    try:
+        ctx.import_client_keys_raw(k["lwe_sk"], k["glwe_sk"])
+        ctx.keygen_server()
+        ctx.set_pke_key(k["pke_sk"])
+        a = ctx.cast_from_pke(ctx.encrypt_public(lfpk, 0xBEEF, 16))
+        b = ctx.cast_from_pke(ctx.encrypt_public(lfpk, 0x1234, 16))
+        assert ctx.decrypt(a) == 0xBEEF and ctx.decrypt(b) == 0x1234            # now under the compute key
+        assert ctx.decrypt(ctx.evaluate("add", 16, a, b)) == (0xBEEF + 0x1234) & 0xFFFF
+        assert ctx.decrypt(ctx.evaluate("lt", 16, a, b)) == 0
+        raw = ctx.encrypt_public(lfpk, 0xBEEF, 16)
+        assert ctx.decrypt(raw) != 0xBEEF                                       # not decryptable before the cast
+    finally:
+        ctx.close()
