@@ -95,13 +95,13 @@ __global__ void __launch_bounds__(NT) k_ntt_inverse(Tables T, const double* __re
         double x[E];
 #pragma unroll
         for (int j = 0; j < E; ++j) x[j] = mmul(in[(poly * 2 + r) * N + own4(t, j)], T.ninv[r], P);
-        gs_radix4x2(x, tw, t, P); norm8(x, P);
+        gs_radix4x2<0xFF, 0xFF>(x, tw, t, P);
         st_o4p34(buf, t, x); __syncthreads(); ld_o3p34(buf, t, x); __syncthreads();
-        gs_radix8<3>(x, tw, base3(t), P);
+        gs_radix8<0, 0xFF, 0xFF>(x, tw, base3(t), P);
         st_o3p23(buf, t, x); __syncthreads(); ld_o2p23(buf, t, x); __syncthreads();
-        gs_radix8<3>(x, tw, base2(t), P);
+        gs_radix8<0, 0xFF, 0xFF>(x, tw, base2(t), P);
         st_o2p12(buf, t, x); __syncthreads(); ld_o1p12(buf, t, x); __syncthreads();
-        gs_radix8<3>(x, tw, 1, P);
+        gs_radix8<0, 0xFF, 0xFF>(x, tw, 1, P);
         if (r == 0) {
 #pragma unroll
             for (int j = 0; j < E; ++j) y0[j] = x[j];
@@ -495,19 +495,19 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q_wide(Tables T, con
 #pragma unroll
             for (int j = 0; j < E; ++j) x[j] = o[j];
         }
-        gs_radix4x2(x, w, P); norm8(x, P);
+        gs_radix4x2<GS_NORM_PASS4[0], GS_NORM_PASS4[1]>(x, w, P);
         __syncthreads();                      // the other half has read this buffer
         st_o4p34(mine, t, x); load_tw8(twi, base3(t), w);
         __syncthreads();
-        ld_o3p34(mine, t, x); gs_radix8(x, w, P);
+        ld_o3p34(mine, t, x); gs_radix8<GS_NORM_PASS3[0], GS_NORM_PASS3[1], GS_NORM_PASS3[2]>(x, w, P);
         __syncthreads();
         st_o3p23(mine, t, x); load_tw8(twi, base2(t), w);
         __syncthreads();
-        ld_o2p23(mine, t, x); gs_radix8<1>(x, w, P);
+        ld_o2p23(mine, t, x); gs_radix8<GS_NORM_PASS2[0], GS_NORM_PASS2[1], GS_NORM_PASS2[2]>(x, w, P);
         __syncthreads();
         st_o2p12(mine, t, x);
         __syncthreads();
-        ld_o1p12(mine, t, x); gs_radix8<2>(x, twi, 1, P);
+        ld_o1p12(mine, t, x); gs_radix8<GS_NORM_PASS1[0], GS_NORM_PASS1[1], GS_NORM_PASS1[2]>(x, twi, 1, P);
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             acc[j] = qp_canon(acc[j] + x[j], P);

@@ -168,44 +168,66 @@ LFHE_HD void ct_radix4x2(double (&x)[8], const double* __restrict__ tw, unsigned
     ct_radix4x2(x, w, P);
 }
 
-LFHE_HD void gs_radix4x2(double (&x)[8], const double (&w)[7], const Prime& P) {
-#pragma unroll
-    for (unsigned k = 0; k < 4; ++k) gs_bfly(x[2 * k], x[2 * k + 1], w[2 + k], P);
-    gs_bfly(x[0], x[2], w[0], P); gs_bfly(x[1], x[3], w[0], P);
-    gs_bfly(x[4], x[6], w[1], P); gs_bfly(x[5], x[7], w[1], P);
-}
-LFHE_HD void gs_radix4x2(double (&x)[8], const double* __restrict__ tw, unsigned t, const Prime& P) {
-    double w[7];
-    load_tw4x2(tw, t, w);
-    gs_radix4x2(x, w, P);
-}
-
 LFHE_HD void norm8(double (&x)[8], const Prime& P) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) x[j] = mnorm(x[j], P);
 }
 
-// NORM_AFTER: 0 none, k = 1..3 normalise after the k-th of the pass's three stages.  A
-// Gentleman-Sande sum doubles the bound per stage, so from centred values (0.5 p) four stages
-// may run before the sums (8 p) must be brought back; the inverse transform places its three
-// normalisations after stages 2, 6 and 10 of 11.
-template <int NORM_AFTER = 0>
+// normalise the registers whose bit is set in MASK
+template <unsigned MASK>
+LFHE_HD void norm_sel(double (&x)[8], const Prime& P) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (MASK & (1u << j)) x[j] = mnorm(x[j], P);
+}
+
+// Where the inverse transform normalises.  A Gentleman-Sande stage turns (a, b) into (a + b,
+// product): the sums grow, the products come back small, so after a few stages only the registers
+// that collected sums are large, and which ones they are depends on the register index only.
+// The masks below (register bits, one per stage of each pass) are the cheapest schedule that keeps
+// every value below 2^53 = 12.79 p in the worst case -- fourteen normalisations per polynomial
+// instead of three times eight -- and leaves the result below 2 p.  tools/lazy_bounds.py derives
+// the bounds (worst 11.75 p) and finds the schedule; tests/test_host_logic.py ties it to these
+// constants.
+constexpr unsigned GS_NORM_PASS4[2] = {0x55, 0x22};
+constexpr unsigned GS_NORM_PASS3[3] = {0x00, 0x00, 0x01};
+constexpr unsigned GS_NORM_PASS2[3] = {0x00, 0x11, 0x0E};
+constexpr unsigned GS_NORM_PASS1[3] = {0x00, 0x00, 0x03};
+
+template <unsigned M1, unsigned M2>
+LFHE_HD void gs_radix4x2(double (&x)[8], const double (&w)[7], const Prime& P) {
+#pragma unroll
+    for (unsigned k = 0; k < 4; ++k) gs_bfly(x[2 * k], x[2 * k + 1], w[2 + k], P);
+    norm_sel<M1>(x, P);
+    gs_bfly(x[0], x[2], w[0], P); gs_bfly(x[1], x[3], w[0], P);
+    gs_bfly(x[4], x[6], w[1], P); gs_bfly(x[5], x[7], w[1], P);
+    norm_sel<M2>(x, P);
+}
+template <unsigned M1, unsigned M2>
+LFHE_HD void gs_radix4x2(double (&x)[8], const double* __restrict__ tw, unsigned t, const Prime& P) {
+    double w[7];
+    load_tw4x2(tw, t, w);
+    gs_radix4x2<M1, M2>(x, w, P);
+}
+
+// M1..M3: registers normalised after the first, second and third stage of the pass
+template <unsigned M1, unsigned M2, unsigned M3>
 LFHE_HD void gs_radix8(double (&x)[8], const double (&w)[7], const Prime& P) {
 #pragma unroll
     for (unsigned k = 0; k < 4; ++k) gs_bfly(x[2 * k], x[2 * k + 1], w[3 + k], P);
-    if (NORM_AFTER == 1) norm8(x, P);
+    norm_sel<M1>(x, P);
     gs_bfly(x[0], x[2], w[1], P); gs_bfly(x[1], x[3], w[1], P);
     gs_bfly(x[4], x[6], w[2], P); gs_bfly(x[5], x[7], w[2], P);
-    if (NORM_AFTER == 2) norm8(x, P);
+    norm_sel<M2>(x, P);
 #pragma unroll
     for (int j = 0; j < 4; ++j) gs_bfly(x[j], x[j + 4], w[0], P);
-    if (NORM_AFTER == 3) norm8(x, P);
+    norm_sel<M3>(x, P);
 }
-template <int NORM_AFTER = 0>
+template <unsigned M1, unsigned M2, unsigned M3>
 LFHE_HD void gs_radix8(double (&x)[8], const double* __restrict__ tw, unsigned b, const Prime& P) {
     double w[7];
     load_tw8(tw, b, w);
-    gs_radix8<NORM_AFTER>(x, w, P);
+    gs_radix8<M1, M2, M3>(x, w, P);
 }
 
 // table index of the first stage of each radix-8 pass

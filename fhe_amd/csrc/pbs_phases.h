@@ -124,28 +124,31 @@ LFHE_HD void ep_phase(EpState& s, double* lds, unsigned t, const Tables& T, cons
 #pragma unroll
             for (int q = 0; q < 4; ++q) { kc[q][0] = kn[q][0]; kc[q][1] = kn[q][1]; }
         }
-        gs_radix4x2(s.x[0], s.tw, P); gs_radix4x2(s.x[1], s.tw, P);
-        norm8(s.x[0], P); norm8(s.x[1], P);
+        gs_radix4x2<GS_NORM_PASS4[0], GS_NORM_PASS4[1]>(s.x[0], s.tw, P);
+        gs_radix4x2<GS_NORM_PASS4[0], GS_NORM_PASS4[1]>(s.x[1], s.tw, P);
     } else if constexpr (ph == 6) {
         st_o4p34(b0, t, s.x[0]); st_o4p34(b1, t, s.x[1]);
         load_tw8(twi, base3(t), s.tw);
     } else if constexpr (ph == 7) {
         ld_o3p34(b0, t, s.x[0]); ld_o3p34(b1, t, s.x[1]);
-        gs_radix8(s.x[0], s.tw, P); gs_radix8(s.x[1], s.tw, P);                 // stages 3-5
+        gs_radix8<GS_NORM_PASS3[0], GS_NORM_PASS3[1], GS_NORM_PASS3[2]>(s.x[0], s.tw, P);     // stages 3-5
+        gs_radix8<GS_NORM_PASS3[0], GS_NORM_PASS3[1], GS_NORM_PASS3[2]>(s.x[1], s.tw, P);
     } else if constexpr (ph == 8) {
         st_o3p23(b0, t, s.x[0]); st_o3p23(b1, t, s.x[1]);
         load_tw8(twi, base2(t), s.tw);
     } else if constexpr (ph == 9) {
         ld_o2p23(b0, t, s.x[0]); ld_o2p23(b1, t, s.x[1]);
-        gs_radix8<1>(s.x[0], s.tw, P); gs_radix8<1>(s.x[1], s.tw, P);           // 6 | 7-8
+        gs_radix8<GS_NORM_PASS2[0], GS_NORM_PASS2[1], GS_NORM_PASS2[2]>(s.x[0], s.tw, P);     // stages 6-8
+        gs_radix8<GS_NORM_PASS2[0], GS_NORM_PASS2[1], GS_NORM_PASS2[2]>(s.x[1], s.tw, P);
     } else if constexpr (ph == 10) {
         st_o2p12(b0, t, s.x[0]); st_o2p12(b1, t, s.x[1]);
     } else {  // ph == 11: inverse pass 1, then keep (prime 0) or lift (prime 1)
         static_assert(ph == 11, "phase out of range");
         ld_o1p12(b0, t, s.x[0]); ld_o1p12(b1, t, s.x[1]);
-        // stages 9-10 | 11: the outputs (|y| <= p) go to the CRT lift as they are; it only needs
-        // residues, not centred ones, because |true value| <= 2^97 < 0.33 p0 p1
-        gs_radix8<2>(s.x[0], twi, 1, P); gs_radix8<2>(s.x[1], twi, 1, P);
+        // stages 9-11: the outputs (|y| < 2 p) go to the CRT lift or the accumulator as they are; the
+        // lift only needs residues, not centred ones, because |true value| <= 2^97 < 0.33 p0 p1
+        gs_radix8<GS_NORM_PASS1[0], GS_NORM_PASS1[1], GS_NORM_PASS1[2]>(s.x[0], twi, 1, P);
+        gs_radix8<GS_NORM_PASS1[0], GS_NORM_PASS1[1], GS_NORM_PASS1[2]>(s.x[1], twi, 1, P);
         if constexpr (SINGLE) {
         } else if constexpr (r == 0) {
 #pragma unroll

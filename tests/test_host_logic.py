@@ -107,3 +107,20 @@ def test_two_rank_layout_gloo():
     assert cut0 == (0, 501) and cut1 == (501, 1001)
     assert part0 + part1 == [(7 * i + 3) % 16 for i in range(1001)]
     assert t0 == t1 == 2.0                          # max over ranks
+
+
+def test_lazy_reduction_schedule_stays_exact():
+    """The per-register normalisation masks compiled into the kernels keep every lazily reduced
+    value below 2^53 in the worst case (bound model: tools/lazy_bounds.py) and hand the
+    accumulator update a value below 2 p."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("lazy_bounds", os.path.join(root, "tools", "lazy_bounds.py"))
+    lb = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lb)
+    worst, final, norms = lb.check_header(os.path.join(root, "fhe_amd", "csrc", "pbs_device.h"))
+    assert worst < lb.LIMIT and final <= 2.0 and norms == 14
+    # the earlier schedule (everything after stages 2, 6, 10) does not pass this model
+    allr = set(range(8))
+    w_old, _, n_old = lb.inverse({(0, 1): allr, (2, 0): allr, (3, 1): allr}, 2 * lb.prod(lb.forward()[-1]))
+    assert w_old > lb.LIMIT and n_old == 24

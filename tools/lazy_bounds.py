@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Worst-case magnitude bounds (in units of p) of the lazily reduced transforms of pbs_device.h.
+
+Every value is an exact integer carried in an f64 and must stay below 2^53 = 12.79 p.
+  * modular product r = b*w - rint(fl(fl(b*w) * fl(1/p))) * p with |w| <= p/2: the quotient estimate
+    carries three roundings, so |r| <= (0.5 + C |b|/p) p with C = (p/2) * 3 * 2^-53 = 0.1172;
+  * Cooley-Tukey butterfly (a, b) -> (a + t, a - t), t = b*w: both outputs <= |a| + P(|b|);
+  * Gentleman-Sande butterfly (a, b) -> (a + b, (a - b)*w): outputs |a| + |b| and P(|a| + |b|);
+  * a normalisation brings a value to 0.5 p (+ 1e-9);
+  * an LDS exchange mixes registers between threads: afterwards every register carries the
+    largest bound any register had.
+The script prints the bound after every stage for a normalisation schedule and checks the limit.
+Run with --search to look for the cheapest per-register schedule."""
+import itertools
+import sys
+
+P_ = 703687441727489.0
+LIMIT = 2.0 ** 53 / P_ - 0.05
+C = (P_ / 2) * 3 * 2.0 ** -53
+NORM = 0.5 + 1e-9
+
+
+def prod(b):
+    return 0.5 + C * b
+
+
+def forward(start=2.0 ** 22 / P_):
+    """11 Cooley-Tukey stages from digits |d| <= 2^22, no normalisation."""
+    b = start
+    out = []
+    for _ in range(11):
+        b = b + prod(b)
+        out.append(b)
+    return out
+
+
+PASS4 = [[(0, 1), (2, 3), (4, 5), (6, 7)], [(0, 2), (1, 3), (4, 6), (5, 7)]]
+PASS8 = PASS4 + [[(0, 4), (1, 5), (2, 6), (3, 7)]]
+
+
+def inverse(schedule, start, verbose=False):
+    """schedule: dict (pass index 0..3, stage index within pass) -> set of registers normalised
+    AFTER that stage.  Returns (worst bound seen, final bounds, number of normalisations)."""
+    x = [start] * 8
+    worst, norms = start, 0
+    for pi, stages in enumerate([PASS4, PASS8, PASS8, PASS8]):
+        for si, pairs in enumerate(stages):
+            for a, b in pairs:
+                s = x[a] + x[b]
+                worst = max(worst, s)
+                x[a], x[b] = s, prod(s)
+            for r in schedule.get((pi, si), ()):
+                x[r] = NORM
+                norms += 1
+            if verbose:
+                print(f"  pass {4 - pi} stage {si + 1}: " + " ".join(f"{v:6.2f}" for v in x))
+        if pi < 3:
+            x = [max(x)] * 8   # exchange
+    return worst, x, norms
+
+
+def schedule_from_header(path):
+    """The GS_NORM_PASS* masks of pbs_device.h as a schedule."""
+    import re
+    text = open(path).read()
+    sched = {}
+    for pi, name in enumerate(("GS_NORM_PASS4", "GS_NORM_PASS3", "GS_NORM_PASS2", "GS_NORM_PASS1")):
+        m = re.search(name + r"\[\d\] = \{([^}]*)\}", text)
+        for si, tok in enumerate(m.group(1).split(",")):
+            mask = int(tok.strip(), 0)
+            if mask:
+                sched[(pi, si)] = {r for r in range(8) if mask >> r & 1}
+    return sched
+
+
+def check_header(path):
+    """(worst bound, final bound, normalisations per polynomial) of the schedule compiled into the kernels."""
+    f = forward()
+    assert f[-1] < LIMIT and forward(0.5)[-1] < LIMIT        # digits, and canonical inputs (key preparation)
+    w, x, n = inverse(schedule_from_header(path), 2 * prod(f[-1]))
+    return w, max(x), n
+
+
+def main():
+    f = forward()
+    print("forward, bound after each stage:", " ".join(f"{v:.2f}" for v in f))
+    assert f[-1] < LIMIT
+    pw = 2 * prod(f[-1])
+    print(f"point-wise sum of two products: {pw:.2f} p   (limit {LIMIT:.2f} p)")
+    import os
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fhe_amd", "csrc", "pbs_device.h")
+    allr = set(range(8))
+    for name, sch in (("three full normalisations after stages 2, 6, 10", {(0, 1): allr, (2, 0): allr, (3, 1): allr}),
+                      ("schedule in pbs_device.h", schedule_from_header(hdr))):
+        w, x, n = inverse(sch, pw, verbose=True)
+        print(f"{name}: worst {w:.2f} p, final {max(x):.2f} p, {n} normalisations ->", "OK" if w < LIMIT else "OVER")
+    if "--search" in sys.argv:
+        best = None
+        # per stage: normalise registers whose bound exceeds a threshold (one threshold per pass end,
+        # plus optional mid-pass thresholds)
+        grid = [1.25, 2.0, 3.3, 99.0]
+        slots = [(0, 0), (0, 1), (1, 1), (1, 2), (2, 0), (2, 1), (2, 2), (3, 0), (3, 1), (3, 2)]
+        for ths in itertools.product(grid, repeat=len(slots)):
+            x = [pw] * 8
+            worst, norms, ok, sched = pw, 0, True, {}
+            for pi, stages in enumerate([PASS4, PASS8, PASS8, PASS8]):
+                for si, pairs in enumerate(stages):
+                    for a, b in pairs:
+                        s = x[a] + x[b]
+                        worst = max(worst, s)
+                        x[a], x[b] = s, prod(s)
+                    if worst >= LIMIT:
+                        ok = False
+                        break
+                    if (pi, si) in slots:
+                        th = ths[slots.index((pi, si))]
+                        regs = {r for r in range(8) if x[r] > th}
+                        for r in regs:
+                            x[r] = NORM
+                        norms += len(regs)
+                        if regs:
+                            sched[(pi, si)] = regs
+                if not ok:
+                    break
+                if pi < 3:
+                    x = [max(x)] * 8
+            if ok and max(x) <= 2.0 and (best is None or norms < best[0]):
+                best = (norms, sched, worst, max(x))
+        print("cheapest schedule found:", best)
+
+
+if __name__ == "__main__":
+    main()
