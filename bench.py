@@ -38,13 +38,6 @@ TRAFFIC_BYTES_4096 = {"prime": (2 * 3808307 + 196800) * 1024, "q64": (2 * 790966
 BSK_BYTES, KSK_BYTES, CT_BYTES = 60162048, 60227584, 16392
 
 
-class _DevMem:
-    """Zero-copy view of library-owned device memory for torch (cuda array interface)."""
-
-    def __init__(self, ptr: int, nbytes: int):
-        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
-
-
 def cpu_baseline(seconds_budget: float = 20.0, prime_bsk: bool = False):
     """The CPU oracle (own port; the reference engine is not available offline) timed on the host
     cores of this box on a bounded sample of the same workload."""
@@ -89,8 +82,7 @@ def main():
     args = ap.parse_args()
 
     import torch
-    from fhe_amd.native import Context, KEY_CLIENT
-    from fhe_amd.sharding import max_over_ranks, replicate, replicate_blob
+    from fhe_amd.sharding import max_over_ranks, replicated_context
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -111,31 +103,7 @@ def main():
 
     def make_context(prime: bool):
         """Context with keys on every rank: generated on rank 0, device images broadcast once."""
-        ctx = Context(seed=seed, device=local, params_id=2 if prime else 1)
-        keep = []  # tensors whose memory the context points at
-        client_blob = None
-        if rank == 0:
-            ctx.keygen()
-            client_blob = ctx.export_keys(KEY_CLIENT)
-        if world > 1:
-            # one broadcast per key image, straight out of / into device memory
-            bsk_bytes, ksk_bytes = ctx.device_keys_size()
-            if rank == 0:
-                bp, _, kp, _ = ctx.device_keys()
-                tb = torch.as_tensor(_DevMem(bp, bsk_bytes), device=dev)
-                tk = torch.as_tensor(_DevMem(kp, ksk_bytes), device=dev)
-            else:
-                tb = torch.empty(bsk_bytes, dtype=torch.uint8, device=dev)
-                tk = torch.empty(ksk_bytes, dtype=torch.uint8, device=dev)
-            replicate(dist, [tb, tk])
-            torch.cuda.synchronize()
-            if rank != 0:
-                ctx.attach_device_keys(tb.data_ptr(), tk.data_ptr())
-                keep += [tb, tk]
-            blob = replicate_blob(dist, client_blob if rank == 0 else None)
-            if rank != 0:
-                ctx.import_keys(KEY_CLIENT, blob)
-        return ctx, keep
+        return replicated_context(dist, rank, world, dev, seed, 2 if prime else 1)
 
     B = args.batch
     f = [lambda x: x, lambda x: (5 * x + 3) % 16]

@@ -32,3 +32,43 @@ def max_over_ranks(dist, value: float, device=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+class _DevMem:
+    """Zero-copy view of library-owned device memory for torch (cuda array interface)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def replicated_context(dist, rank: int, world: int, device, seed: bytes, params_id: int):
+    """A context with the same key set on every rank: rank 0 generates the keys, the two device key
+    images go out with one broadcast each (straight out of / into device memory), the client key
+    follows as a small host object.  Returns (context, tensors the context points at): keep the
+    tensors alive as long as the context."""
+    import torch
+    from .native import Context, KEY_CLIENT
+    ctx = Context(seed=seed, device=device.index or 0, params_id=params_id)
+    keep = []
+    blob = None
+    if rank == 0:
+        ctx.keygen()
+        blob = ctx.export_keys(KEY_CLIENT)
+    if world > 1:
+        bsk_bytes, ksk_bytes = ctx.device_keys_size()
+        if rank == 0:
+            bp, _, kp, _ = ctx.device_keys()
+            tb = torch.as_tensor(_DevMem(bp, bsk_bytes), device=device)
+            tk = torch.as_tensor(_DevMem(kp, ksk_bytes), device=device)
+        else:
+            tb = torch.empty(bsk_bytes, dtype=torch.uint8, device=device)
+            tk = torch.empty(ksk_bytes, dtype=torch.uint8, device=device)
+        replicate(dist, [tb, tk])
+        torch.cuda.synchronize()
+        if rank != 0:
+            ctx.attach_device_keys(tb.data_ptr(), tk.data_ptr())
+            keep += [tb, tk]
+        blob = replicate_blob(dist, blob if rank == 0 else None)
+        if rank != 0:
+            ctx.import_keys(KEY_CLIENT, blob)
+    return ctx, keep

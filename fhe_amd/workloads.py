@@ -1,0 +1,58 @@
+"""The operator workloads of the benchmark configurations, written against the engine surface
+(`evaluate_batch`, `encrypt`) so that they run on the GPU context and, in the CPU tests, on a
+plaintext stand-in.  Sharding follows fhe_amd/sharding.py: every rank owns a contiguous slice of
+the independent instances, there is no collective on the data path; only the argmax needs one
+exchange, of one (value, index) pair per rank, at the very end.
+
+  * transfers: the confidential-ERC20 transfer (tests/fhevm-suite/e2e/contracts/EncryptedERC20.sol:
+    87-93, 208-220): ok = amount <= from; v = ok ? amount : 0; from -= v; to += v.
+  * argmax: a blind-auction tournament over encrypted bids: per pair gt + select(value) +
+    select(index).
+"""
+from __future__ import annotations
+
+from .sharding import shard_bounds
+
+
+def transfers(backend, bal_from: list, bal_to: list, amount: list, zero, width: int = 64):
+    """(new_from[], new_to[]) for n independent transfers; four batched operator calls."""
+    n = len(amount)
+    if n == 0:
+        return [], []
+    ok = backend.evaluate_batch("le", width, amount, bal_from)
+    v = backend.evaluate_batch("select", width, amount, [zero] * n, ok)
+    return backend.evaluate_batch("sub", width, bal_from, v), backend.evaluate_batch("add", width, bal_to, v)
+
+
+def argmax(backend, vals: list, idxs: list, width: int = 32, idx_width: int = 16):
+    """(max value, its index) by a binary tournament; ties keep the right-hand entry's rival, i.e.
+    the strictly greater left value wins."""
+    vals, idxs = list(vals), list(idxs)
+    if not vals:
+        raise ValueError("empty tournament")
+    while len(vals) > 1:
+        half = len(vals) // 2
+        L, R = vals[:half], vals[half:2 * half]
+        LI, RI = idxs[:half], idxs[half:2 * half]
+        g = backend.evaluate_batch("gt", width, L, R)
+        nv = backend.evaluate_batch("select", width, L, R, g)
+        ni = backend.evaluate_batch("select", idx_width, LI, RI, g)
+        vals, idxs = nv + vals[2 * half:], ni + idxs[2 * half:]
+    return vals[0], idxs[0]
+
+
+def sharded_argmax(dist, backend, vals: list, idxs: list, rank: int, world: int, width: int = 32,
+                   idx_width: int = 16):
+    """Every rank reduces its own slice of the bids, the (at most `world`) shard winners are gathered
+    host-side and reduced on rank 0.  `vals` / `idxs` are the full lists on every rank (a rank only
+    touches its slice).  Returns the winner on rank 0, None elsewhere."""
+    lo, hi = shard_bounds(len(vals), world, rank)
+    mine = argmax(backend, vals[lo:hi], idxs[lo:hi], width, idx_width) if hi > lo else None
+    if dist is None or world == 1:
+        return mine
+    box = [None] * world
+    dist.all_gather_object(box, mine)
+    if rank != 0:
+        return None
+    winners = [w for w in box if w is not None]
+    return argmax(backend, [w[0] for w in winners], [w[1] for w in winners], width, idx_width)

@@ -109,6 +109,64 @@ def test_two_rank_layout_gloo():
     assert t0 == t1 == 2.0                          # max over ranks
 
 
+def _workload_rank(rank, world, port, q):
+    """Sharded transfers and the sharded argmax on the plaintext stand-in, gloo."""
+    import random
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from fhe_amd import workloads
+    from fhe_amd.sharding import shard_bounds
+    from tests.mock_engine import MockBackend
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B = MockBackend()
+    rnd = random.Random(5)
+    n = 37                                              # ragged: slices of 19 and 18
+    bids = rnd.sample(range(1 << 32), n)
+    lo, hi = shard_bounds(n, world, rank)
+    vals = [B.encrypt(v, 32) if lo <= i < hi else None for i, v in enumerate(bids)]
+    idxs = [B.encrypt(i, 16) if lo <= i < hi else None for i in range(n)]
+    win = workloads.sharded_argmax(dist, B, vals, idxs, rank, world)
+    got = None if win is None else (B.decrypt(win[0]), B.decrypt(win[1]))
+    frm = [rnd.randrange(1000) for _ in range(n)]
+    to = [rnd.randrange(1000) for _ in range(n)]
+    amt = [rnd.randrange(1500) for _ in range(n)]
+    enc = lambda vs: [B.encrypt(v, 64) for v in vs[lo:hi]]
+    nf, nt = workloads.transfers(B, enc(frm), enc(to), enc(amt), B.encrypt(0, 64))
+    q.put((rank, got, (max(bids), bids.index(max(bids))), [B.decrypt(c) for c in nf], [B.decrypt(c) for c in nt],
+           frm, to, amt, (lo, hi)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_workloads_two_ranks_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_workload_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][1] == got[0][2] and got[1][1] is None      # rank 0 holds the winner
+    for rank, _, _, nf, nt, frm, to, amt, (lo, hi) in got:
+        moved = [a if a <= f else 0 for a, f in zip(amt[lo:hi], frm[lo:hi])]
+        assert nf == [f - v for f, v in zip(frm[lo:hi], moved)]
+        assert nt == [t + v for t, v in zip(to[lo:hi], moved)]
+    # one rank, no process group: the same functions
+    from fhe_amd import workloads
+    from tests.mock_engine import MockBackend
+    B = MockBackend()
+    w = workloads.sharded_argmax(None, B, [B.encrypt(v, 32) for v in (5, 9, 2)], [B.encrypt(i, 16) for i in range(3)], 0, 1)
+    assert (B.decrypt(w[0]), B.decrypt(w[1])) == (9, 1)
+    assert workloads.transfers(B, [], [], [], B.encrypt(0, 64)) == ([], [])
+
+
 def test_lazy_reduction_schedule_stays_exact():
     """The per-register normalisation masks compiled into the kernels keep every lazily reduced
     value below 2^53 in the worst case (bound model: tools/lazy_bounds.py) and hand the
