@@ -6,6 +6,7 @@
 #include <cstring>
 #include <map>
 #include <stdexcept>
+#include <string>
 #include <thread>
 #include <tuple>
 
@@ -90,6 +91,7 @@ struct Compiled {
 typedef std::array<uint8_t, 32> Scalar;
 struct lfhe_radix {
     std::map<std::tuple<uint32_t, uint32_t, int, int, int, bool, Scalar>, std::unique_ptr<Compiled>> cache;
+    std::map<std::string, std::unique_ptr<Compiled>> fused;   // key: the bytes of the request's shape
 };
 
 lfhe_ctx::lfhe_ctx() = default;
@@ -99,6 +101,38 @@ lfhe_ctx::~lfhe_ctx() {
 }
 
 namespace {
+
+// descriptors and tables of a program to the device
+void upload_program(lfhe_ctx* ctx, Compiled& C) {
+    Engine& E = *ctx->eng;
+    HC(hipSetDevice(E.device()));
+    const Program& P = C.prog;
+    std::vector<u64> bodies(P.luts.size() * (size_t)N);
+    for (size_t i = 0; i < P.luts.size(); ++i)
+        make_lut_body(ctx->space(), ctx->delta(), P.luts[i].data(), bodies.data() + i * N);
+    if (!bodies.empty()) {
+        HC(hipMalloc(&C.d_luts, bodies.size() * 8));
+        HC(hipMemcpy(C.d_luts, bodies.data(), bodies.size() * 8, hipMemcpyHostToDevice));
+    }
+    for (const Layer& L : P.layers) {
+        LinOp* dl = nullptr;
+        if (!L.lin.empty()) {
+            HC(hipMalloc(&dl, L.lin.size() * sizeof(LinOp)));
+            HC(hipMemcpy(dl, L.lin.data(), L.lin.size() * sizeof(LinOp), hipMemcpyHostToDevice));
+        }
+        C.d_lin.push_back(dl);
+        u32 *di = nullptr, *dout = nullptr, *dlut = nullptr;
+        if (!L.pbs.empty()) {
+            std::vector<u32> a, b, l;
+            for (const PbsOp& q : L.pbs) { a.push_back(q.in); b.push_back(q.out); l.push_back(q.lut); }
+            HC(hipMalloc(&di, a.size() * 4)); HC(hipMalloc(&dout, a.size() * 4)); HC(hipMalloc(&dlut, a.size() * 4));
+            HC(hipMemcpy(di, a.data(), a.size() * 4, hipMemcpyHostToDevice));
+            HC(hipMemcpy(dout, b.data(), a.size() * 4, hipMemcpyHostToDevice));
+            HC(hipMemcpy(dlut, l.data(), a.size() * 4, hipMemcpyHostToDevice));
+        }
+        C.d_in.push_back(di); C.d_out.push_back(dout); C.d_lut.push_back(dlut);
+    }
+}
 
 // programs specialised on a clear right operand: shift and rotation amounts, divisors
 bool specialised_op(uint32_t op) {
@@ -116,34 +150,7 @@ Compiled& compiled_for(lfhe_ctx* ctx, uint32_t op, uint32_t width, int ln, int r
     if (it != ctx->radix->cache.end()) return *it->second;
     std::unique_ptr<Compiled> c(new Compiled());
     c->prog = build_program(op, width, ln, rn, cn, scalar);
-    Engine& E = *ctx->eng;
-    HC(hipSetDevice(E.device()));
-    const Program& P = c->prog;
-    std::vector<u64> bodies(P.luts.size() * (size_t)N);
-    for (size_t i = 0; i < P.luts.size(); ++i)
-        make_lut_body(ctx->space(), ctx->delta(), P.luts[i].data(), bodies.data() + i * N);
-    if (!bodies.empty()) {
-        HC(hipMalloc(&c->d_luts, bodies.size() * 8));
-        HC(hipMemcpy(c->d_luts, bodies.data(), bodies.size() * 8, hipMemcpyHostToDevice));
-    }
-    for (const Layer& L : P.layers) {
-        LinOp* dl = nullptr;
-        if (!L.lin.empty()) {
-            HC(hipMalloc(&dl, L.lin.size() * sizeof(LinOp)));
-            HC(hipMemcpy(dl, L.lin.data(), L.lin.size() * sizeof(LinOp), hipMemcpyHostToDevice));
-        }
-        c->d_lin.push_back(dl);
-        u32 *di = nullptr, *dout = nullptr, *dlut = nullptr;
-        if (!L.pbs.empty()) {
-            std::vector<u32> a, b, l;
-            for (const PbsOp& q : L.pbs) { a.push_back(q.in); b.push_back(q.out); l.push_back(q.lut); }
-            HC(hipMalloc(&di, a.size() * 4)); HC(hipMalloc(&dout, a.size() * 4)); HC(hipMalloc(&dlut, a.size() * 4));
-            HC(hipMemcpy(di, a.data(), a.size() * 4, hipMemcpyHostToDevice));
-            HC(hipMemcpy(dout, b.data(), a.size() * 4, hipMemcpyHostToDevice));
-            HC(hipMemcpy(dlut, l.data(), a.size() * 4, hipMemcpyHostToDevice));
-        }
-        c->d_in.push_back(di); c->d_out.push_back(dout); c->d_lut.push_back(dlut);
-    }
+    upload_program(ctx, *c);
     Compiled& ref = *c;
     ctx->radix->cache[key] = std::move(c);
     return ref;
@@ -156,6 +163,8 @@ int check_operand(const uint8_t* base, uint64_t n, uint32_t width) {
     for (uint64_t i = 0; i < n; ++i) noise = std::max<int>(noise, parse_header(base + i * stride, width).noise_level);
     return noise;
 }
+
+void replay(lfhe_ctx* ctx, Compiled& C, u64* arena, uint64_t n);
 
 void cast_one(lfhe_ctx* ctx, const uint8_t* in, uint64_t in_len, uint32_t to_width, uint8_t* out) {
     if (in_len < sizeof(CtHeader)) throw std::invalid_argument("ciphertext too short");
@@ -226,14 +235,7 @@ void run_batch(lfhe_ctx* ctx, uint32_t op, uint32_t width, uint64_t n, const uin
     }
     if (op == LFHE_OP_SELECT) upload(cond, ct_bytes(1), P.cond[0], 1);
 
-    for (size_t l = 0; l < P.layers.size(); ++l) {
-        const Layer& L = P.layers[l];
-        E.lin_layer(arena.p, n, P.nblocks, C.d_lin[l], (int)L.lin.size(), ctx->delta());
-        if (!L.pbs.empty()) {
-            E.pbs_layer(arena.p, n, P.nblocks, C.d_in[l], C.d_out[l], C.d_lut[l], (u32)L.pbs.size(), C.d_luts);
-            ctx->pbs_count += n * L.pbs.size();
-        }
-    }
+    replay(ctx, C, arena.p, n);
     const uint64_t out_stride = ct_bytes(P.out_width);
     for (size_t j = 0; j < P.out.size(); ++j)
         HC(hipMemcpy2DAsync(out + sizeof(CtHeader) + j * BLK_BYTES, out_stride,
@@ -242,6 +244,81 @@ void run_batch(lfhe_ctx* ctx, uint32_t op, uint32_t width, uint64_t n, const uin
     E.sync();
     CtHeader h{CT_MAGIC, 1, (uint16_t)P.out_width, (uint32_t)P.out.size(), P.out_noise, P.out_degree, 0};
     for (uint64_t i = 0; i < n; ++i) std::memcpy(out + i * out_stride, &h, sizeof h);
+}
+
+// replay of a compiled program over an arena holding `n` instances
+void replay(lfhe_ctx* ctx, Compiled& C, u64* arena, uint64_t n) {
+    Engine& E = *ctx->eng;
+    const Program& P = C.prog;
+    for (size_t l = 0; l < P.layers.size(); ++l) {
+        const Layer& L = P.layers[l];
+        E.lin_layer(arena, n, P.nblocks, C.d_lin[l], (int)L.lin.size(), ctx->delta());
+        if (!L.pbs.empty()) {
+            E.pbs_layer(arena, n, P.nblocks, C.d_in[l], C.d_out[l], C.d_lut[l], (u32)L.pbs.size(), C.d_luts);
+            ctx->pbs_count += n * L.pbs.size();
+        }
+    }
+}
+
+void run_fused(lfhe_ctx* ctx, const lfhe_step* steps, uint32_t nsteps, uint32_t n_inputs, const uint32_t* in_widths,
+               uint64_t n, const uint8_t* const* inputs, const int32_t* outputs, uint32_t n_outputs,
+               uint8_t* const* outs) {
+    if (!steps || !nsteps || !in_widths || !inputs || !outputs || !n_outputs || !outs)
+        throw std::invalid_argument("null or empty argument");
+    if (!n) return;
+    if (!ctx->eng->has_keys()) throw std::logic_error("server keys not loaded");
+    std::vector<uint32_t> widths(in_widths, in_widths + n_inputs);
+    std::vector<int> noises(n_inputs);
+    for (uint32_t i = 0; i < n_inputs; ++i) {
+        if (!width_ok(widths[i]) || !inputs[i]) throw std::invalid_argument("bad input");
+        noises[i] = check_operand(inputs[i], n, widths[i]);
+    }
+    std::string key((const char*)steps, nsteps * sizeof(lfhe_step));
+    key.append((const char*)widths.data(), widths.size() * 4);
+    key.append((const char*)noises.data(), noises.size() * sizeof(int));
+    key.append((const char*)outputs, n_outputs * 4);
+    if (!ctx->radix) ctx->radix.reset(new lfhe_radix());
+    auto it = ctx->radix->fused.find(key);
+    if (it == ctx->radix->fused.end()) {
+        std::vector<FusedStep> fs(nsteps);
+        for (uint32_t k = 0; k < nsteps; ++k) {
+            fs[k].op = steps[k].op; fs[k].width = steps[k].bit_width;
+            fs[k].lhs = steps[k].lhs; fs[k].rhs = steps[k].rhs; fs[k].cond = steps[k].cond;
+            fs[k].rhs_is_scalar = steps[k].rhs_is_scalar;
+            std::memcpy(fs[k].scalar, steps[k].scalar, 32);
+            if (!width_ok(fs[k].width)) throw std::invalid_argument("unsupported bit width");
+        }
+        std::unique_ptr<Compiled> c(new Compiled());
+        c->prog = build_fused(fs, widths, noises, std::vector<int32_t>(outputs, outputs + n_outputs));
+        upload_program(ctx, *c);
+        it = ctx->radix->fused.emplace(key, std::move(c)).first;
+    }
+    Compiled& C = *it->second;
+    const Program& P = C.prog;
+    Engine& E = *ctx->eng;
+    HC(hipSetDevice(E.device()));
+    hipStream_t st = E.stream();
+    const size_t inst_bytes = (size_t)P.nblocks * BLK_BYTES;
+    DevBuf<u64> arena(n * (size_t)P.nblocks * BLK_WORDS);
+    for (uint32_t i = 0; i < n_inputs; ++i)
+        HC(hipMemcpy2DAsync(reinterpret_cast<uint8_t*>(arena.p) + (size_t)P.ins[i][0] * BLK_BYTES, inst_bytes,
+                            inputs[i] + sizeof(CtHeader), ct_bytes(widths[i]), (size_t)blocks_of(widths[i]) * BLK_BYTES, n,
+                            hipMemcpyHostToDevice, st));
+    replay(ctx, C, arena.p, n);
+    for (uint32_t o = 0; o < n_outputs; ++o) {
+        if (!outs[o]) throw std::invalid_argument("null output");
+        const uint64_t stride = ct_bytes(P.out_widths[o]);
+        for (size_t j = 0; j < P.outs[o].size(); ++j)
+            HC(hipMemcpy2DAsync(outs[o] + sizeof(CtHeader) + j * BLK_BYTES, stride,
+                                reinterpret_cast<uint8_t*>(arena.p) + (size_t)P.outs[o][j] * BLK_BYTES, inst_bytes,
+                                BLK_BYTES, n, hipMemcpyDeviceToHost, st));
+    }
+    E.sync();
+    for (uint32_t o = 0; o < n_outputs; ++o) {
+        const uint64_t stride = ct_bytes(P.out_widths[o]);
+        CtHeader h{CT_MAGIC, 1, (uint16_t)P.out_widths[o], (uint32_t)P.outs[o].size(), P.out_noises[o], P.out_degrees[o], 0};
+        for (uint64_t i = 0; i < n; ++i) std::memcpy(outs[o] + i * stride, &h, sizeof h);
+    }
 }
 
 }  // namespace
@@ -561,6 +638,50 @@ int32_t lfhe_evaluate_batch(lfhe_ctx* ctx, uint32_t op, uint32_t bit_width, uint
     });
     if (rc == LFHE_ERR_ARG && ctx->err == "operator not supported") rc = LFHE_ERR_UNSUPPORTED;
     return rc;
+}
+
+int32_t lfhe_evaluate_fused(lfhe_ctx* ctx, const lfhe_step* steps, uint32_t nsteps, uint32_t n_inputs,
+                            const uint32_t* input_widths, uint64_t n, const uint8_t* const* inputs,
+                            const int32_t* outputs, uint32_t n_outputs, uint8_t* const* outs) {
+    int32_t rc = guarded(ctx, [&]() -> int32_t {
+        run_fused(ctx, steps, nsteps, n_inputs, input_widths, n, inputs, outputs, n_outputs, outs);
+        return LFHE_OK;
+    });
+    if (rc == LFHE_ERR_ARG && ctx->err == "operator not supported") rc = LFHE_ERR_UNSUPPORTED;
+    return rc;
+}
+
+int32_t lfhe_fused_dump(const lfhe_step* steps, uint32_t nsteps, uint32_t n_inputs, const uint32_t* input_widths,
+                        const int32_t* input_noise, const int32_t* outputs, uint32_t n_outputs, char* out,
+                        uint64_t* out_len) {
+    if (!steps || !input_widths || !outputs || !out_len) return LFHE_ERR_ARG;
+    std::string js;
+    try {
+        std::vector<FusedStep> fs(nsteps);
+        for (uint32_t k = 0; k < nsteps; ++k) {
+            fs[k].op = steps[k].op; fs[k].width = steps[k].bit_width;
+            fs[k].lhs = steps[k].lhs; fs[k].rhs = steps[k].rhs; fs[k].cond = steps[k].cond;
+            fs[k].rhs_is_scalar = steps[k].rhs_is_scalar;
+            std::memcpy(fs[k].scalar, steps[k].scalar, 32);
+            if (!width_ok(fs[k].width)) return LFHE_ERR_ARG;
+        }
+        std::vector<int> noise(n_inputs, 1);
+        if (input_noise) noise.assign(input_noise, input_noise + n_inputs);
+        js = build_fused(fs, std::vector<uint32_t>(input_widths, input_widths + n_inputs), noise,
+                         std::vector<int32_t>(outputs, outputs + n_outputs)).to_json();
+    } catch (const std::domain_error&) {
+        return LFHE_ERR_ARG;
+    } catch (const std::invalid_argument& e) {
+        return std::string(e.what()) == "operator not supported" ? LFHE_ERR_UNSUPPORTED : LFHE_ERR_ARG;
+    } catch (const std::exception&) {
+        return LFHE_ERR_STATE;
+    }
+    const uint64_t need = js.size() + 1;
+    if (!out) { *out_len = need; return LFHE_OK; }
+    if (*out_len < need) { *out_len = need; return LFHE_ERR_SIZE; }
+    std::memcpy(out, js.c_str(), need);
+    *out_len = need;
+    return LFHE_OK;
 }
 
 int32_t lfhe_evaluate(lfhe_ctx* ctx, uint32_t op, uint32_t bit_width, const uint8_t* lhs, uint64_t lhs_len,

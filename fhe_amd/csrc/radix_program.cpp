@@ -99,6 +99,13 @@ std::string Program::to_json() const {
     o << "{\"op\":" << op << ",\"width\":" << width << ",\"out_width\":" << out_width << ",\"rhs_width\":" << rhs_width << ",\"nblocks\":" << nblocks
       << ",\"out_noise\":" << (int)out_noise << ",\"pbs\":" << pbs_per_instance() << ",\"lhs\":";
     list(lhs); o << ",\"rhs\":"; list(rhs); o << ",\"cond\":"; list(cond); o << ",\"out\":"; list(out);
+    auto lists = [&](const char* key, const std::vector<std::vector<uint32_t>>& vv) {
+        o << ",\"" << key << "\":[";
+        for (size_t i = 0; i < vv.size(); ++i) { o << (i ? "," : ""); list(vv[i]); }
+        o << "]";
+    };
+    lists("ins", ins); lists("outs", outs);
+    o << ",\"in_widths\":"; list(in_widths); o << ",\"out_widths\":"; list(out_widths);
     o << ",\"luts\":[";
     for (size_t i = 0; i < luts.size(); ++i) {
         o << (i ? "," : "") << "[";
@@ -521,6 +528,57 @@ void op_divrem_clear(Builder& B, const Blocks& a0, const Nat& d, Blocks* quot, B
 
 }  // namespace
 
+// One operator on blocks that already exist in the builder.  b: right operand blocks (encrypted, or
+// the constant blocks of a clear operand); scalar: the clear right operand, for the operators whose
+// schedule is specialised on it (shift / rotation amounts, divisors), else null.
+static Blocks apply_op(Builder& B, uint32_t op, uint32_t width, const Blocks& a, const Blocks& b, uint32_t cond,
+                       const uint8_t* scalar, uint32_t& out_width) {
+    const int deg = width == 1 ? 1 : 3;
+    const bool shift = op == LFHE_OP_SHL || op == LFHE_OP_SHR || op == LFHE_OP_ROTL || op == LFHE_OP_ROTR;
+    const bool divrem = op == LFHE_OP_DIV || op == LFHE_OP_REM;
+    if ((shift || divrem) && width == 1) throw std::invalid_argument("operator not supported");
+    if (divrem && !scalar) throw std::invalid_argument("operator not supported");  // clear divisor only
+    out_width = width;
+    Blocks out;
+    switch (op) {
+        case LFHE_OP_ADD: return op_add(B, a, b);
+        case LFHE_OP_SUB: return op_sub(B, a, b);
+        case LFHE_OP_NEG: return op_neg(B, a);
+        case LFHE_OP_MUL: return op_mul(B, a, b);
+        case LFHE_OP_AND: case LFHE_OP_OR: case LFHE_OP_XOR: return op_bitwise(B, a, b, op);
+        case LFHE_OP_NOT:
+            for (uint32_t blk : a) out.push_back(B.mat(Builder::sub(Builder::C(deg), B.E(blk))));
+            return out;
+        case LFHE_OP_EQ: out_width = 1; return {op_eq(B, a, b, false)};
+        case LFHE_OP_NE: out_width = 1; return {op_eq(B, a, b, true)};
+        case LFHE_OP_GE: case LFHE_OP_GT: case LFHE_OP_LE: case LFHE_OP_LT:
+            out_width = 1;
+            return {op_cmp(B, a, b, op)};
+        case LFHE_OP_MIN: return op_select(B, op_cmp(B, a, b, LFHE_OP_LT), a, b);
+        case LFHE_OP_MAX: return op_select(B, op_cmp(B, a, b, LFHE_OP_GT), a, b);
+        case LFHE_OP_SELECT: return op_select(B, cond, a, b);
+        case LFHE_OP_SHL: case LFHE_OP_SHR: case LFHE_OP_ROTL: case LFHE_OP_ROTR:
+            if (scalar) {
+                long t = 0;  // amount modulo the width (a divisor of 2^16 * 5 for every supported width)
+                for (int i = 31; i >= 0; --i) t = (t * 256 + scalar[i]) % (long)width;
+                return op_shift_clear(B, op, a, t);
+            }
+            return op_shift_encrypted(B, op, a, b);
+        case LFHE_OP_DIV: case LFHE_OP_REM: {
+            Nat d(4);
+            for (int i = 0; i < 32; ++i) d[i / 8] |= (uint64_t)scalar[i] << (8 * (i % 8));
+            op_divrem_clear(B, a, d, op == LFHE_OP_DIV ? &out : nullptr, op == LFHE_OP_REM ? &out : nullptr);
+            return out;
+        }
+        default: throw std::invalid_argument("operator not supported");
+    }
+}
+
+static bool specialised_on_scalar(uint32_t op) {
+    return op == LFHE_OP_SHL || op == LFHE_OP_SHR || op == LFHE_OP_ROTL || op == LFHE_OP_ROTR || op == LFHE_OP_DIV ||
+           op == LFHE_OP_REM;
+}
+
 Program build_program(uint32_t op, uint32_t width, int lhs_noise, int rhs_noise, int cond_noise, const uint8_t* scalar) {
     Builder B;
     B.P.op = op;
@@ -532,10 +590,7 @@ Program build_program(uint32_t op, uint32_t width, int lhs_noise, int rhs_noise,
     B.P.lhs = a;
     const bool unary = op == LFHE_OP_NOT || op == LFHE_OP_NEG;
     const bool shift = op == LFHE_OP_SHL || op == LFHE_OP_SHR || op == LFHE_OP_ROTL || op == LFHE_OP_ROTR;
-    const bool divrem = op == LFHE_OP_DIV || op == LFHE_OP_REM;
-    if ((shift || divrem) && width == 1) throw std::invalid_argument("operator not supported");
-    if (divrem && !scalar) throw std::invalid_argument("operator not supported");  // clear divisor only
-    const bool specialised = scalar && (shift || divrem);
+    const bool specialised = scalar && specialised_on_scalar(op);
     B.P.rhs_width = (unary || specialised) ? 0 : (shift ? 8 : width);
     if (B.P.rhs_width) {
         const uint32_t mr = B.P.rhs_width == 1 ? 1 : B.P.rhs_width / 2;
@@ -547,43 +602,73 @@ Program build_program(uint32_t op, uint32_t width, int lhs_noise, int rhs_noise,
         c = B.input(1, cond_noise);
         B.P.cond = {c};
     }
-    B.P.out_width = width;
-    switch (op) {
-        case LFHE_OP_ADD: B.P.out = op_add(B, a, b); break;
-        case LFHE_OP_SUB: B.P.out = op_sub(B, a, b); break;
-        case LFHE_OP_NEG: B.P.out = op_neg(B, a); break;
-        case LFHE_OP_MUL: B.P.out = op_mul(B, a, b); break;
-        case LFHE_OP_AND: case LFHE_OP_OR: case LFHE_OP_XOR: B.P.out = op_bitwise(B, a, b, op); break;
-        case LFHE_OP_NOT:
-            for (uint32_t i = 0; i < m; ++i) B.P.out.push_back(B.mat(Builder::sub(Builder::C(deg), B.E(a[i]))));
-            break;
-        case LFHE_OP_EQ: B.P.out = {op_eq(B, a, b, false)}; B.P.out_width = 1; break;
-        case LFHE_OP_NE: B.P.out = {op_eq(B, a, b, true)}; B.P.out_width = 1; break;
-        case LFHE_OP_GE: case LFHE_OP_GT: case LFHE_OP_LE: case LFHE_OP_LT:
-            B.P.out = {op_cmp(B, a, b, op)}; B.P.out_width = 1; break;
-        case LFHE_OP_MIN: B.P.out = op_select(B, op_cmp(B, a, b, LFHE_OP_LT), a, b); break;
-        case LFHE_OP_MAX: B.P.out = op_select(B, op_cmp(B, a, b, LFHE_OP_GT), a, b); break;
-        case LFHE_OP_SELECT: B.P.out = op_select(B, c, a, b); break;
-        case LFHE_OP_SHL: case LFHE_OP_SHR: case LFHE_OP_ROTL: case LFHE_OP_ROTR:
-            if (scalar) {
-                long t = 0;  // amount modulo the width (a divisor of 2^16 * 5 for every supported width)
-                for (int i = 31; i >= 0; --i) t = (t * 256 + scalar[i]) % (long)width;
-                B.P.out = op_shift_clear(B, op, a, t);
-            } else {
-                B.P.out = op_shift_encrypted(B, op, a, b);
-            }
-            break;
-        case LFHE_OP_DIV: case LFHE_OP_REM: {
-            Nat d(4);
-            for (int i = 0; i < 32; ++i) d[i / 8] |= (uint64_t)scalar[i] << (8 * (i % 8));
-            Blocks r;
-            op_divrem_clear(B, a, d, op == LFHE_OP_DIV ? &r : nullptr, op == LFHE_OP_REM ? &r : nullptr);
-            B.P.out = r;
-            break;
-        }
-        default: throw std::invalid_argument("operator not supported");
-    }
+    B.P.out = apply_op(B, op, width, a, b, c, specialised ? scalar : nullptr, B.P.out_width);
     B.finish();
+    return B.P;
+}
+
+// Several operators chained into one program: intermediate results stay in the arena, independent
+// steps share bootstrap layers.  Value references: 0 .. n_inputs-1 are the inputs, n_inputs + k is
+// the result of step k.
+Program build_fused(const std::vector<FusedStep>& steps, const std::vector<uint32_t>& in_widths,
+                    const std::vector<int>& in_noise, const std::vector<int32_t>& outputs) {
+    Builder B;
+    B.P.op = 0xffffffffu;
+    std::vector<Blocks> val;
+    std::vector<uint32_t> wid;
+    for (size_t i = 0; i < in_widths.size(); ++i) {
+        const uint32_t w = in_widths[i], m = w == 1 ? 1 : w / 2;
+        Blocks v;
+        for (uint32_t k = 0; k < m; ++k) v.push_back(B.input(w == 1 ? 1 : 3, in_noise[i]));
+        B.P.ins.push_back(v);
+        val.push_back(v);
+        wid.push_back(w);
+    }
+    B.P.in_widths = in_widths;
+    auto ref = [&](int32_t r, uint32_t want_width, const char* what) -> const Blocks& {
+        if (r < 0 || (size_t)r >= val.size()) throw std::invalid_argument(std::string("bad value reference for ") + what);
+        if (wid[r] != want_width) throw std::invalid_argument(std::string("width mismatch at ") + what);
+        return val[r];
+    };
+    for (const FusedStep& st : steps) {
+        const uint32_t w = st.width;
+        const bool unary = st.op == LFHE_OP_NOT || st.op == LFHE_OP_NEG;
+        const bool shift = st.op == LFHE_OP_SHL || st.op == LFHE_OP_SHR || st.op == LFHE_OP_ROTL || st.op == LFHE_OP_ROTR;
+        const Blocks& a = ref(st.lhs, w, "lhs");
+        Blocks b;
+        const uint8_t* scalar = nullptr;
+        if (!unary) {
+            if (st.rhs_is_scalar) {
+                if (specialised_on_scalar(st.op)) {
+                    scalar = st.scalar;
+                } else {  // a clear operand becomes constant blocks
+                    const uint32_t m = w == 1 ? 1 : w / 2;
+                    for (uint32_t k = 0; k < m; ++k) {
+                        const uint32_t bit = 2 * k;
+                        const int d = w == 1 ? (st.scalar[0] & 1) : ((st.scalar[bit >> 3] >> (bit & 7)) & 3);
+                        b.push_back(B.mat(Builder::C(d)));
+                    }
+                }
+            } else {
+                b = ref(st.rhs, shift ? 8 : w, "rhs");
+            }
+        }
+        uint32_t c = 0;
+        if (st.op == LFHE_OP_SELECT) c = ref(st.cond, 1, "cond")[0];
+        uint32_t ow = w;
+        val.push_back(apply_op(B, st.op, w, a, b, c, scalar, ow));
+        wid.push_back(ow);
+    }
+    for (int32_t r : outputs) {
+        if (r < 0 || (size_t)r >= val.size()) throw std::invalid_argument("bad output reference");
+        int noise = 0, deg = 0;
+        for (uint32_t blk : val[r]) { noise = std::max(noise, B.noise(blk)); deg = std::max(deg, B.hi(blk)); }
+        if (deg > 3) throw std::logic_error("operator output is not carry-free");
+        B.P.outs.push_back(val[r]);
+        B.P.out_widths.push_back(wid[r]);
+        B.P.out_noises.push_back((uint8_t)std::max(noise, 1));
+        B.P.out_degrees.push_back((uint8_t)deg);
+    }
     return B.P;
 }
 

@@ -49,6 +49,10 @@ struct Program {
     std::vector<std::array<uint64_t, 16>> luts;
     std::vector<Layer> layers;
     uint8_t out_noise = 1, out_degree = 3;
+    // fused programs (build_fused): any number of inputs and outputs instead of lhs / rhs / cond / out
+    std::vector<std::vector<uint32_t>> ins, outs;
+    std::vector<uint32_t> in_widths, out_widths;
+    std::vector<uint8_t> out_noises, out_degrees;
     uint64_t pbs_per_instance() const {
         uint64_t s = 0;
         for (const auto& l : layers) s += l.pbs.size();
@@ -110,10 +114,21 @@ private:
     uint32_t lin(const Expr& e, const Info& i);
 };
 
+// one step of a fused program; lhs / rhs / cond are value references (-1: unused)
+struct FusedStep {
+    uint32_t op = 0, width = 0;
+    int32_t lhs = -1, rhs = -1, cond = -1;
+    uint32_t rhs_is_scalar = 0;
+    uint8_t scalar[32] = {0};
+};
+
 // operator ids are the LFHE_OP_* values of include/lfhe.h
 // scalar: a clear right operand (32 bytes, little-endian) the program is specialised on -- shift and
 // rotation amounts, divisors; null for an encrypted (or trivially encrypted) right operand
 Program build_program(uint32_t op, uint32_t width, int lhs_noise, int rhs_noise, int cond_noise,
                       const uint8_t* scalar = nullptr);
+
+Program build_fused(const std::vector<FusedStep>& steps, const std::vector<uint32_t>& in_widths,
+                    const std::vector<int>& in_noise, const std::vector<int32_t>& outputs);
 
 }  // namespace lfhe

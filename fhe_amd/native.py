@@ -44,6 +44,28 @@ def default_params() -> Params:
     return p
 
 
+class Step(C.Structure):
+    """One step of a fused schedule (lfhe_step)."""
+    _fields_ = [("op", C.c_uint32), ("bit_width", C.c_uint32), ("lhs", C.c_int32), ("rhs", C.c_int32),
+                ("cond", C.c_int32), ("rhs_is_scalar", C.c_uint32), ("scalar", C.c_uint8 * 32)]
+
+
+def make_steps(steps: list):
+    """steps: (op name, width, lhs ref, rhs, cond ref) with rhs a value reference, or ("clear", int)
+    for a clear right operand, or None for unary operators."""
+    arr = (Step * len(steps))()
+    for k, (op, width, lhs, rhs, cond) in enumerate(steps):
+        st = arr[k]
+        st.op, st.bit_width, st.lhs = OPS[op], width, lhs
+        st.rhs, st.cond, st.rhs_is_scalar = -1, -1 if cond is None else cond, 0
+        if isinstance(rhs, tuple):
+            st.rhs_is_scalar = 1
+            st.scalar[:] = list(int(rhs[1]).to_bytes(32, "little"))
+        elif rhs is not None:
+            st.rhs = rhs
+    return arr
+
+
 _lib = None
 
 
@@ -88,6 +110,8 @@ def load():
         "lfhe_evaluate": (i32, [vp, u32, u32, vp, u64, vp, u64, i32, vp, u64, vp, pu64]),
         "lfhe_evaluate_batch": (i32, [vp, u32, u32, u64, vp, vp, i32, vp, vp]),
         "lfhe_program_dump": (i32, [u32, u32, i32, i32, i32, C.c_char_p, C.c_char_p, pu64]),
+        "lfhe_evaluate_fused": (i32, [vp, vp, u32, u32, pu32, u64, vp, vp, u32, vp]),
+        "lfhe_fused_dump": (i32, [vp, u32, u32, pu32, vp, vp, u32, C.c_char_p, pu64]),
         "lfhe_rand": (i32, [vp, u32, C.c_char_p, u32, vp, pu64]),
         "lfhe_pbs_count": (i32, [vp, pu64]),
         "lfhe_make_lut": (i32, [vp, vp, vp]),
@@ -138,6 +162,25 @@ def program(op: str, bit_width: int, lhs_noise: int = 1, rhs_noise: int = 1, con
     rc = L.lfhe_program_dump(OPS[op], bit_width, lhs_noise, rhs_noise, cond_noise, sc, buf, C.byref(n))
     if rc != LFHE_OK:
         raise LfheError(rc, f"no program for {op}/{bit_width}")
+    return json.loads(buf.value.decode())
+
+
+def fused_program(steps: list, in_widths: list, outputs: list, in_noise: list | None = None) -> dict:
+    """The schedule of a fused request (host-side plan; needs no GPU)."""
+    import json
+    L = load()
+    arr = make_steps(steps)
+    w = (C.c_uint32 * len(in_widths))(*in_widths)
+    o = (C.c_int32 * len(outputs))(*outputs)
+    nz = None if in_noise is None else (C.c_int32 * len(in_noise))(*in_noise)
+    n = C.c_uint64(0)
+    rc = L.lfhe_fused_dump(arr, len(steps), len(in_widths), w, nz, o, len(outputs), None, C.byref(n))
+    if rc != LFHE_OK:
+        raise LfheError(rc, "no schedule for this request")
+    buf = C.create_string_buffer(n.value)
+    rc = L.lfhe_fused_dump(arr, len(steps), len(in_widths), w, nz, o, len(outputs), buf, C.byref(n))
+    if rc != LFHE_OK:
+        raise LfheError(rc, "no schedule for this request")
     return json.loads(buf.value.decode())
 
 
@@ -334,6 +377,29 @@ class Context:
         self._ck(self._L.lfhe_rand(self._h, bit_width, seed, bit_width if random_bits is None else random_bits,
                                    _ptr(buf), C.byref(n)))
         return buf.tobytes()
+
+    def evaluate_fused(self, steps: list, in_widths: list, inputs: list, outputs: list, out_widths: list) -> list:
+        """Several operations as one schedule.  inputs: one list of n ciphertexts per input;
+        outputs: value references; out_widths: the width of each (1 for comparisons).  Returns one
+        list of n ciphertexts per output."""
+        n = len(inputs[0])
+        if n == 0:
+            return [[] for _ in outputs]
+        arr = make_steps(steps)
+        w = (C.c_uint32 * len(in_widths))(*in_widths)
+        o = (C.c_int32 * len(outputs))(*outputs)
+        ins = [np.frombuffer(b"".join(col), dtype=np.uint8) for col in inputs]
+        in_ptrs = (C.c_void_p * len(ins))(*[a.ctypes.data for a in ins])
+        sizes = [self.ciphertext_size(x) for x in out_widths]
+        outs = [np.zeros(n * sz, dtype=np.uint8) for sz in sizes]
+        out_ptrs = (C.c_void_p * len(outs))(*[a.ctypes.data for a in outs])
+        self._ck(self._L.lfhe_evaluate_fused(self._h, arr, len(steps), len(in_widths), w, n, in_ptrs, o, len(outputs),
+                                             out_ptrs))
+        res = []
+        for a, sz in zip(outs, sizes):
+            raw = a.tobytes()
+            res.append([raw[i * sz:(i + 1) * sz] for i in range(n)])
+        return res
 
     def pbs_count(self) -> int:
         n = C.c_uint64()

@@ -14,11 +14,23 @@ from __future__ import annotations
 from .sharding import shard_bounds
 
 
-def transfers(backend, bal_from: list, bal_to: list, amount: list, zero, width: int = 64):
-    """(new_from[], new_to[]) for n independent transfers; four batched operator calls."""
+# the transfer as one fused schedule: values 0 = from, 1 = to, 2 = amount; 3 = amount <= from;
+# 4 = select(3, amount, 0); 5 = from - 4; 6 = to + 4.  Subtraction and addition share their layers.
+def transfer_steps(width: int = 64):
+    return [("le", width, 2, 0, None), ("select", width, 2, ("clear", 0), 3), ("sub", width, 0, 4, None),
+            ("add", width, 1, 4, None)]
+
+
+def transfers(backend, bal_from: list, bal_to: list, amount: list, zero, width: int = 64, fused: bool = True):
+    """(new_from[], new_to[]) for n independent transfers: one fused schedule when the backend has
+    `evaluate_fused`, else four batched operator calls."""
     n = len(amount)
     if n == 0:
         return [], []
+    if fused and hasattr(backend, "evaluate_fused"):
+        nf, nt = backend.evaluate_fused(transfer_steps(width), [width] * 3, [bal_from, bal_to, amount], [5, 6],
+                                        [width, width])
+        return nf, nt
     ok = backend.evaluate_batch("le", width, amount, bal_from)
     v = backend.evaluate_batch("select", width, amount, [zero] * n, ok)
     return backend.evaluate_batch("sub", width, bal_from, v), backend.evaluate_batch("add", width, bal_to, v)

@@ -170,6 +170,27 @@ int32_t lfhe_evaluate(lfhe_ctx* ctx, uint32_t op, uint32_t bit_width, const uint
  * is lfhe_ciphertext_size of its width (cond: width 1); scalars are 32 bytes each. */
 int32_t lfhe_evaluate_batch(lfhe_ctx* ctx, uint32_t op, uint32_t bit_width, uint64_t n, const uint8_t* lhs,
                             const uint8_t* rhs, int32_t rhs_is_scalar, const uint8_t* cond, uint8_t* out);
+/* Several operations as ONE schedule.  Values are numbered: 0 .. n_inputs-1 are the inputs,
+ * n_inputs + k is the result of step k; a step names its operands by number (-1: unused) or carries
+ * a clear right operand.  Intermediate results never leave the GPU and independent steps share
+ * bootstrap layers (the subtraction and the addition of a token transfer run side by side).
+ * inputs[i] / outs[o]: arrays of n ciphertexts, as in lfhe_evaluate_batch; the width of output o
+ * is that of the step it names (1 for comparisons).  Replaces: one coprocessor round trip per
+ * executor event (tests/fhevm-suite/e2e/test/utils.ts:182-214) for transactions of one shape, e.g.
+ * EncryptedERC20.sol:208-220 (le, select, sub, add). */
+typedef struct {
+    uint32_t op, bit_width;
+    int32_t lhs, rhs, cond;
+    uint32_t rhs_is_scalar;
+    uint8_t scalar[32];
+} lfhe_step;
+int32_t lfhe_evaluate_fused(lfhe_ctx* ctx, const lfhe_step* steps, uint32_t nsteps, uint32_t n_inputs,
+                            const uint32_t* input_widths, uint64_t n, const uint8_t* const* inputs,
+                            const int32_t* outputs, uint32_t n_outputs, uint8_t* const* outs);
+/* its schedule as JSON (no context, no GPU); input_noise may be NULL (all 1) */
+int32_t lfhe_fused_dump(const lfhe_step* steps, uint32_t nsteps, uint32_t n_inputs, const uint32_t* input_widths,
+                        const int32_t* input_noise, const int32_t* outputs, uint32_t n_outputs, char* out,
+                        uint64_t* out_len);
 /* The bootstrap schedule of an operator as JSON (layers of linear combinations and bootstraps over
  * block ids, the lookup tables, input/output block ids).  Needs no context and no GPU: it is the
  * host-side plan the executor replays, exposed for inspection and for checking the plan against a

@@ -49,6 +49,29 @@ def run_plain(prog: dict, lhs: int, rhs: int | None = None, cond: int | None = N
     return from_digits(out, prog["out_width"])
 
 
+def run_plain_fused(prog: dict, inputs: list) -> list:
+    """A fused program (several inputs and outputs) on clear blocks: one clear value per input,
+    returns one per output."""
+    blk = {}
+    for ids, w, v in zip(prog["ins"], prog["in_widths"], inputs):
+        for b, d in zip(ids, digits(v, w)):
+            blk[b] = d
+    for layer in prog["layers"]:
+        for op in layer["lin"]:
+            v = op["cst"] + sum(c * blk[s] for c, s in op["terms"])
+            assert 0 <= v <= 15, f"block overflow {v}"
+            blk[op["out"]] = v
+        for i, o, l in layer["pbs"]:
+            assert 0 <= blk[i] <= 15
+            blk[o] = prog["luts"][l][blk[i]]
+    out = []
+    for ids, w in zip(prog["outs"], prog["out_widths"]):
+        d = [blk[b] for b in ids]
+        assert all(0 <= v <= 3 for v in d), "output not carry-free"
+        out.append(from_digits(d, w))
+    return out
+
+
 def run_oracle(prog: dict, orc, keys, pbsk, rng, lhs: int, rhs: int | None = None, cond: int | None = None) -> int:
     """Same program on real ciphertexts with the CPU oracle (use small parameters)."""
     lwe_sk, glwe_sk, bsk, ksk = keys

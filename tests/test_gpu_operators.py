@@ -143,6 +143,25 @@ def test_erc20_transfer_semantics(ctx):
     assert (ctx.decrypt(alice2), ctx.decrypt(bob2)) == (10000 - 1337, 1337)
 
 
+def test_fused_transfer_matches_the_separate_operators(ctx):
+    from fhe_amd import workloads
+    cases = [(1000, 5, 400), (1000, 5, 1001), (0, 0, 0), ((1 << 64) - 1, 7, (1 << 64) - 1), (77, (1 << 64) - 1, 3)]
+    F = [ctx.encrypt(c[0], 64) for c in cases]
+    T = [ctx.encrypt(c[1], 64) for c in cases]
+    A = [ctx.encrypt(c[2], 64) for c in cases]
+    zero = ctx.encrypt(0, 64, trivial=True)
+    n0 = ctx.pbs_count()
+    nf, nt = workloads.transfers(ctx, F, T, A, zero)
+    fused_pbs = ctx.pbs_count() - n0
+    sf, st = workloads.transfers(ctx, F, T, A, zero, fused=False)
+    want = [(f - (a if a <= f else 0), (t + (a if a <= f else 0)) & ((1 << 64) - 1)) for f, t, a in cases]
+    assert [(ctx.decrypt(x), ctx.decrypt(y)) for x, y in zip(nf, nt)] == want
+    assert [(ctx.decrypt(x), ctx.decrypt(y)) for x, y in zip(sf, st)] == want
+    assert fused_pbs <= (ctx.pbs_count() - n0 - fused_pbs)
+    # results of a fused schedule feed further operators
+    assert ctx.decrypt(ctx.evaluate("add", 64, nf[0], nt[0])) == want[0][0] + want[0][1]
+
+
 def test_error_paths(ctx):
     from fhe_amd.native import LfheError
     a8, a16 = ctx.encrypt(1, 8), ctx.encrypt(1, 16)

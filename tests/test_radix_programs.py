@@ -128,6 +128,40 @@ def test_division_by_clear_divisors(w):
         program("div", w)                 # encrypted divisor: not in the reference's operator set
 
 
+def test_fused_schedules():
+    """Several operators as one schedule: the ERC20 transfer (le, select with a clear zero, sub, add)
+    and a chain with a comparison result feeding a select, on clear blocks."""
+    from fhe_amd.native import fused_program
+    from fhe_amd.workloads import transfer_steps
+    rnd = random.Random(77)
+    for w in (8, 64):
+        for noise in (None, [2, 2, 2]):
+            p = fused_program(transfer_steps(w), [w, w, w], [5, 6], noise)
+            assert p["out_widths"] == [w, w] and len(p["ins"]) == 3
+            m = (1 << w) - 1
+            cases = [(0, 0, 0), (m, m, m), (5, m, 5), (5, 0, 6)] + [tuple(rnd.randrange(m + 1) for _ in range(3)) for _ in range(30)]
+            for frm, to, amt in cases:
+                v = amt if amt <= frm else 0
+                assert radix.run_plain_fused(p, [frm, to, amt]) == [frm - v, (to + v) & m], (w, frm, to, amt)
+    # the four operators separately cost the same bootstraps but more layers
+    p64 = fused_program(transfer_steps(64), [64] * 3, [5, 6])
+    sep = [prog(o, 64) for o in ("le", "select", "sub", "add")]
+    assert len(p64["layers"]) < sum(len(q["layers"]) for q in sep) - 5
+    assert p64["pbs"] <= sum(q["pbs"] for q in sep)
+    # max(a, b) * 3 + (a == b), outputs of two different widths
+    steps = [("max", 16, 0, 1, None), ("mul", 16, 2, ("clear", 3), None), ("eq", 16, 0, 1, None),
+             ("shl", 16, 3, ("clear", 5), None)]
+    p = fused_program(steps, [16, 16], [3, 4, 5])
+    assert p["out_widths"] == [16, 1, 16]
+    for a, b in [(7, 7), (65535, 1), (123, 45678)] + [(rnd.randrange(1 << 16), rnd.randrange(1 << 16)) for _ in range(20)]:
+        t = (max(a, b) * 3) & 0xFFFF
+        assert radix.run_plain_fused(p, [a, b]) == [t, int(a == b), (t << 5) & 0xFFFF]
+    with pytest.raises(LfheError):
+        fused_program([("add", 16, 0, 1, None)], [16, 8], [2])          # width mismatch
+    with pytest.raises(LfheError):
+        fused_program([("add", 16, 0, 5, None)], [16, 16], [2])         # dangling reference
+
+
 def test_schedule_sizes_are_reported():
     """Bootstraps per operation (the scheduler's own count; the reference publishes none)."""
     want_at_most = {("add", 64): 230, ("mul", 64): 2000, ("lt", 64): 63, ("eq", 64): 45, ("select", 64): 64}
