@@ -42,10 +42,18 @@ def argmax(backend, vals: list, idxs: list, width: int = 32, idx_width: int = 16
     vals, idxs = list(vals), list(idxs)
     if not vals:
         raise ValueError("empty tournament")
+    fused = hasattr(backend, "evaluate_fused")
+    # one round as one schedule: values 0 = L, 1 = R, 2 = LI, 3 = RI; 4 = L > R; 5, 6 = the two selects
+    steps = [("gt", width, 0, 1, None), ("select", width, 0, 1, 4), ("select", idx_width, 2, 3, 4)]
     while len(vals) > 1:
         half = len(vals) // 2
         L, R = vals[:half], vals[half:2 * half]
         LI, RI = idxs[:half], idxs[half:2 * half]
+        if fused:
+            nv, ni = backend.evaluate_fused(steps, [width, width, idx_width, idx_width], [L, R, LI, RI], [5, 6],
+                                            [width, idx_width])
+            vals, idxs = nv + vals[2 * half:], ni + idxs[2 * half:]
+            continue
         g = backend.evaluate_batch("gt", width, L, R)
         nv = backend.evaluate_batch("select", width, L, R, g)
         ni = backend.evaluate_batch("select", idx_width, LI, RI, g)
