@@ -3,6 +3,7 @@
 // independent instances, layer by layer, on the GPU.
 #include <algorithm>
 #include <array>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <stdexcept>
@@ -101,6 +102,18 @@ lfhe_ctx::~lfhe_ctx() {
 }
 
 namespace {
+
+// How many instances of a program fit one arena: half of the free device memory (the bootstrap
+// scratch of the largest layer needs room too), LFHE_ARENA_BYTES overrides the budget.  Larger
+// batches are run in chunks of this many instances.
+uint64_t arena_capacity(size_t inst_bytes) {
+    size_t free_b = 0, total_b = 0;
+    HC(hipMemGetInfo(&free_b, &total_b));
+    uint64_t budget = free_b / 2;
+    if (const char* e = std::getenv("LFHE_ARENA_BYTES")) budget = std::strtoull(e, nullptr, 10);
+    const uint64_t cap = budget / (inst_bytes ? inst_bytes : 1);
+    return cap ? cap : 1;
+}
 
 // descriptors and tables of a program to the device
 void upload_program(lfhe_ctx* ctx, Compiled& C) {
@@ -206,8 +219,15 @@ void run_batch(lfhe_ctx* ctx, uint32_t op, uint32_t width, uint64_t n, const uin
     hipStream_t st = E.stream();
     const uint32_t m = blocks_of(width);
     const size_t inst_bytes = (size_t)P.nblocks * BLK_BYTES;
-    DevBuf<u64> arena(n * (size_t)P.nblocks * BLK_WORDS);
     const uint64_t in_stride = ct_bytes(width);
+    if (const uint64_t cap = arena_capacity(inst_bytes); n > cap) {   // too many instances for one arena
+        const uint64_t rs = rhs_scalar ? 32 : ct_bytes(rhs_width), os = ct_bytes(P.out_width);
+        for (uint64_t off = 0; off < n; off += cap)
+            run_batch(ctx, op, width, std::min(cap, n - off), lhs + off * in_stride, rhs ? rhs + off * rs : nullptr,
+                      rhs_scalar, cond ? cond + off * ct_bytes(1) : nullptr, out + off * os);
+        return;
+    }
+    DevBuf<u64> arena(n * (size_t)P.nblocks * BLK_WORDS);
     auto upload = [&](const uint8_t* src, uint64_t sstride, uint32_t first, uint32_t nb) {
         HC(hipMemcpy2DAsync(reinterpret_cast<uint8_t*>(arena.p) + (size_t)first * BLK_BYTES, inst_bytes,
                             src + sizeof(CtHeader), sstride, (size_t)nb * BLK_BYTES, n, hipMemcpyHostToDevice, st));
@@ -299,6 +319,17 @@ void run_fused(lfhe_ctx* ctx, const lfhe_step* steps, uint32_t nsteps, uint32_t 
     HC(hipSetDevice(E.device()));
     hipStream_t st = E.stream();
     const size_t inst_bytes = (size_t)P.nblocks * BLK_BYTES;
+    if (const uint64_t cap = arena_capacity(inst_bytes); n > cap) {   // too many instances for one arena
+        std::vector<const uint8_t*> in_c(n_inputs);
+        std::vector<uint8_t*> out_c(n_outputs);
+        for (uint64_t off = 0; off < n; off += cap) {
+            for (uint32_t i = 0; i < n_inputs; ++i) in_c[i] = inputs[i] + off * ct_bytes(widths[i]);
+            for (uint32_t o = 0; o < n_outputs; ++o) out_c[o] = outs[o] + off * ct_bytes(P.out_widths[o]);
+            run_fused(ctx, steps, nsteps, n_inputs, in_widths, std::min(cap, n - off), in_c.data(), outputs, n_outputs,
+                      out_c.data());
+        }
+        return;
+    }
     DevBuf<u64> arena(n * (size_t)P.nblocks * BLK_WORDS);
     for (uint32_t i = 0; i < n_inputs; ++i)
         HC(hipMemcpy2DAsync(reinterpret_cast<uint8_t*>(arena.p) + (size_t)P.ins[i][0] * BLK_BYTES, inst_bytes,

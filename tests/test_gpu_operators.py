@@ -162,6 +162,27 @@ def test_fused_transfer_matches_the_separate_operators(ctx):
     assert ctx.decrypt(ctx.evaluate("add", 64, nf[0], nt[0])) == want[0][0] + want[0][1]
 
 
+def test_batches_larger_than_the_arena_budget_run_in_chunks(ctx):
+    import os
+    import random
+    rnd = random.Random(9)
+    n = 11
+    xs = [rnd.randrange(1 << 32) for _ in range(n)]
+    ys = [rnd.randrange(1 << 32) for _ in range(n)]
+    A, B = [ctx.encrypt(x, 32) for x in xs], [ctx.encrypt(y, 32) for y in ys]
+    os.environ["LFHE_ARENA_BYTES"] = str(10 << 20)      # a few instances of add32 per arena
+    try:
+        out = ctx.evaluate_batch("add", 32, A, B)
+        assert [ctx.decrypt(o) for o in out] == [(x + y) & 0xFFFFFFFF for x, y in zip(xs, ys)]
+        out = ctx.evaluate_batch("lt", 32, A, [y & 0xFFFF for y in ys])         # clear operands, chunked too
+        assert [ctx.decrypt(o) for o in out] == [int(x < (y & 0xFFFF)) for x, y in zip(xs, ys)]
+        steps = [("sub", 32, 0, 1, None), ("max", 32, 2, 0, None)]
+        (r,) = ctx.evaluate_fused(steps, [32, 32], [A, B], [3], [32])
+        assert [ctx.decrypt(o) for o in r] == [max((x - y) & 0xFFFFFFFF, x) for x, y in zip(xs, ys)]
+    finally:
+        del os.environ["LFHE_ARENA_BYTES"]
+
+
 def test_error_paths(ctx):
     from fhe_amd.native import LfheError
     a8, a16 = ctx.encrypt(1, 8), ctx.encrypt(1, 16)
