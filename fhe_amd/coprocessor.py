@@ -69,11 +69,12 @@ class Coprocessor:
     evaluate(op, width, lhs, rhs, cond), encrypt(value, width, trivial=True) and
     rand(width, seed16, random_bits) -- fhe_amd.native.Context is one."""
 
-    def __init__(self, backend):
+    def __init__(self, backend, fuse: bool = True):
         self.backend = backend
         self.store: dict = {}
-        self.launches = 0          # evaluate_batch / single calls issued
+        self.launches = 0          # evaluate_batch / evaluate_fused / single calls issued
         self.executed = 0
+        self.fuse = fuse and hasattr(backend, "evaluate_fused")
 
     def put(self, handle: bytes, ciphertext: bytes):
         self.store[bytes(handle)] = ciphertext
@@ -81,12 +82,94 @@ class Coprocessor:
     def get(self, handle: bytes) -> bytes:
         return self.store[bytes(handle)]
 
+    # ---- fusion of transactions of one shape
+    def _fuse(self, events: list) -> list:
+        """Operator events that form chains (a transaction's le -> select -> sub / add) are grouped
+        into connected components over the handles produced inside the list; components of the same
+        shape -- same operators, widths, clear operands and wiring -- are run as ONE fused schedule
+        over all of them, every result handle kept.  Returns the events that were not fused."""
+        ops = [e for e in events if e.name in BINARY or e.name in UNARY or e.name == "FheIfThenElse"]
+        producer = {bytes(e.args["result"]): i for i, e in enumerate(ops)}
+        parent = list(range(len(ops)))
+
+        def find(i):
+            while parent[i] != i:
+                parent[i] = parent[parent[i]]
+                i = parent[i]
+            return i
+        for i, e in enumerate(ops):
+            for h in e.inputs():
+                j = producer.get(bytes(h))
+                if j is not None:
+                    parent[find(i)] = find(j)
+        comps: dict = {}
+        for i in range(len(ops)):
+            comps.setdefault(find(i), []).append(i)
+        shapes: dict = {}
+        for members in comps.values():
+            if len(members) < 2:
+                continue                      # a lone event gains nothing over the batched path
+            inputs, ref, steps, ok = [], {}, [], True
+            for i in members:                 # list order is a topological order of a valid block
+                e, a = ops[i], ops[i].args
+                for h in e.inputs():
+                    hb = bytes(h)
+                    if hb not in ref:
+                        if hb in producer or hb not in self.store:
+                            ok = False        # produced later in the list, or by an event outside the operators
+                            break
+                        ref[hb] = len(inputs)
+                        inputs.append(hb)
+                if not ok:
+                    break
+                if e.name in BINARY:
+                    rhs = ("clear", _clear(a["rhs"])) if _is_scalar(a) else ref[bytes(a["rhs"])]
+                    steps.append((BINARY[e.name], handle_width(a["lhs"]), ref[bytes(a["lhs"])], rhs, None))
+                elif e.name in UNARY:
+                    steps.append((UNARY[e.name], handle_width(a["ct"]), ref[bytes(a["ct"])], None, None))
+                else:
+                    steps.append(("select", handle_width(a["ifTrue"]), ref[bytes(a["ifTrue"])], ref[bytes(a["ifFalse"])],
+                                  ref[bytes(a["control"])]))
+                ref[bytes(a["result"])] = -1 - len(steps)      # placeholder: step results are renumbered below
+            if not ok:
+                continue
+            n_in = len(inputs)
+            fix = lambda r: r if not isinstance(r, int) or r >= 0 else n_in + (-1 - r) - 1
+            steps = tuple((op, w, fix(l), r if isinstance(r, tuple) or r is None else fix(r), None if c is None else fix(c))
+                          for op, w, l, r, c in steps)
+            widths = tuple(handle_width(h) for h in inputs)
+            shapes.setdefault((steps, widths), []).append((members, inputs))
+        fused_ids = set()
+        for (steps, widths), insts in shapes.items():
+            cols = [[self.store[inp[k]] for _, inp in insts] for k in range(len(widths))]
+            outs = list(range(len(widths), len(widths) + len(steps)))
+            out_w = [1 if op in ("eq", "ne", "ge", "gt", "le", "lt") else w for op, w, _, _, _ in steps]
+            res = self.backend.evaluate_fused(list(steps), list(widths), cols, outs, out_w)
+            self.launches += 1
+            for k, (members, _) in enumerate(insts):
+                for sidx, i in enumerate(members):
+                    self.store[bytes(ops[i].args["result"])] = res[sidx][k]
+                    fused_ids.add(id(ops[i]))
+            self.executed += sum(len(m) for m, _ in insts)
+        return [e for e in events if id(e) not in fused_ids]
+
     # ---- scheduling
     def execute(self, events: list) -> int:
         """Runs all events; returns the number of waves.  Raises KeyError if an input handle is
         neither stored nor produced by another event of the list."""
         pending = list(events)
         waves = 0
+        if self.fuse:
+            # first the events that only make inputs (trivial encryptions, casts, randoms), then the
+            # operator chains as fused schedules, then whatever is left wave by wave
+            makers = [e for e in pending if e.name not in BINARY and e.name not in UNARY and e.name != "FheIfThenElse"
+                      and all(bytes(h) in self.store for h in e.inputs())]
+            for e in makers:
+                self.store.update(self._run_group(self._group_key(e), [e]))
+            self.executed += len(makers)
+            done = set(map(id, makers))
+            pending = self._fuse([e for e in pending if id(e) not in done])
+            waves = 1 if len(pending) < len(events) else 0
         while pending:
             ready = [e for e in pending if all(bytes(h) in self.store for h in e.inputs())]
             if not ready:

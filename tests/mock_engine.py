@@ -46,3 +46,23 @@ class MockBackend:
         import hashlib
         v = int.from_bytes(hashlib.sha256(seed).digest(), "big") & ((1 << random_bits) - 1)
         return self.encrypt(v, width)
+
+
+class FusingMockBackend(MockBackend):
+    """The stand-in with a fused entry: steps are evaluated one after the other on clear values."""
+
+    def evaluate_fused(self, steps, in_widths, inputs, outputs, out_widths):
+        self.fused_calls = getattr(self, "fused_calls", 0) + 1
+        n = len(inputs[0])
+        res = [[] for _ in outputs]
+        for k in range(n):
+            vals = [int(json.loads(col[k])["v"]) for col in inputs]
+            for col, w in zip(inputs, in_widths):
+                assert json.loads(col[k])["w"] == w
+            for op, w, lhs, rhs, cond in steps:
+                b = rhs[1] if isinstance(rhs, tuple) else (None if rhs is None else vals[rhs])
+                c = None if cond is None else vals[cond]
+                vals.append(clear_op(op, w, vals[lhs], b, c))
+            for o, (ref, w) in enumerate(zip(outputs, out_widths)):
+                res[o].append(self.encrypt(vals[ref], w))
+        return res

@@ -8,7 +8,7 @@ import pytest
 
 from fhe_amd.coprocessor import BINARY, Coprocessor, Event, TYPE_WIDTH, handle_type
 from oracle import radix
-from tests.mock_engine import MockBackend
+from tests.mock_engine import FusingMockBackend, MockBackend
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 KATS = json.load(open(os.path.join(GOLDEN, "fhevm_operator_kats.json")))["kats"]
@@ -115,6 +115,56 @@ def test_dependency_waves_select_cast_and_rand():
         cop.execute([Event("FheRandBounded", {"upperBound": 1000, "randType": 3, "seed": bytes(16), "result": H(13, 16)})])
 
 
+def _transfer_block(cop, enc, n, new):
+    """n transfers as events (le, select against a trivially encrypted zero, sub, add)."""
+    ev, outs, plain = [], [], []
+    zero = new(64)
+    ev.append(Event("TrivialEncrypt", {"pt": 0, "toType": 5, "result": zero}))
+    for i in range(n):
+        bal, to, amt = 1000 + 37 * i, 5 * i, (400 * i) % 1500
+        hb, ht, ha = new(64), new(64), new(64)
+        cop.put(hb, enc(bal, 64)); cop.put(ht, enc(to, 64)); cop.put(ha, enc(amt, 64))
+        ok, v, nb, nt = new(1), new(64), new(64), new(64)
+        ev += [Event("FheLe", {"lhs": ha, "rhs": hb, "scalarByte": b"\x00", "result": ok}),
+               Event("FheIfThenElse", {"control": ok, "ifTrue": ha, "ifFalse": zero, "result": v}),
+               Event("FheSub", {"lhs": hb, "rhs": v, "scalarByte": b"\x00", "result": nb}),
+               Event("FheAdd", {"lhs": ht, "rhs": v, "scalarByte": b"\x00", "result": nt})]
+        moved = amt if amt <= bal else 0
+        plain.append((bal - moved, to + moved, int(amt <= bal), moved))
+        outs.append((nb, nt, ok, v))
+    return ev, outs, plain
+
+
+def test_transactions_of_one_shape_are_fused():
+    backend = FusingMockBackend()
+    cop = Coprocessor(backend)
+    c = [0]
+
+    def new(w):
+        c[0] += 1
+        return mk_handle(c[0], w)
+    ev, outs, plain = _transfer_block(cop, backend.encrypt, 9, new)
+    # plus one transaction of another shape and a lone event
+    x, y, r1, r2, r3 = new(8), new(8), new(8), new(8), new(8)
+    cop.put(x, backend.encrypt(200, 8)); cop.put(y, backend.encrypt(100, 8))
+    ev += [Event("FheAdd", {"lhs": x, "rhs": y, "scalarByte": b"\x00", "result": r1}),
+           Event("FheMul", {"lhs": r1, "rhs": (3).to_bytes(32, "big"), "scalarByte": b"\x01", "result": r2}),
+           Event("FheNot", {"ct": y, "result": r3})]
+    cop.execute(ev)
+    d = lambda h: backend.decrypt(cop.get(h))
+    assert [tuple(d(h) for h in o) for o in outs] == plain          # intermediates (ok, v) are kept too
+    assert (d(r1), d(r2), d(r3)) == (44, 132, 155)
+    assert backend.fused_calls == 2                                 # nine transfers in one call, the 8-bit chain in another
+    assert cop.executed == len(ev)
+    # with fusion off the same block goes wave by wave
+    b2 = FusingMockBackend()
+    cop2 = Coprocessor(b2, fuse=False)
+    c[0] = 0
+    ev2, outs2, plain2 = _transfer_block(cop2, b2.encrypt, 9, new)
+    assert cop2.execute(ev2) == 3 and getattr(b2, "fused_calls", 0) == 0
+    assert [tuple(b2.decrypt(cop2.get(h)) for h in o) for o in outs2] == plain2
+
+
 @pytest.mark.gpu
 def test_block_of_transfers_and_rand_on_gpu():
     """A block of transfers (le, select, sub, add per transfer: EncryptedERC20.sol:87-93,208-220)
@@ -146,8 +196,8 @@ def test_block_of_transfers_and_rand_on_gpu():
             plain.append((bal - moved, to + moved))
             outs.append((nb, nt))
         before = cop.launches
-        assert cop.execute(ev) == 3
-        assert cop.launches - before == 5              # trivial, le, select, sub, add
+        cop.execute(ev)
+        assert cop.launches - before == 2              # the trivial zero, then the six transfers as one fused schedule
         assert [(ctx.decrypt(cop.get(a)), ctx.decrypt(cop.get(b))) for a, b in outs] == plain
         # oblivious randoms: deterministic in the seed, inside the bound, not constant
         r1 = ctx.decrypt(ctx.rand(64, bytes(range(16))))
