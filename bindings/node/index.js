@@ -107,6 +107,22 @@ class NativeEngine {
     return out;
   }
 
+  /** Oblivious pseudo-random ciphertext (FheRand / FheRandBounded): uniform below 2^randomBits. */
+  rand(bitWidth, seed16, randomBits) {
+    return native.rand(this.handle, bitWidth, Buffer.from(seed16), randomBits || bitWidth);
+  }
+
+  /** Secret keys made elsewhere (arrays of 0/1 as BigUint64Array), then server keys for them. */
+  importClientKeys(lweSk, glweSk) {
+    native.importClientKeys(this.handle, Buffer.from(lweSk.buffer, lweSk.byteOffset, lweSk.byteLength),
+      Buffer.from(glweSk.buffer, glweSk.byteOffset, glweSk.byteLength));
+    native.keygenServer(this.handle);
+  }
+
+  /** Inputs encrypted under a separate public-key secret: set that key once, then cast ciphertexts. */
+  setPkeKey(pkeSk) { native.setPkeKey(this.handle, Buffer.from(pkeSk.buffer, pkeSk.byteOffset, pkeSk.byteLength)); }
+  castFromPke(ciphertext) { return native.castFromPke(this.handle, Buffer.from(ciphertext)); }
+
   pbsCount() { return native.pbsCount(this.handle); }
   close() { if (this.handle) { native.destroy(this.handle); this.handle = null; } }
 }

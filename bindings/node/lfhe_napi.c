@@ -45,6 +45,11 @@ FN(int32_t, lfhe_evaluate, (lfhe_ctx*, uint32_t, uint32_t, const uint8_t*, uint6
 FN(int32_t, lfhe_evaluate_batch, (lfhe_ctx*, uint32_t, uint32_t, uint64_t, const uint8_t*, const uint8_t*, int32_t,
                                   const uint8_t*, uint8_t*))
 FN(int32_t, lfhe_pbs_count, (const lfhe_ctx*, uint64_t*))
+FN(int32_t, lfhe_rand, (lfhe_ctx*, uint32_t, const uint8_t*, uint32_t, uint8_t*, uint64_t*))
+FN(int32_t, lfhe_keygen_server, (lfhe_ctx*))
+FN(int32_t, lfhe_client_keys_import_raw, (lfhe_ctx*, const uint64_t*, const uint64_t*))
+FN(int32_t, lfhe_pke_key_set, (lfhe_ctx*, const uint64_t*))
+FN(int32_t, lfhe_cast_from_pke, (lfhe_ctx*, const uint8_t*, uint64_t, uint8_t*, uint64_t*))
 #undef FN
 
 static napi_value throw_msg(napi_env env, const char* msg) {
@@ -72,6 +77,7 @@ static int resolve_all(napi_env env, const char* path) {
     GET(lfhe_keygen) GET(lfhe_keys_export) GET(lfhe_keys_import) GET(lfhe_public_key) GET(lfhe_encrypt)
     GET(lfhe_trivial_encrypt) GET(lfhe_encrypt_public) GET(lfhe_decrypt) GET(lfhe_ciphertext_size)
     GET(lfhe_op_from_name) GET(lfhe_evaluate) GET(lfhe_evaluate_batch) GET(lfhe_pbs_count)
+    GET(lfhe_rand) GET(lfhe_keygen_server) GET(lfhe_client_keys_import_raw) GET(lfhe_pke_key_set) GET(lfhe_cast_from_pke)
 #undef GET
     return 1;
 }
@@ -399,6 +405,84 @@ static napi_value js_evaluate_batch(napi_env env, napi_callback_info info) {
     return out;
 }
 
+/* rand(ctx, bits, seed16, randomBits) -> Buffer */
+static napi_value js_rand(napi_env env, napi_callback_info info) {
+    NEED_LIB();
+    napi_value argv[4];
+    if (!get_args(env, info, 4, argv)) return NULL;
+    lfhe_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return NULL;
+    uint32_t bits, rbits;
+    napi_get_value_uint32(env, argv[1], &bits);
+    napi_get_value_uint32(env, argv[3], &rbits);
+    const uint8_t* seed; size_t sl;
+    if (!get_bytes(env, argv[2], &seed, &sl)) return NULL;
+    if (sl != 16) return throw_msg(env, "seed must be 16 bytes");
+    uint64_t n = 0;
+    if (p_lfhe_ciphertext_size(c, bits, &n) != LFHE_OK) return throw_msg(env, "unsupported bit width");
+    uint8_t* tmp = (uint8_t*)malloc(n);
+    const int32_t rc = p_lfhe_rand(c, bits, seed, rbits, tmp, &n);
+    napi_value out = rc == LFHE_OK ? make_buffer(env, tmp, n) : fail(env, c, rc, "lfhe_rand");
+    free(tmp);
+    return out;
+}
+
+/* importClientKeys(ctx, lweSk: BigUint64Array-backed Buffer, glweSk) ; keygenServer(ctx) ; setPkeKey(ctx, sk) */
+static napi_value js_import_client(napi_env env, napi_callback_info info) {
+    NEED_LIB();
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return NULL;
+    lfhe_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return NULL;
+    const uint8_t *a, *b; size_t al, bl;
+    if (!get_bytes(env, argv[1], &a, &al) || !get_bytes(env, argv[2], &b, &bl)) return NULL;
+    if (al % 8 || bl != 2048 * 8 || ((uintptr_t)a & 7) || ((uintptr_t)b & 7)) return throw_msg(env, "keys are arrays of 64-bit words");
+    const int32_t rc = p_lfhe_client_keys_import_raw(c, (const uint64_t*)a, (const uint64_t*)b);
+    if (rc != LFHE_OK) return fail(env, c, rc, "lfhe_client_keys_import_raw");
+    return NULL;
+}
+
+static napi_value js_keygen_server(napi_env env, napi_callback_info info) {
+    NEED_LIB();
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    lfhe_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return NULL;
+    const int32_t rc = p_lfhe_keygen_server(c);
+    if (rc != LFHE_OK) return fail(env, c, rc, "lfhe_keygen_server");
+    return NULL;
+}
+
+static napi_value js_set_pke_key(napi_env env, napi_callback_info info) {
+    NEED_LIB();
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return NULL;
+    lfhe_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return NULL;
+    const uint8_t* a; size_t al;
+    if (!get_bytes(env, argv[1], &a, &al)) return NULL;
+    if (al != 2048 * 8 || ((uintptr_t)a & 7)) return throw_msg(env, "the key is 2048 64-bit words");
+    const int32_t rc = p_lfhe_pke_key_set(c, (const uint64_t*)a);
+    if (rc != LFHE_OK) return fail(env, c, rc, "lfhe_pke_key_set");
+    return NULL;
+}
+
+static napi_value js_cast_from_pke(napi_env env, napi_callback_info info) {
+    NEED_LIB();
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return NULL;
+    lfhe_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return NULL;
+    const uint8_t* ct; size_t n;
+    if (!get_bytes(env, argv[1], &ct, &n)) return NULL;
+    uint64_t on = n;
+    uint8_t* tmp = (uint8_t*)malloc(n ? n : 1);
+    const int32_t rc = p_lfhe_cast_from_pke(c, ct, n, tmp, &on);
+    napi_value out = rc == LFHE_OK ? make_buffer(env, tmp, on) : fail(env, c, rc, "lfhe_cast_from_pke");
+    free(tmp);
+    return out;
+}
+
 static napi_value js_pbs_count(napi_env env, napi_callback_info info) {
     NEED_LIB();
     napi_value argv[1];
@@ -418,7 +502,9 @@ static napi_value init(napi_env env, napi_value exports) {
         {"health", js_health}, {"publicKey", js_public_key}, {"keysExport", js_keys_export},
         {"keysImport", js_keys_import}, {"encrypt", js_encrypt}, {"encryptPublic", js_encrypt_public},
         {"decrypt", js_decrypt}, {"opFromName", js_op_from_name}, {"evaluate", js_evaluate},
-        {"evaluateBatch", js_evaluate_batch}, {"pbsCount", js_pbs_count}};
+        {"evaluateBatch", js_evaluate_batch}, {"pbsCount", js_pbs_count}, {"rand", js_rand},
+        {"importClientKeys", js_import_client}, {"keygenServer", js_keygen_server}, {"setPkeKey", js_set_pke_key},
+        {"castFromPke", js_cast_from_pke}};
     for (size_t i = 0; i < sizeof tab / sizeof tab[0]; ++i) {
         napi_value f;
         napi_create_function(env, tab[i].name, NAPI_AUTO_LENGTH, tab[i].fn, NULL, &f);

@@ -21,12 +21,13 @@ const { LuxFHEClient, NativeEngine } = require('./index.js');
     shl: String(await sdk.decrypt(await sdk.evaluate('shl', a, 3, 8))),
     mul64: String(await sdk.decrypt(await sdk.evaluate('mul', await sdk.encrypt_uint64(4293652672n), await sdk.encrypt_uint64(4293367238n), 64))),
     batch: engine.evaluateBatch('gt', 8, [a, b], [b, a]).map((c) => String(engine.decrypt(c))),
+    rand: String(engine.decrypt(engine.rand(16, Buffer.alloc(16, 7), 10))),
     pbs: engine.pbsCount(),
   };
   console.log(JSON.stringify(res));
   const ok = res.health === 'ok' && res.add === '59' && res.sub === '25' && res.lt === '0' && res.eq === '1' &&
     res.addScalar === '242' && res.shl === String((42 << 3) & 255) && res.mul64 === '18434227713315959936' &&
-    res.batch[0] === '1' && res.batch[1] === '0';
+    res.batch[0] === '1' && res.batch[1] === '0' && Number(res.rand) < 1024;
   engine.close();
   process.exit(ok ? 0 : 1);
 })().catch((e) => { console.error(e.message); process.exit(2); });
