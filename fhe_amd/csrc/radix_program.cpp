@@ -155,7 +155,7 @@ Expr pack(Builder& B, uint32_t hi_blk, uint32_t lo_blk) { return Builder::add(Bu
 
 // Carry propagation over per-block sums v[i] in [0,7]: digit i = (v[i] + carry_in[i]) mod 4,
 // carry_out[i] = (v[i] + carry_in[i]) >= 4.  One layer extracts digit and carry state (0 none,
-// 1 propagate, 2 generate), a Hillis-Steele scan resolves the states in ceil(log2 m) layers, a
+// 1 propagate, 2 generate), a prefix network resolves the states in ceil(log2 m) layers, a
 // last layer adds the incoming carry.
 Blocks propagate(Builder& B, const std::vector<Expr>& v) {
     const size_t m = v.size();
@@ -167,10 +167,16 @@ Blocks propagate(Builder& B, const std::vector<Expr>& v) {
             else st[i] = B.pbs(v[i], [](int x) { return x >= 4 ? 2 : (x == 3 ? 1 : 0); });
         }
     }
-    for (size_t d = 1; d < st.size(); d *= 2) {
+    // Sklansky prefix network: at level d every position whose bit d is set absorbs the last
+    // position of the preceding group of 2^d.  Same depth as a Hillis-Steele scan (ceil(log2 m)
+    // layers) with (m/2) log2 m bootstraps instead of m log2 m.
+    for (size_t d = 0; ((size_t)1 << d) < st.size(); ++d) {
         Blocks nx = st;
-        for (size_t i = d; i < st.size(); ++i)
-            nx[i] = B.pbs(pack(B, st[i], st[i - d]), [](int x) { return hi2(x) == 1 ? lo2(x) : std::min(hi2(x), 2); });
+        for (size_t i = 0; i < st.size(); ++i) {
+            if (!((i >> d) & 1)) continue;
+            const size_t j = ((i >> d) << d) - 1;
+            nx[i] = B.pbs(pack(B, st[i], st[j]), [](int x) { return hi2(x) == 1 ? lo2(x) : std::min(hi2(x), 2); });
+        }
         st = nx;
     }
     Blocks res(m);
