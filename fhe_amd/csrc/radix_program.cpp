@@ -62,10 +62,11 @@ uint32_t Builder::lin(const Expr& e0, const Info& i) {
     return out;
 }
 
-uint32_t Builder::mat(const Expr& e, int hi_known) {
+uint32_t Builder::mat(const Expr& e, int hi_known, int lo_known) {
     if (e.t.size() == 1 && e.t[0].first == 1 && e.cst == 0) return e.t[0].second;
     Info i = eval(e);
     if (hi_known >= 0) i.hi = std::min(i.hi, hi_known);
+    if (lo_known >= 0) i.lo = std::max(i.lo, lo_known);
     return lin(e, i);
 }
 
@@ -326,18 +327,22 @@ uint32_t op_cmp(Builder& B, const Blocks& a0, const Blocks& b0, uint32_t op) {
     return cur[0];
 }
 
+// cond ? a : b per block in ONE bootstrap: x = 2 (a - b + 3) + cond fits the block (at most 13) and
+// costs exactly the noise budget (2 + 2 + 1); the table returns a - b + 3 when the low bit is set
+// and 3 otherwise, and b + table - 3 is the selected digit.
 Blocks op_select(Builder& B, uint32_t c0, const Blocks& a0, const Blocks& b0) {
     const uint32_t c = clean(B, {c0})[0];
     const Blocks a = clean(B, a0), b = clean(B, b0);
     Blocks r;
     for (size_t i = 0; i < a.size(); ++i) {
-        const uint32_t p = B.pbs(pack(B, c, a[i]), [](int x) { return hi2(x) ? lo2(x) : 0; });
-        const uint32_t q = B.pbs(pack(B, c, b[i]), [](int x) { return hi2(x) ? 0 : lo2(x); });
-        r.push_back(B.mat(Builder::add(B.E(p), B.E(q)), std::max(B.hi(a[i]), B.hi(b[i]))));  // one of p, q is zero
+        Expr in = Builder::add(Builder::scale(Builder::sub(B.E(a[i]), B.E(b[i])), 2), Builder::add(B.E(c), Builder::C(6)));
+        const uint32_t t = B.pbs(in, [](int x) { return (x & 1) ? (x >> 1) : 3; });
+        // between 0 and 3 whatever the interval arithmetic says: it is a[i] or b[i]
+        r.push_back(B.mat(Builder::add(Builder::add(B.E(b[i]), B.E(t)), Builder::C(-3)),
+                          std::max(B.hi(a[i]), B.hi(b[i])), 0));
     }
     return r;
 }
-
 
 // ---- shifts and rotations -----------------------------------------------------------------------
 // An integer of W bits is the bit string X[0..W); every variant maps output bit p to one source bit

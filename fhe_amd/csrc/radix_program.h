@@ -89,9 +89,10 @@ public:
 
     // bootstrap of e through the table f : [0,16) -> [0,16)
     uint32_t pbs(const Expr& e, const std::function<int(int)>& f);
-    // e as a block (a linear op unless e already is a plain block); hi_known >= 0 overrides the
-    // interval bound when the caller knows a tighter one (e.g. a sum whose terms exclude each other)
-    uint32_t mat(const Expr& e, int hi_known = -1);
+    // e as a block (a linear op unless e already is a plain block); hi_known / lo_known >= 0
+    // override the interval bounds when the caller knows tighter ones (e.g. a sum whose terms
+    // exclude each other)
+    uint32_t mat(const Expr& e, int hi_known = -1, int lo_known = -1);
     int hi(uint32_t b) const { return info_[b].hi; }
     int noise(uint32_t b) const { return info_[b].noise; }
     void finish();
