@@ -27,6 +27,9 @@ N = 2048
 # algorithmic work of one bootstrap at n=918, k=1, N=2048, l=1 (single-modulus count):
 # 3672 length-2048 transforms * 11264 butterflies + 918*4*2048 point-wise multiply-accumulates
 MODMUL_PER_PBS = 3672 * 11264 + 918 * 4 * 2048
+# with the key bits in pairs: 459 steps of 4 transforms, and per transform-domain point 12 products
+# for the step's GGSW (3 key rows x 4 polynomials) + 4 for the external product itself
+MODMUL_PER_PBS_GROUPED = 459 * (4 * 11264 + 16 * 2048)
 # register-resident calibration on MI355X (profiles/r01/valu_rates_8wg_per_cu.txt): 4748 G/s exact
 # f64 butterflies (modular multiply + add + sub) per prime.  Over q = 2^64 a logical modular product
 # costs one butterfly in each of two primes; over the prime ring modulus it costs one.
@@ -38,7 +41,15 @@ TRAFFIC_BYTES_4096 = {"prime": (2 * 3808307 + 196800) * 1024, "q64": (2 * 790966
 BSK_BYTES, KSK_BYTES, CT_BYTES = 60162048, 60227584, 16392
 
 
-def cpu_baseline(seconds_budget: float = 20.0, prime_bsk: bool = False):
+# bootstrapping-key flavour -> (parameter set id, label, kernel, VALU peak in butterflies/s per GPU)
+FLAVOURS = {
+    "q64": (1, "2^64", "k_blind_rotate"),
+    "prime": (2, "703687441727489 (NTT prime)", "k_blind_rotate_q"),
+    "grouped": (3, "703687441727489 (NTT prime), key bits in pairs", "k_blind_rotate_q2"),
+}
+
+
+def cpu_baseline(seconds_budget: float = 20.0, flavour: str = "prime"):
     """The CPU oracle (own port; the reference engine is not available offline) timed on the host
     cores of this box on a bounded sample of the same workload."""
     from oracle.oracle import Oracle, Rng, seed_bytes
@@ -46,8 +57,13 @@ def cpu_baseline(seconds_budget: float = 20.0, prime_bsk: bool = False):
     orc = Oracle()
     lwe_sk, glwe_sk, bsk, ksk = orc.gen_keys(seed_bytes(9))
     orc.set_ms(orc.gen_ms_zeros(lwe_sk, seed_bytes(9), orc.ms_params().zeros_count))   # same pipeline as the GPU's
-    pb = orc.prepare_bsk_qp(orc.gen_bsk_qp(lwe_sk, glwe_sk, seed_bytes(9))) if prime_bsk else orc.prepare_bsk(bsk)
-    pbs_batch = orc.pbs_batch_qp if prime_bsk else orc.pbs_batch
+    if flavour == "grouped":
+        pb = orc.prepare_bsk_qp_grouped(orc.gen_bsk_qp_grouped(lwe_sk, glwe_sk, seed_bytes(9)))
+    elif flavour == "prime":
+        pb = orc.prepare_bsk_qp(orc.gen_bsk_qp(lwe_sk, glwe_sk, seed_bytes(9)))
+    else:
+        pb = orc.prepare_bsk(bsk)
+    pbs_batch = orc.pbs_batch if flavour == "q64" else orc.pbs_batch_qp
     r = Rng(seed_bytes(10))
     lut = orc.make_lut(lambda x: x)
     probe = np.stack([orc.encrypt_block(glwe_sk, int(r.u64() % 16), r) for _ in range(threads)])
@@ -75,10 +91,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--bsk-modulus", choices=["q64", "prime"], default="prime",
-                    help="ring modulus of the bootstrapping key and accumulator: the NTT prime (one transform per "
-                         "polynomial) or 2^64 (two-prime transform + CRT lift)")
-    ap.add_argument("--no-alt", action="store_true", help="skip the second leg with the other ring modulus")
+    ap.add_argument("--bsk-modulus", choices=list(FLAVOURS), default="grouped",
+                    help="bootstrapping key of the timed leg: over 2^64 (two-prime transform + CRT lift), over the NTT "
+                         "prime (one transform per polynomial), or over the prime with the key bits taken two per "
+                         "blind-rotation step")
+    ap.add_argument("--no-alt", action="store_true", help="skip the legs with the other bootstrapping keys")
     args = ap.parse_args()
 
     import torch
@@ -101,17 +118,18 @@ def main():
 
     seed = bytes((7 * i + 3) & 0xFF for i in range(32))
 
-    def make_context(prime: bool):
+    def make_context(flavour: str):
         """Context with keys on every rank: generated on rank 0, device images broadcast once."""
-        return replicated_context(dist, rank, world, dev, seed, 2 if prime else 1)
+        return replicated_context(dist, rank, world, dev, seed, FLAVOURS[flavour][0])
 
     B = args.batch
-    f = [lambda x: x, lambda x: (5 * x + 3) % 16]
-    idx = (np.arange(B) % 2).astype(np.uint32)
+    # 16 distinct tables, table j on block i when i % 16 == j (table 0 is the identity)
+    f = [(lambda x, j=j: ((2 * j + 1) * x + j) % 16) for j in range(16)]
+    idx = (np.arange(B) % 16).astype(np.uint32)
 
-    def run_leg(prime: bool, steps: int, warmup: int):
+    def run_leg(flavour: str, steps: int, warmup: int):
         """K timed passes over this rank's B blocks; returns (elapsed s, ks ms, br ms, verified)."""
-        ctx, keep = make_context(prime)
+        ctx, keep = make_context(flavour)
         # synthetic inputs: batch blocks = batch/4 euint8 values, fresh encryptions, distinct per rank
         rng = np.random.default_rng(1234 + rank)
         vals = rng.integers(0, 256, size=(B + 3) // 4)
@@ -157,23 +175,28 @@ def main():
         del keep
         return elapsed, ks_ms, br_ms, ok
 
-    prime = args.bsk_modulus == "prime"
-    elapsed, ks_ms, br_ms, ok = run_leg(prime, args.steps, args.warmup)
-    alt = None
+    flavour = args.bsk_modulus
+    elapsed, ks_ms, br_ms, ok = run_leg(flavour, args.steps, args.warmup)
+    alts = []
     if not args.no_alt:
         a_steps = max(1, min(args.steps, 3))
-        a_el, a_ks, a_br, a_ok = run_leg(not prime, a_steps, 1)
-        ok = ok and a_ok
-        alt = {"bsk_modulus": "2^64" if prime else "703687441727489 (NTT prime)",
-               "value": B * a_steps * world / a_el, "unit": "PBS/s", "steps": a_steps,
-               "kernel_ms": {"keyswitch_and_ms_noise_reduction": a_ks, "blind_rotate": a_br}, "verified": a_ok}
+        for other in FLAVOURS:
+            if other == flavour:
+                continue
+            a_el, a_ks, a_br, a_ok = run_leg(other, a_steps, 1)
+            ok = ok and a_ok
+            alts.append({"bsk_modulus": FLAVOURS[other][1], "kernel": FLAVOURS[other][2],
+                         "value": B * a_steps * world / a_el, "unit": "PBS/s", "steps": a_steps,
+                         "kernel_ms": {"keyswitch_and_ms_noise_reduction": a_ks, "blind_rotate": a_br},
+                         "verified": a_ok})
 
     if rank == 0:
         total = B * args.steps * world
         value = total / elapsed
         br_s = br_ms * 1e-3
-        achieved = B * MODMUL_PER_PBS / br_s / 1e9
-        peak = PEAK_GBFLY_PER_PRIME if prime else PEAK_GBFLY_PER_PRIME / 2
+        modmul = MODMUL_PER_PBS_GROUPED if flavour == "grouped" else MODMUL_PER_PBS
+        achieved = B * modmul / br_s / 1e9
+        peak = PEAK_GBFLY_PER_PRIME / 2 if flavour == "q64" else PEAK_GBFLY_PER_PRIME
         algo_bytes = BSK_BYTES + KSK_BYTES + 2 * CT_BYTES * B
         res = {
             "metric": "programmable bootstraps/sec (node)",
@@ -189,21 +212,21 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"batched PBS microbench: {B} independent euint8 blocks per GPU, "
-                                   "PARAM_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128 (n=918, N=2048), 2 LUTs",
-                       "bsk_modulus": "703687441727489 (NTT prime)" if prime else "2^64",
+                                   "PARAM_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128 (n=918, N=2048), 16 distinct LUTs",
+                       "bsk_modulus": FLAVOURS[flavour][1],
                        "batch_per_gpu": B, "parallelism": f"batch-shard x{world}, keys broadcast once"},
             "verified": ok,
             "kernel_ms": {"keyswitch_and_ms_noise_reduction": ks_ms, "blind_rotate": br_ms},
-            "roofline": {"bound": "valu", "kernel": "k_blind_rotate_q" if prime else "k_blind_rotate", "achieved": achieved, "peak": peak,
-                         "unit": "Gmodmul/s", "frac": achieved / peak,
-                         "traffic": TRAFFIC_BYTES_4096[args.bsk_modulus] if B == BATCH else None,
+            "roofline": {"bound": "valu", "kernel": FLAVOURS[flavour][2], "achieved": achieved, "peak": peak,
+                         "unit": "Gmodmul/s", "frac": achieved / peak, "modmul_per_pbs": modmul,
+                         "traffic": TRAFFIC_BYTES_4096.get(flavour) if B == BATCH else None,
                          "hbm": {"achieved": algo_bytes / ((ks_ms + br_ms) * 1e-3) / 1e9, "peak": 8000.0,
                                  "unit": "GB/s", "algorithmic_bytes": algo_bytes}},
         }
-        if alt is not None:
-            res["alt_ring_modulus"] = alt
+        if alts:
+            res["other_bootstrapping_keys"] = alts
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(prime_bsk=prime)
+            res["cpu_baseline"] = cpu_baseline(flavour=flavour)
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

@@ -24,9 +24,11 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--transfers", type=int, default=512, help="total over all GPUs")
+    ap.add_argument("--transfers", type=int, default=0,
+                    help="total over all GPUs; default 1250 per GPU (10 000 over a node of eight)")
     ap.add_argument("--bids", type=int, default=1000, help="total over all GPUs")
-    ap.add_argument("--mul-batch", type=int, default=64, help="total over all GPUs")
+    ap.add_argument("--mul-batch", type=int, default=256,
+                    help="random pairs, total over all GPUs (the reference's vectors are added)")
     ap.add_argument("--bsk-modulus", choices=["q64", "prime"], default="prime")
     args = ap.parse_args()
 
@@ -88,8 +90,13 @@ def main():
     t0 = time.perf_counter(); out = ctx.evaluate("add", 64, a, b); t_add = time.perf_counter() - t0
     assert ctx.decrypt(out) == (ka + kb) & M64
     nb = args.mul_batch
-    xs = [rnd.randrange(1 << 64) for _ in range(nb)]
-    ys = [rnd.randrange(1 << 64) for _ in range(nb)]
+    # the reference's euint64 vectors first (fhevmOperations6.ts:647-705 mul, :1067-1125 gt), then random pairs
+    kat = [(4293652672, 4293367238), (4293367238, 4293367238),
+           (18442678758156446977, 18443460298071844659), (18442678758156446973, 18442678758156446977),
+           (18442678758156446977, 18442678758156446977), (18442678758156446977, 18442678758156446973)]
+    xs = [p[0] for p in kat] + [rnd.randrange(1 << 64) for _ in range(nb)]
+    ys = [p[1] for p in kat] + [rnd.randrange(1 << 64) for _ in range(nb)]
+    nb = len(xs)
     lo, hi = shard_bounds(nb, world, rank)
     A, B = [ctx.encrypt(x, 64) for x in xs[lo:hi]], [ctx.encrypt(y, 64) for y in ys[lo:hi]]
     outs, t_mulb = timed(lambda: ctx.evaluate_batch("mul", 64, A, B))
@@ -101,7 +108,7 @@ def main():
                       "mul_batch_pbs_per_s": nb * pbs_mul / t_mulb, "gt_per_s": nb / t_gtb}
 
     # ---- config 4: ERC20 transfers (le64 + select64 + sub64 + add64 each), sharded by transfer
-    n = args.transfers
+    n = args.transfers or 1250 * world
     bal_from = [rnd.randrange(1 << 40) for _ in range(n)]
     bal_to = [rnd.randrange(1 << 40) for _ in range(n)]
     amount = [rnd.randrange(1 << 41) for _ in range(n)]   # about half exceed the balance

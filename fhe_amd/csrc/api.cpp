@@ -63,6 +63,7 @@ static void params_out(const EngineParams& d, lfhe_params* p) {
     p->ms_zeros_count = d.ms_zeros_count; p->ms_bound_log2 = d.ms_bound_log2;
     p->ms_r_sigma_factor = d.ms_r_sigma_factor; p->ms_input_variance = d.ms_input_variance;
     p->bsk_modulus = d.bsk_modulus;
+    p->bsk_grouping = d.bsk_grouping;
 }
 
 void lfhe_default_params(lfhe_params* p) {
@@ -83,6 +84,7 @@ int32_t lfhe_ctx_create_custom(lfhe_ctx** out, const lfhe_params* p, int32_t dev
     c->prm.ms_zeros_count = p->ms_zeros_count; c->prm.ms_bound_log2 = p->ms_bound_log2;
     c->prm.ms_r_sigma_factor = p->ms_r_sigma_factor; c->prm.ms_input_variance = p->ms_input_variance;
     c->prm.bsk_modulus = p->bsk_modulus;
+    c->prm.bsk_grouping = p->bsk_grouping ? p->bsk_grouping : 1;
     std::memcpy(c->seed, seed, 32);
     c->enc_rng.init(seed, 16);
     int32_t rc = LFHE_OK;
@@ -107,11 +109,13 @@ int32_t lfhe_ctx_create_custom(lfhe_ctx** out, const lfhe_params* p, int32_t dev
 
 int32_t lfhe_ctx_create(lfhe_ctx** out, uint32_t params_id, int32_t device, const uint8_t seed[32]) {
     if (params_id != LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128 &&
-        params_id != LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK)
+        params_id != LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK &&
+        params_id != LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK_GROUPED)
         return LFHE_ERR_UNSUPPORTED;
     lfhe_params p;
     lfhe_default_params(&p);
-    if (params_id == LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK) p.bsk_modulus = LFHE_BSK_MODULUS_PRIME;
+    if (params_id != LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128) p.bsk_modulus = LFHE_BSK_MODULUS_PRIME;
+    if (params_id == LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK_GROUPED) p.bsk_grouping = 2;
     return lfhe_ctx_create_custom(out, &p, device, seed);
 }
 

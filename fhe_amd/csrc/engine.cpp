@@ -24,6 +24,8 @@ Engine::Engine(int device, const EngineParams& p) : device_(device), prm_(p) {
     if (p.lwe_dim < 1 || p.lwe_dim > 4096) throw std::runtime_error("unsupported LWE dimension");
     if (p.bsk_modulus != 0 && p.bsk_modulus != QP_U)
         throw std::runtime_error("unsupported bootstrapping-key modulus: 0 (2^64) or 703687441727489");
+    if (p.bsk_grouping != 1 && !(p.bsk_grouping == 2 && p.bsk_modulus == QP_U))
+        throw std::runtime_error("unsupported key grouping: 1, or 2 with the prime bootstrapping-key modulus");
     if (p.ms_zeros_count && (p.ms_bound_log2 < 27 || p.ms_bound_log2 > 63 || !(p.ms_r_sigma_factor > 0) ||
                              !(p.ms_r_sigma_factor < 1024) || !(p.ms_input_variance >= 0) ||
                              !(p.ms_input_variance < 1e-3)))
@@ -42,7 +44,7 @@ Engine::Engine(int device, const EngineParams& p) : device_(device), prm_(p) {
 
     HostTables H;
     build_host_tables(H);
-    HC(hipMalloc(&d_tw_, sizeof(double) * 4 * N));
+    HC(hipMalloc(&d_tw_, sizeof(double) * (4 * N + MONO_WORDS)));
     for (int r = 0; r < 2; ++r) {
         HC(hipMemcpy(d_tw_ + (2 * r) * N, H.tw_fwd[r].data(), sizeof(double) * N, hipMemcpyHostToDevice));
         HC(hipMemcpy(d_tw_ + (2 * r + 1) * N, H.tw_inv[r].data(), sizeof(double) * N, hipMemcpyHostToDevice));
@@ -54,6 +56,17 @@ Engine::Engine(int device, const EngineParams& p) : device_(device), prm_(p) {
         T_.ninv[r] = H.ninv[r];
     }
     T_.p0inv_mod_p1 = H.p0inv_mod_p1;
+    {   // psi^k - 1 over prime 0 for every exponent k of X^k (k < 2N), and the identity's diagonal
+        std::vector<double> mono(MONO_WORDS);
+        u64 w = 1;
+        for (int k = 0; k < MONO_WORDS; ++k) {
+            mono[k] = h_centred((w + H.p[0] - 1) % H.p[0], H.p[0]);
+            w = h_mulmod(w, H.psi[0], H.p[0]);
+        }
+        HC(hipMemcpy(d_tw_ + 4 * N, mono.data(), sizeof(double) * MONO_WORDS, hipMemcpyHostToDevice));
+        T_.mono = d_tw_ + 4 * N;
+        gconst_ = h_centred(h_mulmod(qp_gadget() % H.p[0], h_powmod(N, H.p[0] - 2, H.p[0]), H.p[0]), H.p[0]);
+    }
 }
 
 Engine::~Engine() {
@@ -83,8 +96,9 @@ void Engine::load_bsk(const u64* host_bsk) {
     const size_t slab = 64;
     u64* d_raw = nullptr;
     HC(hipMalloc(&d_raw, slab * 4 * N * sizeof(u64)));
-    for (size_t i0 = 0; i0 < prm_.lwe_dim; i0 += slab) {
-        const size_t cnt = (prm_.lwe_dim - i0) < slab ? (prm_.lwe_dim - i0) : slab;
+    const size_t total = bsk_ggsw_count();
+    for (size_t i0 = 0; i0 < total; i0 += slab) {
+        const size_t cnt = (total - i0) < slab ? (total - i0) : slab;
         HC(hipMemcpyAsync(d_raw, host_bsk + i0 * 4 * N, cnt * 4 * N * sizeof(u64), hipMemcpyHostToDevice, stream_));
         if (single_modulus()) launch_bskq_prepare(T_, d_raw, d_bsk_ + i0 * BSKQ_ROW, cnt * 4, stream_);
         else launch_ntt_forward(T_, d_raw, d_bsk_ + i0 * BSK_ROW, cnt * 4, 1, stream_);
@@ -219,7 +233,7 @@ void Engine::blind_rotate(const u64* lwe_small, const u64* luts, const u32* lut_
     HC(hipSetDevice(device_));
     if (single_modulus())
         launch_blind_rotate_q(T_, d_bsk_, lwe_small, (int)prm_.lwe_dim, luts, lut_index, glwe_out, lwe_out, count, omap,
-                              1.0 / (double)qp_gadget(), wide_below_, stream_);
+                              1.0 / (double)qp_gadget(), wide_below_, (int)prm_.bsk_grouping, gconst_, stream_);
     else
         launch_blind_rotate(T_, d_bsk_, lwe_small, (int)prm_.lwe_dim, luts, lut_index, glwe_out, lwe_out, count, omap,
                             stream_);

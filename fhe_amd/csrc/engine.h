@@ -39,6 +39,9 @@ struct EngineParams {
     // ring modulus of the bootstrapping key and the accumulator: 0 = 2^64 (two-prime transform and
     // lift), QP_U = the NTT prime itself (single transform, modulus switch on the way in and out)
     uint64_t bsk_modulus = 0;
+    // key bits per blind-rotation step: 1, or 2 (needs the prime ring modulus): the key then holds
+    // three GGSWs per pair of bits and a step is one external product for two mask elements
+    uint32_t bsk_grouping = 1;
 };
 
 // kernel launchers (kernels.hip)
@@ -54,7 +57,8 @@ void launch_external_product_q(const Tables& T, const double* bsk, const u32* id
                                size_t count, double inv_g, hipStream_t st);
 void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
                            const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
-                           const BlockMap& omap, double inv_g, int wide_below, hipStream_t st);
+                           const BlockMap& omap, double inv_g, int wide_below, int grouping, double gconst,
+                           hipStream_t st);
 void launch_lin_batch(u64* arena, const LinOp* ops, int nops, size_t instances, size_t inst_stride_blocks, u64 delta,
                       hipStream_t st);
 void launch_ksk_colsum(const u64* ksk, int rows, int cols, int half_base, u64* colsum, hipStream_t st);
@@ -81,19 +85,21 @@ public:
     const Tables& tables() const { return T_; }
     bool has_keys() const { return d_bsk_ && d_ksk_; }
 
-    size_t bsk_raw_words() const { return (size_t)prm_.lwe_dim * 4 * N; }
+    // GGSWs in the bootstrapping key
+    size_t bsk_ggsw_count() const { return prm_.bsk_grouping == 2 ? 3 * (((size_t)prm_.lwe_dim + 1) / 2) : prm_.lwe_dim; }
+    size_t bsk_raw_words() const { return bsk_ggsw_count() * 4 * N; }
     size_t ksk_words() const { return (size_t)N * prm_.ks_level * (prm_.lwe_dim + 1); }
     bool single_modulus() const { return prm_.bsk_modulus != 0; }
     // gadget of the single-modulus key: round(q' / 2^base_log); digits are rint(c / gadget)
     u64 qp_gadget() const { return (QP_U + (1ull << (prm_.pbs_base_log - 1))) >> prm_.pbs_base_log; }
-    size_t bsk_dev_bytes() const { return (size_t)prm_.lwe_dim * (single_modulus() ? BSKQ_ROW : BSK_ROW) * sizeof(double); }
+    size_t bsk_dev_bytes() const { return bsk_ggsw_count() * (single_modulus() ? BSKQ_ROW : BSK_ROW) * sizeof(double); }
     size_t ms_zeros_words() const { return (size_t)prm_.ms_zeros_count * (prm_.lwe_dim + 1); }
     // device image of the key-switching key: key words, n+1 column sums, one word holding the
     // number of encryptions of zero that follow (0 when the key set came without them), the zeros
     size_t ksk_dev_bytes() const { return (ksk_words() + prm_.lwe_dim + 1 + 1 + ms_zeros_words()) * sizeof(u64); }
 
     // key material: host coefficient-domain keys in, device images built here
-    void load_bsk(const u64* host_bsk);   // [n][row][poly][N]
+    void load_bsk(const u64* host_bsk);   // [ggsw][row][poly][N]
     // [N][level][n+1]; ms_zeros [ms_zeros_count][n+1] or null
     void load_ksk(const u64* host_ksk, const u64* ms_zeros = nullptr);
     // or attach images that already sit in device memory (e.g. received by a broadcast);
@@ -148,6 +154,7 @@ private:
     size_t ksdig_cap_ = 0;
     MsParams ms_{};
     int cu_count_ = 256;
+    double gconst_ = 0;     // gadget * N^-1 mod q', centred (grouped blind rotation)
     int wide_below_ = -1;   // launches of at most this many ciphertexts use 512 threads each
     void set_ms_params(u32 zcount);
     u64* ms_zeros_dev() const { return d_ksk_ + ksk_words() + prm_.lwe_dim + 1 + 1; }

@@ -122,7 +122,18 @@ void gen_bsk_qp(const EngineParams& p, const uint64_t* lwe_sk, const uint64_t* g
     const uint64_t Q = QP_U;
     const uint64_t G = (Q + (1ull << (p.pbs_base_log - 1))) >> p.pbs_base_log;
     const uint64_t E = (uint64_t)((((unsigned __int128)1 << p.glwe_noise_log2) * Q + ((unsigned __int128)1 << 63)) >> 64);
-    const size_t rows = (size_t)p.lwe_dim * 2;
+    // the bit each GGSW encrypts: the key bits themselves, or per pair (s, s') the three products
+    // s(1-s'), (1-s)s', s s' (s' = 0 past the end of an odd-length key)
+    std::vector<uint64_t> msg;
+    if (p.bsk_grouping == 2) {
+        for (uint32_t g = 0; 2 * g < p.lwe_dim; ++g) {
+            const uint64_t s0 = lwe_sk[2 * g], s1 = 2 * g + 1 < p.lwe_dim ? lwe_sk[2 * g + 1] : 0;
+            msg.push_back(s0 & (1 - s1)); msg.push_back((1 - s0) & s1); msg.push_back(s0 & s1);
+        }
+    } else {
+        msg.assign(lwe_sk, lwe_sk + p.lwe_dim);
+    }
+    const size_t rows = msg.size() * 2;
     parallel_for(rows, threads, [&](size_t row) {
         ChaCha r(seed, 0x400000000ull + row);
         uint64_t* mask = bsk + row * 2 * N;
@@ -145,7 +156,7 @@ void gen_bsk_qp(const EngineParams& p, const uint64_t* lwe_sk, const uint64_t* g
         for (int j = 0; j < N; ++j) body[j] = (body[j] + pos[j] % Q + Q - negs[j] % Q) % Q;
         const size_t i = row >> 1;
         const int rr = (int)(row & 1);
-        if (lwe_sk[i]) { uint64_t& w = (rr == 0 ? mask : body)[0]; w = (w + G) % Q; }
+        if (msg[i]) { uint64_t& w = (rr == 0 ? mask : body)[0]; w = (w + G) % Q; }
     });
 }
 

@@ -36,7 +36,8 @@ uint64_t lwe_phase(const uint64_t* sk, size_t dim, const uint64_t* ct);
 // key-switching key ksk[N][level][n+1]; `threads` host threads
 void gen_bsk(const EngineParams& p, const uint64_t* lwe_sk, const uint64_t* glwe_sk, const uint8_t seed[32],
              uint64_t* bsk, int threads);
-// the bootstrapping key over the prime ring modulus (EngineParams::bsk_modulus), same layout
+// the bootstrapping key over the prime ring modulus (EngineParams::bsk_modulus), same layout; with
+// EngineParams::bsk_grouping == 2 three GGSWs per pair of key bits: bsk[group][3][row][poly][N]
 void gen_bsk_qp(const EngineParams& p, const uint64_t* lwe_sk, const uint64_t* glwe_sk, const uint8_t seed[32],
                 uint64_t* bsk, int threads);
 // stream_base separates the generator streams of different keys made from one seed

@@ -534,6 +534,100 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q_wide(Tables T, con
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Blind rotation with two mask elements per step (grouped key, pbs_phases.h: ep_group2_phase5).
+// The accumulator lives in registers only: a step decomposes it, transforms the digits, forms the
+// step's GGSW point by point from three key rows and the monomial table (kept in LDS behind the
+// exchange buffer), multiplies, transforms back and REPLACES the accumulator -- no rotated reads,
+// hence no accumulator copy in LDS.  (n + 1) / 2 steps of one external product each.
+// ------------------------------------------------------------------------------------------------
+static constexpr size_t LDS_BYTES_G2 = LDS_BYTES + (size_t)MONO_WORDS * sizeof(double);
+
+template <int... PH>
+__device__ __forceinline__ void epq_run_range(EpState& s, double* lds, unsigned t, const Tables& T,
+                                              std::integer_sequence<int, PH...>) {
+    ((ep_phase<PH, false, true>(s, lds, t, T, nullptr), __syncthreads()), ...);
+}
+template <int FIRST, int... K>
+constexpr auto phase_range(std::integer_sequence<int, K...>) { return std::integer_sequence<int, (FIRST + K)...>{}; }
+
+__global__ void __launch_bounds__(NT, LFHE_BRQ_WAVES) k_blind_rotate_q2(Tables T, const double* __restrict__ bsk,
+                                                                        const u64* __restrict__ lwe_small, int n,
+                                                                        const u64* __restrict__ luts,
+                                                                        const u32* __restrict__ lut_index,
+                                                                        u64* __restrict__ glwe_out,
+                                                                        u64* __restrict__ lwe_out, BlockMap omap,
+                                                                        double inv_g, double gconst) {
+    const unsigned t = threadIdx.x;
+    const size_t ct = blockIdx.x;
+    const Prime P = T.pr[0];
+    const u64* __restrict__ lwe = lwe_small + ct * (size_t)(n + 1);
+    const u64* __restrict__ lut = luts + (size_t)(lut_index ? lut_index[omap.ops ? ct % omap.ops : ct] : 0) * N;
+    double* mono = lds_dyn + LDS_WORDS;
+    for (unsigned i = t; i < (unsigned)MONO_WORDS; i += NT) mono[i] = T.mono[i];
+
+    double acc[2][E];
+    {
+        const unsigned bt = modswitch_2n(lwe[n]);
+        const unsigned a = (2 * N - bt) & (2 * N - 1);  // multiply by X^-b~
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            bool neg;
+            const double v = torus_to_qp(lut[rot_index(own1(t, j), a, neg)]);
+            acc[0][j] = 0.0;
+            acc[1][j] = neg ? -v : v;
+        }
+    }
+    __syncthreads();
+
+    EpState s;
+    const int groups = (n + 1) / 2;
+    for (int g = 0; g < groups; ++g) {
+        const unsigned a0 = modswitch_2n(lwe[2 * g]);
+        const unsigned a1 = 2 * g + 1 < n ? modswitch_2n(lwe[2 * g + 1]) : 0u;
+        if ((a0 | a1) == 0) continue;  // the step's GGSW is the identity: skipped
+        unsigned tt = t;
+        asm volatile("" : "+v"(tt));  // recompute the addresses per step (see ep_phase)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < E; ++j) s.x[q][j] = __builtin_rint(acc[q][j] * inv_g);
+        ct_radix8(s.x[0], T.tw_fwd[0], 1, P);
+        ct_radix8(s.x[1], T.tw_fwd[0], 1, P);
+        st_o1p12(lds_dyn, tt, s.x[0]); st_o1p12(lds_dyn + POLY_STRIDE, tt, s.x[1]);
+        load_tw8(T.tw_fwd[0], base2(tt), s.tw);   // twiddles of the next pass, one phase ahead
+        __syncthreads();
+        epq_run_range(s, lds_dyn, t, T, phase_range<1>(std::make_integer_sequence<int, 4>{}));
+        ep_group2_phase5(s, lds_dyn, t, T, mono, bsk + (size_t)3 * g * BSKQ_ROW, a0, a1, gconst);
+        __syncthreads();
+        epq_run_range(s, lds_dyn, t, T, phase_range<6>(std::make_integer_sequence<int, 5>{}));
+        ep_phase<11, false, true>(s, lds_dyn, t, T, nullptr);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < E; ++j) acc[q][j] = qp_canon(s.x[q][j], P);
+        __syncthreads();  // the last pass's reads are done before the next step overwrites the buffer
+    }
+    if (glwe_out) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const double c = acc[q][j];
+                glwe_out[(ct * 2 + q) * N + own1(t, j)] = c < 0 ? QP_U - (u64)(-c) : (u64)c;
+            }
+    }
+    if (lwe_out) {  // sample extraction of coefficient 0, every word switched back to 2^64
+        u64* o = lwe_out + omap.block(ct) * (size_t)(N + 1);
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const unsigned e = own1(t, j);
+            if (e == 0) { o[0] = qp_to_torus(acc[0][j]); o[N] = qp_to_torus(acc[1][j]); }
+            else o[N - e] = qp_to_torus(-acc[0][j]);
+        }
+    }
+}
+
 void launch_bskq_prepare(const Tables& T, const u64* in, double* out, size_t polys, hipStream_t st) {
     hipLaunchKernelGGL(k_bskq_prepare, dim3((unsigned)polys), dim3(NT), LDS_BYTES, st, T, in, out);
 }
@@ -544,7 +638,13 @@ void launch_external_product_q(const Tables& T, const double* bsk, const u32* id
 }
 void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
                            const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
-                           const BlockMap& omap, double inv_g, int wide_below, hipStream_t st) {
+                           const BlockMap& omap, double inv_g, int wide_below, int grouping, double gconst,
+                           hipStream_t st) {
+    if (grouping == 2) {
+        hipLaunchKernelGGL(k_blind_rotate_q2, dim3((unsigned)count), dim3(NT), LDS_BYTES_G2, st, T, bsk, lwe_small, n,
+                           luts, lut_index, glwe_out, lwe_out, omap, inv_g, gconst);
+        return;
+    }
     // up to two ciphertexts per CU: latency matters more than throughput, use 512 threads each
     if (count <= (size_t)wide_below)
         hipLaunchKernelGGL(k_blind_rotate_q_wide, dim3((unsigned)count), dim3(2 * NT), LDS_BYTES, st, T, bsk, lwe_small,

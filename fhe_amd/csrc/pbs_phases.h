@@ -15,6 +15,7 @@ struct Tables {
     double two32[2];           // 2^32 mod p, centred
     double ninv[2];            // N^-1 mod p, centred
     double p0inv_mod_p1;       // centred
+    const double* mono;        // [2N] psi^k - 1 over prime 0, centred (grouped blind rotation)
 };
 
 // Bootstrapping key on the device: f64 residues, N^-1 folded in, transform (bit-reversed) order,
@@ -165,6 +166,101 @@ LFHE_HD void ep_phase(EpState& s, double* lds, unsigned t, const Tables& T, cons
                 }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Blind rotation with two mask elements per step (single ring modulus).  The key holds, per pair of
+// key bits (s, s'), GGSWs G0, G1, G2 of s(1-s'), (1-s)s', s s' as three consecutive rows of the
+// single-modulus layout; the step is  acc <- B [.] acc  with
+//     B = I + (X^a - 1) G0 + (X^a' - 1) G1 + (X^(a+a') - 1) G2 .
+// In the transform domain X^e is the point-wise factor psi^(e (2 bitrev(pos) + 1)) at position pos,
+// so B is formed point by point from the three key rows and a table of psi^k - 1, and the step
+// costs ONE external product: the transforms of phases 0-4 and 6-11 above, with this function in
+// place of phase 5's point-wise stage.  `gconst` is the diagonal of I, the gadget times N^-1 (the
+// key rows carry N^-1 too).
+// ------------------------------------------------------------------------------------------------
+constexpr int MONO_WORDS = 2 * N;
+
+LFHE_HD unsigned rev8(unsigned t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brev(t) >> 24;
+#else
+    unsigned r = ((t & 0xF0u) >> 4) | ((t & 0x0Fu) << 4);
+    r = ((r & 0xCCu) >> 2) | ((r & 0x33u) << 2);
+    return ((r & 0xAAu) >> 1) | ((r & 0x55u) << 1);
+#endif
+}
+
+LFHE_HD void ep_group2_phase5(EpState& s, double* lds, unsigned t, const Tables& T, const double* mono,
+                              const double* __restrict__ rows, unsigned a1, unsigned a2, double gconst) {
+    const Prime P = T.pr[0];
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned zero = 0;
+    asm volatile("" : "+v"(t));
+    asm volatile("" : "+s"(zero));
+    const double* __restrict__ twi = T.tw_inv[0] + zero;
+#else
+    const double* __restrict__ twi = T.tw_inv[0];
+#endif
+    double* b0 = lds;
+    double* b1 = lds + POLY_STRIDE;
+    ld_o4p34(b0, t, s.x[0]); ld_o4p34(b1, t, s.x[1]);
+    ct_radix4x2(s.x[0], s.tw, P); ct_radix4x2(s.x[1], s.tw, P);
+    load_tw4x2(twi, t, s.tw);   // for the inverse pass below
+    // position 8 t + j evaluates at psi^(2 bitrev11(8 t + j) + 1) = psi^(512 bitrev3(j) + 2 rev8(t) + 1)
+    const unsigned ut = 2 * rev8(t) + 1;
+    const unsigned am[3] = {a1, a2, (a1 + a2) & (2 * N - 1)};
+    unsigned base[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) base[m] = am[m] * ut;
+    constexpr unsigned R3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+    // key words of unit u = 3 c4 + m: row m, the four polynomials q, positions 8 t + 2 c4 + {0, 1};
+    // the next unit's four 16-byte loads are in flight while this one is multiplied
+    double kc[4][2], kn[4][2];
+#pragma unroll
+    for (unsigned q = 0; q < 4; ++q) { const unsigned o = bsk_off(0, q, 0, t); kc[q][0] = LFHE_LDK(rows, o); kc[q][1] = LFHE_LDK(rows, o + 1); }
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+        double B[4][2];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const int u = 3 * c4 + m;
+            if (u < 11) {
+                const unsigned c4n = (unsigned)(u + 1) / 3, mn = (unsigned)(u + 1) % 3;
+#pragma unroll
+                for (unsigned q = 0; q < 4; ++q) {
+                    const unsigned o = mn * (unsigned)BSKQ_ROW + bsk_off(0, q, c4n, t);
+                    kn[q][0] = LFHE_LDK(rows, o); kn[q][1] = LFHE_LDK(rows, o + 1);
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const unsigned idx = (base[m] + ((am[m] * R3[2 * c4 + h]) << 9)) & (2 * N - 1);
+                const double M = mono[idx];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double v = mmul(M, kc[q][h], P);
+                    B[q][h] = m == 0 ? v : B[q][h] + v;
+                }
+            }
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" ::: "memory");
+#endif
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { kc[q][0] = kn[q][0]; kc[q][1] = kn[q][1]; }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int j = 2 * c4 + h;
+            const double B00 = mnorm(B[0][h] + gconst, P), B01 = mnorm(B[1][h], P);
+            const double B10 = mnorm(B[2][h], P), B11 = mnorm(B[3][h] + gconst, P);
+            const double d0 = s.x[0][j], d1 = s.x[1][j];
+            s.x[0][j] = mmul(d0, B00, P) + mmul(d1, B10, P);
+            s.x[1][j] = mmul(d0, B01, P) + mmul(d1, B11, P);
+        }
+    }
+    gs_radix4x2<GS_NORM_PASS4[0], GS_NORM_PASS4[1]>(s.x[0], s.tw, P);
+    gs_radix4x2<GS_NORM_PASS4[0], GS_NORM_PASS4[1]>(s.x[1], s.tw, P);
 }
 
 // coefficient e of X^a * poly: index to read and whether to negate it

@@ -16,6 +16,7 @@ ERR_NAMES = {-1: "LFHE_ERR_ARG", -2: "LFHE_ERR_STATE", -3: "LFHE_ERR_DEVICE", -4
 KEY_CLIENT, KEY_SERVER = 1, 2
 PARAMS_DEFAULT = 1
 PARAMS_PRIME_BSK = 2          # same set, bootstrapping key over the NTT prime
+PARAMS_PRIME_BSK_GROUPED = 3  # prime modulus, two key bits per blind-rotation step
 BSK_MODULUS_PRIME = 703687441727489
 
 OPS = {"add": 0, "sub": 1, "mul": 2, "eq": 3, "ne": 4, "ge": 5, "gt": 6, "le": 7, "lt": 8, "min": 9, "max": 10,
@@ -35,7 +36,7 @@ class Params(C.Structure):
         "lwe_dim", "glwe_dim", "poly_size", "pbs_base_log", "pbs_level", "ks_base_log", "ks_level",
         "message_modulus", "carry_modulus", "lwe_noise_log2", "glwe_noise_log2", "ms_zeros_count",
         "ms_bound_log2")] + [("ms_r_sigma_factor", C.c_double), ("ms_input_variance", C.c_double),
-                             ("bsk_modulus", C.c_uint64)]
+                             ("bsk_modulus", C.c_uint64), ("bsk_grouping", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 def default_params() -> Params:

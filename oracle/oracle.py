@@ -131,6 +131,9 @@ def lib():
         "orc_gen_bsk_qp": (None, [vp, _u64p, _u64p, C.POINTER(_Rng), _u64p]),
         "orc_external_product_qp": (None, [vp, _u64p, _u64p, _u64p]),
         "orc_bsk_qp_prepare": (vp, [vp, _u64p]),
+        "orc_bsk_qp_grouped_count": (sz, [C.POINTER(_Params)]),
+        "orc_gen_bsk_qp_grouped": (None, [vp, _u64p, _u64p, C.POINTER(_Rng), _u64p]),
+        "orc_bsk_qp_grouped_prepare": (vp, [vp, _u64p]),
         "orc_blind_rotate_qp": (None, [vp, vp, _u64p, _u64p, _u64p]),
         "orc_pbs_qp": (None, [vp, _u64p, vp, _u64p, _u64p, _u64p]),
         "orc_pbs_batch_qp": (None, [vp, _u64p, vp, _u64p, _u64p, vp, _u64p, sz, C.c_int]),
@@ -374,6 +377,16 @@ class Oracle:
         lib().orc_gen_bsk_qp(self._ctx, lwe_sk, glwe_sk, Rng(seed, 6).ref, bsk)
         return bsk
 
+    def gen_bsk_qp_grouped(self, lwe_sk: np.ndarray, glwe_sk: np.ndarray, seed: bytes) -> np.ndarray:
+        """Grouped key over q': three GGSWs per pair of key bits (tfhe_oracle.h)."""
+        count = lib().orc_bsk_qp_grouped_count(C.byref(self._cp))
+        bsk = np.zeros(count * self.ggsw_words(), dtype=np.uint64)
+        lib().orc_gen_bsk_qp_grouped(self._ctx, lwe_sk, glwe_sk, Rng(seed, 7).ref, bsk)
+        return bsk
+
+    def prepare_bsk_qp_grouped(self, bsk: np.ndarray):
+        return _PreparedBsk(self, bsk, prime=True, grouped=True)
+
     def external_product_qp(self, ggsw: np.ndarray, glwe: np.ndarray) -> np.ndarray:
         out = np.zeros((self.k + 1) * self.N, dtype=np.uint64)
         lib().orc_external_product_qp(self._ctx, np.ascontiguousarray(ggsw), np.ascontiguousarray(glwe), out)
@@ -413,9 +426,11 @@ class Oracle:
 
 
 class _PreparedBsk:
-    def __init__(self, orc: Oracle, bsk: np.ndarray, prime: bool = False):
+    def __init__(self, orc: Oracle, bsk: np.ndarray, prime: bool = False, grouped: bool = False):
         self._orc = orc
         prep = lib().orc_bsk_qp_prepare if prime else lib().orc_bsk_prepare
+        if grouped:
+            prep = lib().orc_bsk_qp_grouped_prepare
         self.h = prep(orc._ctx, np.ascontiguousarray(bsk, dtype=np.uint64))
 
     def __del__(self):

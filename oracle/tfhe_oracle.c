@@ -676,6 +676,7 @@ void orc_sample_extract(const orc_ctx* c, const uint64_t* glwe, uint64_t* lwe_bi
 struct orc_prepared_bsk {
     u64* hat;        /* [i][level][row][poly][prime][N] */
     size_t per_ggsw; /* words per GGSW image */
+    u32 grouping;    /* key bits per blind-rotation step (1, or 2 for the grouped key over q') */
 };
 
 orc_prepared_bsk* orc_bsk_prepare(const orc_ctx* c, const uint64_t* bsk) {
@@ -683,6 +684,7 @@ orc_prepared_bsk* orc_bsk_prepare(const orc_ctx* c, const uint64_t* bsk) {
     const size_t polys = (size_t)P->pbs_level * (P->glwe_dim + 1) * (P->glwe_dim + 1);
     orc_prepared_bsk* b = (orc_prepared_bsk*)malloc(sizeof *b);
     b->per_ggsw = polys * 2 * P->poly_size;
+    b->grouping = 1;
     b->hat = (u64*)malloc(sizeof(u64) * b->per_ggsw * P->lwe_dim);
     for (u32 i = 0; i < P->lwe_dim; ++i)
         ggsw_to_hat(c, bsk + (size_t)i * polys * P->poly_size, b->hat + (size_t)i * b->per_ggsw);
@@ -812,28 +814,51 @@ static void qp_mul_binary(const orc_ctx* c, const u64* a, const u64* s, u64* out
     free(t);
 }
 
-void orc_gen_bsk_qp(const orc_ctx* c, const uint64_t* lwe_sk, const uint64_t* glwe_sk, orc_rng* r, uint64_t* bsk) {
+/* one GGSW over q' of the bit `msg`: rows (Z + msg G), written at `row` ((k+1)^2 polynomials) */
+static void gen_ggsw_qp(const orc_ctx* c, u64 msg, const u64* glwe_sk, orc_rng* r, u64* row, u64* tmp) {
     const orc_params* P = &c->prm;
     const u32 N = P->poly_size, k = P->glwe_dim;
     const u64 G = orc_qp_gadget(c);
     const u64 E = orc_qp_noise_bound(c);
-    u64* tmp = (u64*)malloc(sizeof(u64) * N);
-    u64* row = bsk;
-    for (u32 i = 0; i < P->lwe_dim; ++i)
-        for (u32 rr = 0; rr <= k; ++rr, row += (size_t)(k + 1) * N) {
-            u64* body = row + (size_t)k * N;
-            for (u32 j = 0; j < N; ++j) {
-                const u64 e = orc_rng_u64(r) % (2 * E + 1);          /* uniform in [-E, E] */
-                body[j] = e >= E ? e - E : e + ORC_QP - E;
-            }
-            for (u32 q = 0; q < k; ++q) {
-                u64* a = row + (size_t)q * N;
-                for (u32 j = 0; j < N; ++j) a[j] = (u64)(((u128)orc_rng_u64(r) * ORC_QP) >> 64);
-                qp_mul_binary(c, a, glwe_sk + (size_t)q * N, tmp);
-                for (u32 j = 0; j < N; ++j) body[j] = qp_add(body[j], tmp[j]);
-            }
-            if (lwe_sk[i]) row[(size_t)rr * N] = qp_add(row[(size_t)rr * N], G % ORC_QP);
+    for (u32 rr = 0; rr <= k; ++rr, row += (size_t)(k + 1) * N) {
+        u64* body = row + (size_t)k * N;
+        for (u32 j = 0; j < N; ++j) {
+            const u64 e = orc_rng_u64(r) % (2 * E + 1);          /* uniform in [-E, E] */
+            body[j] = e >= E ? e - E : e + ORC_QP - E;
         }
+        for (u32 q = 0; q < k; ++q) {
+            u64* a = row + (size_t)q * N;
+            for (u32 j = 0; j < N; ++j) a[j] = (u64)(((u128)orc_rng_u64(r) * ORC_QP) >> 64);
+            qp_mul_binary(c, a, glwe_sk + (size_t)q * N, tmp);
+            for (u32 j = 0; j < N; ++j) body[j] = qp_add(body[j], tmp[j]);
+        }
+        if (msg) row[(size_t)rr * N] = qp_add(row[(size_t)rr * N], G % ORC_QP);
+    }
+}
+
+void orc_gen_bsk_qp(const orc_ctx* c, const uint64_t* lwe_sk, const uint64_t* glwe_sk, orc_rng* r, uint64_t* bsk) {
+    const orc_params* P = &c->prm;
+    const size_t per = (size_t)(P->glwe_dim + 1) * (P->glwe_dim + 1) * P->poly_size;
+    u64* tmp = (u64*)malloc(sizeof(u64) * P->poly_size);
+    for (u32 i = 0; i < P->lwe_dim; ++i) gen_ggsw_qp(c, lwe_sk[i], glwe_sk, r, bsk + (size_t)i * per, tmp);
+    free(tmp);
+}
+
+/* Grouped key: the LWE key bits are taken in pairs (s, s') = (s_2g, s_2g+1) (s' = 0 past the end of
+ * an odd-length key); group g holds three GGSWs, of s(1-s'), (1-s)s' and s s'. */
+size_t orc_bsk_qp_grouped_count(const orc_params* p) { return 3 * (((size_t)p->lwe_dim + 1) / 2); }
+
+void orc_gen_bsk_qp_grouped(const orc_ctx* c, const uint64_t* lwe_sk, const uint64_t* glwe_sk, orc_rng* r,
+                            uint64_t* bsk) {
+    const orc_params* P = &c->prm;
+    const size_t per = (size_t)(P->glwe_dim + 1) * (P->glwe_dim + 1) * P->poly_size;
+    const u32 groups = (P->lwe_dim + 1) / 2;
+    u64* tmp = (u64*)malloc(sizeof(u64) * P->poly_size);
+    for (u32 g = 0; g < groups; ++g) {
+        const u64 s0 = lwe_sk[2 * g], s1 = 2 * g + 1 < P->lwe_dim ? lwe_sk[2 * g + 1] : 0;
+        const u64 msg[3] = {s0 & (1 - s1), (1 - s0) & s1, s0 & s1};
+        for (u32 m = 0; m < 3; ++m) gen_ggsw_qp(c, msg[m], glwe_sk, r, bsk + ((size_t)3 * g + m) * per, tmp);
+    }
     free(tmp);
 }
 
@@ -879,14 +904,23 @@ void orc_external_product_qp(const orc_ctx* c, const uint64_t* ggsw, const uint6
     free(hat);
 }
 
-orc_prepared_bsk* orc_bsk_qp_prepare(const orc_ctx* c, const uint64_t* bsk) {
+static orc_prepared_bsk* bsk_qp_prepare_n(const orc_ctx* c, const u64* bsk, size_t count, u32 grouping) {
     const orc_params* P = &c->prm;
     const size_t per = (size_t)(P->glwe_dim + 1) * (P->glwe_dim + 1) * P->poly_size;
     orc_prepared_bsk* b = (orc_prepared_bsk*)malloc(sizeof *b);
     b->per_ggsw = per;
-    b->hat = (u64*)malloc(sizeof(u64) * per * P->lwe_dim);
-    for (u32 i = 0; i < P->lwe_dim; ++i) ggsw_qp_to_hat(c, bsk + (size_t)i * per, b->hat + (size_t)i * per);
+    b->grouping = grouping;
+    b->hat = (u64*)malloc(sizeof(u64) * per * count);
+    for (size_t i = 0; i < count; ++i) ggsw_qp_to_hat(c, bsk + i * per, b->hat + i * per);
     return b;
+}
+
+orc_prepared_bsk* orc_bsk_qp_prepare(const orc_ctx* c, const uint64_t* bsk) {
+    return bsk_qp_prepare_n(c, bsk, c->prm.lwe_dim, 1);
+}
+
+orc_prepared_bsk* orc_bsk_qp_grouped_prepare(const orc_ctx* c, const uint64_t* bsk) {
+    return bsk_qp_prepare_n(c, bsk, orc_bsk_qp_grouped_count(&c->prm), 2);
 }
 
 /* X^rot * in over Z_q' */
@@ -898,8 +932,90 @@ static void qp_monomial_mul(u64* out, const u64* in, u32 rot, u32 N) {
     }
 }
 
+/* Two mask elements per step:  acc <- B [.] acc  with the GGSW
+ *     B = I + (X^a - 1) GGSW(s(1-s')) + (X^a' - 1) GGSW((1-s)s') + (X^(a+a') - 1) GGSW(s s'),
+ * an encryption of X^(a s + a' s'); I is the noiseless GGSW of 1 (gadget on the diagonal).  B is
+ * formed in the transform domain, where a monomial is a point-wise factor, so a step costs one
+ * external product.  The accumulator is replaced, not added to: what the gadget decomposition
+ * rounds away (|.| <= G/2 per coefficient and step) stays in the error instead of being carried. */
+/* one step: acc <- B [.] acc for the three NTT-domain GGSWs at hat3 and the exponents a0, a1 */
+static void group_step_hat(const orc_ctx* c, const u64* hat3, size_t per, u32 a0, u32 a1, u64* acc) {
+    const orc_params* P = &c->prm;
+    const u32 N = P->poly_size, k1 = P->glwe_dim + 1;
+    const mont_t* M = &c->qp.m;
+    const u64 G = orc_qp_gadget(c) % ORC_QP;
+    const u32 a[3] = {a0, a1, (a0 + a1) % (2 * N)};
+    u64* tmp = (u64*)malloc(sizeof(u64) * ((size_t)k1 * N * 2 + 3 * (size_t)N));
+    u64 *dig = tmp, *out = tmp + (size_t)k1 * N, *mono = tmp + (size_t)2 * k1 * N;
+    /* transform of X^a - 1, Montgomery form */
+    for (u32 m = 0; m < 3; ++m) {
+        u64* mm = mono + (size_t)m * N;
+        memset(mm, 0, sizeof(u64) * N);
+        if (a[m] < N) mm[a[m]] = 1; else mm[a[m] - N] = ORC_QP - 1;
+        mm[0] = qp_sub(mm[0], 1);
+        ntt_fwd(&c->qp, mm, N);
+        for (u32 j = 0; j < N; ++j) mm[j] = to_mont(M, mm[j]);
+    }
+    for (u32 rr = 0; rr < k1; ++rr) {
+        u64* d = dig + (size_t)rr * N;
+        for (u32 j = 0; j < N; ++j) {
+            const i64 dg = orc_qp_digit(c, acc[(size_t)rr * N + j]);
+            d[j] = dg < 0 ? (u64)(dg + (i64)ORC_QP) : (u64)dg;
+        }
+        ntt_fwd(&c->qp, d, N);
+    }
+    for (u32 cc = 0; cc < k1; ++cc) {
+        u64* o = out + (size_t)cc * N;
+        for (u32 j = 0; j < N; ++j) {
+            u64 sum = 0;
+            for (u32 rr = 0; rr < k1; ++rr) {
+                u64 b = rr == cc ? G : 0;
+                for (u32 m = 0; m < 3; ++m) {
+                    /* both factors are Montgomery forms: two reductions give the plain product */
+                    const u64 h = hat3[(size_t)m * per + ((size_t)rr * k1 + cc) * N + j];
+                    b = qp_add(b, mont_mul(M, mont_mul(M, mono[(size_t)m * N + j], h), 1));
+                }
+                sum = qp_add(sum, mont_mul(M, dig[(size_t)rr * N + j], to_mont(M, b)));
+            }
+            o[j] = sum;
+        }
+        ntt_inv(&c->qp, o, N);
+    }
+    memcpy(acc, out, sizeof(u64) * (size_t)k1 * N);
+    free(tmp);
+}
+
+void orc_group_step_qp(const orc_ctx* c, const uint64_t* ggsw3, uint32_t a0, uint32_t a1, uint64_t* acc) {
+    const u32 N = c->prm.poly_size, k1 = c->prm.glwe_dim + 1;
+    const size_t per = (size_t)k1 * k1 * N;
+    u64* hat = (u64*)malloc(sizeof(u64) * 3 * per);
+    for (u32 m = 0; m < 3; ++m) ggsw_qp_to_hat(c, ggsw3 + (size_t)m * per, hat + (size_t)m * per);
+    group_step_hat(c, hat, per, a0, a1, acc);
+    free(hat);
+}
+
+static void blind_rotate_qp_grouped(const orc_ctx* c, const orc_prepared_bsk* pb, const u64* lwe_small,
+                                    const u64* lut, u64* acc) {
+    const orc_params* P = &c->prm;
+    const u32 N = P->poly_size, k1 = P->glwe_dim + 1, n = P->lwe_dim;
+    const u32 log2n = c->logN + 1, groups = (n + 1) / 2;
+    u64* tmp = (u64*)malloc(sizeof(u64) * (size_t)k1 * N);
+    for (size_t j = 0; j < (size_t)k1 * N; ++j) tmp[j] = orc_to_qp(lut[j]);
+    const u32 bt = orc_modswitch(lwe_small[n], log2n);
+    for (u32 q = 0; q < k1; ++q)
+        qp_monomial_mul(acc + (size_t)q * N, tmp + (size_t)q * N, (2 * N - bt) % (2 * N), N);
+    free(tmp);
+    for (u32 g = 0; g < groups; ++g) {
+        const u32 a0 = orc_modswitch(lwe_small[2 * g], log2n);
+        const u32 a1 = 2 * g + 1 < n ? orc_modswitch(lwe_small[2 * g + 1], log2n) : 0;
+        if (a0 == 0 && a1 == 0) continue;   /* B = I: skipped, the accumulator is left as it is */
+        group_step_hat(c, pb->hat + (size_t)3 * g * pb->per_ggsw, pb->per_ggsw, a0, a1, acc);
+    }
+}
+
 void orc_blind_rotate_qp(const orc_ctx* c, const orc_prepared_bsk* pb, const uint64_t* lwe_small,
                          const uint64_t* lut, uint64_t* acc) {
+    if (pb->grouping == 2) { blind_rotate_qp_grouped(c, pb, lwe_small, lut, acc); return; }
     const orc_params* P = &c->prm;
     const u32 N = P->poly_size, k1 = P->glwe_dim + 1, n = P->lwe_dim;
     const u32 log2n = c->logN + 1;

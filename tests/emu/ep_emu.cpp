@@ -73,6 +73,64 @@ static int run_case(const orc_ctx* oc, const HostTables& H, const Tables& T, con
     return bad;
 }
 
+// ---- one step of the grouped blind rotation (single ring modulus): phases 0-4, the grouped
+// point-wise stage, phases 6-11, against orc_group_step_qp
+template <int PH, int END>
+static void run_phases_q(std::vector<EpState>& st, double* lds, const Tables& T) {
+    if constexpr (PH < END) {
+        for (int t = 0; t < NT; ++t) ep_phase<PH, false, true>(st[t], lds, t, T, nullptr);
+        run_phases_q<PH + 1, END>(st, lds, T);
+    }
+}
+
+static void make_bskq_rows(const HostTables& H, const u64* ggsw3, std::vector<double>& rows) {
+    rows.assign(3 * BSKQ_ROW, 0.0);
+    const u64 p = H.p[0];
+    const u64 ninv = h_powmod(N, p - 2, p);
+    std::vector<u64> out(N);
+    for (int m = 0; m < 3; ++m)
+        for (int q = 0; q < 4; ++q) {
+            orc_ntt_definition(p, H.psi[0], ggsw3 + ((size_t)m * 4 + q) * N, out.data(), N);
+            for (int e = 0; e < N; ++e) {
+                const u64 v = h_mulmod(out[h_bitrev((u32)e, LOGN)], ninv, p);
+                rows[(size_t)m * BSKQ_ROW + bsk_off(0, q, (e & 7) >> 1, e >> 3) + (e & 1)] = h_centred(v, p);
+            }
+        }
+}
+
+static int run_group_case(const orc_ctx* oc, const HostTables& H, const Tables& T, const std::vector<double>& mono,
+                          const u64* ggsw3, const u64* acc_in, unsigned a0, unsigned a1, const char* name) {
+    std::vector<double> rows;
+    make_bskq_rows(H, ggsw3, rows);
+    const u64 p = H.p[0];
+    const u64 G = orc_qp_gadget(oc);
+    const double inv_g = 1.0 / (double)G;
+    const double gconst = h_centred(h_mulmod(G % p, h_powmod(N, p - 2, p), p), p);
+    std::vector<EpState> st(NT);
+    std::vector<double> lds(LDS_WORDS, 0.0);
+    for (int t = 0; t < NT; ++t)
+        for (int q = 0; q < 2; ++q)
+            for (int j = 0; j < E; ++j)
+                st[t].x[q][j] = __builtin_rint(h_centred(acc_in[q * N + own1(t, j)], p) * inv_g);
+    run_phases_q<0, 5>(st, lds.data(), T);
+    for (int t = 0; t < NT; ++t) ep_group2_phase5(st[t], lds.data(), t, T, mono.data(), rows.data(), a0, a1, gconst);
+    run_phases_q<6, 12>(st, lds.data(), T);
+    std::vector<u64> want(acc_in, acc_in + 2 * N);
+    orc_group_step_qp(oc, ggsw3, a0, a1, want.data());
+    int bad = 0;
+    for (int t = 0; t < NT; ++t)
+        for (int q = 0; q < 2; ++q)
+            for (int j = 0; j < E; ++j) {
+                const double c = mnorm(st[t].x[q][j], T.pr[0]);
+                const u64 got = c < 0 ? p - (u64)(-c) : (u64)c;
+                if (got != want[q * N + own1(t, j)]) ++bad;
+            }
+    printf("%-28s mismatches: %d   max|x| = 2^%.2f = %.2f p\n", name, bad, log2(track_max_ref()), track_max_ref() / P0);
+    if (track_max_ref() >= 9007199254740992.0) { printf("lazy-reduction bound exceeded\n"); ++bad; }
+    track_max_ref() = 0;
+    return bad;
+}
+
 int main() {
     HostTables H;
     build_host_tables(H);
@@ -119,6 +177,22 @@ int main() {
     for (int i = 0; i < 4 * N; ++i) ggsw[i] = rnd();
     for (int i = 0; i < 2 * N; ++i) glwe[i] = (rnd() & 1) ? (1ull << 63) : (1ull << 63) + (1ull << 41);
     bad += run_case(oc, H, T, ggsw.data(), glwe.data(), "extreme-digits-random-key");
+    // grouped step over the prime ring modulus
+    {
+        const u64 p = H.p[0];
+        std::vector<double> mono(MONO_WORDS);
+        for (int k = 0; k < MONO_WORDS; ++k) mono[k] = h_centred((h_powmod(H.psi[0], k, p) + p - 1) % p, p);
+        T.mono = mono.data();
+        std::vector<u64> g3(3 * 4 * N), acc(2 * N);
+        for (auto& v : g3) v = rnd() % p;
+        for (auto& v : acc) v = rnd() % p;
+        bad += run_group_case(oc, H, T, mono, g3.data(), acc.data(), 1234, 3071, "grouped random");
+        bad += run_group_case(oc, H, T, mono, g3.data(), acc.data(), 0, 4095, "grouped a0 = 0");
+        bad += run_group_case(oc, H, T, mono, g3.data(), acc.data(), 2048, 2048, "grouped a0 + a1 = 2N");
+        for (auto& v : g3) v = p / 2;
+        for (int i = 0; i < 2 * N; ++i) acc[i] = (i & 1) ? p / 2 : p / 2 + 1;
+        bad += run_group_case(oc, H, T, mono, g3.data(), acc.data(), 4095, 1, "grouped extreme");
+    }
     orc_ctx_free(oc);
     if (bad) { printf("FAIL\n"); return 1; }
     printf("OK\n");

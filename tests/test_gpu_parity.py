@@ -192,9 +192,10 @@ def test_ms_noise_reduction_bit_exact(full):
 
 
 # ---- bootstrap over the prime ring modulus (bootstrapping key and accumulator in Z_q') ------------
-def _mk_prime(n, seed, ms_zeros=0, wide=True):
+def _mk_prime(n, seed, ms_zeros=0, wide=True, grouped=False):
     """wide=False forces the 256-thread blind rotation for small launches too (by default launches
-    of up to two ciphertexts per CU take the 512-thread kernel)."""
+    of up to two ciphertexts per CU take the 512-thread kernel).  grouped: the key with three GGSWs
+    per pair of key bits, blind rotation in (n + 1) / 2 steps."""
     import os
     from fhe_amd.native import Context, Params, default_params, BSK_MODULUS_PRIME
     os.environ.pop("LFHE_WIDE_BELOW", None)
@@ -203,9 +204,11 @@ def _mk_prime(n, seed, ms_zeros=0, wide=True):
     op = OParams(lwe_dim=n)
     orc = Oracle(op)
     lwe_sk, glwe_sk, _, ksk = orc.gen_keys(seed_bytes(seed))
-    bskq = orc.gen_bsk_qp(lwe_sk, glwe_sk, seed_bytes(seed))
+    gen = orc.gen_bsk_qp_grouped if grouped else orc.gen_bsk_qp
+    bskq = gen(lwe_sk, glwe_sk, seed_bytes(seed))
     p = Params(**{k: getattr(op, k) for k in op.__dataclass_fields__})
     p.bsk_modulus = BSK_MODULUS_PRIME
+    p.bsk_grouping = 2 if grouped else 1
     zeros = None
     if ms_zeros:
         d = default_params()
@@ -288,7 +291,68 @@ def test_prime_modulus_pbs_full_parameters(wide):
         ctx.close()
 
 
-@pytest.mark.parametrize("params_id", [1, 2])
+@pytest.mark.parametrize("n", [12, 13])
+def test_grouped_key_blind_rotation_bit_exact(n):
+    """Two key bits per step: accumulators and bootstrapped ciphertexts equal the oracle's bit for
+    bit, for an even and an odd key length, including all-zero masks (every step skipped) and masks
+    whose pairs cancel (a + a' = 2N)."""
+    orc, keys, ctx = _mk_prime(n, seed=6, grouped=True)
+    try:
+        lwe_sk, glwe_sk, bskg, ksk = keys
+        pb = orc.prepare_bsk_qp_grouped(bskg)
+        r = Rng(seed_bytes(29))
+        f = [lambda x: x, lambda x: (3 * x + 1) % 16]
+        luts_o = [orc.make_lut(g) for g in f]
+        luts_g = np.stack([ctx.make_lut(g) for g in f])
+        smalls = np.stack([r.u64s(orc.n + 1) for _ in range(6)])
+        smalls[3][:] = 0
+        smalls[4][0::2] = np.uint64(1 << 63)          # a = N for every first element of a pair
+        smalls[4][1:n:2] = np.uint64(1 << 63)         # ... and a' = N: a + a' = 2N
+        smalls[5][0:n:2] = 0                          # a = 0, a' random
+        li = np.array([0, 1, 1, 0, 1, 0], dtype=np.uint32)
+        got = ctx.blind_rotate(smalls, luts_g, li)
+        for c in range(6):
+            assert np.array_equal(got[c].reshape(-1), orc.blind_rotate_qp(pb, smalls[c], luts_o[li[c]])), c
+        cts = np.stack([orc.encrypt_block(glwe_sk, m, r) for m in range(16)])
+        li = np.array([m % 2 for m in range(16)], dtype=np.uint32)
+        out = ctx.pbs_batch(cts, luts_g, li)
+        for m in range(16):
+            assert np.array_equal(out[m], orc.pbs_qp(ksk, pb, cts[m], luts_o[li[m]])), m
+            assert orc.decrypt_block(glwe_sk, out[m]) == f[li[m]](m) % 16
+    finally:
+        ctx.close()
+
+
+def test_grouped_key_pbs_full_parameters():
+    """n = 918, noise reduction on, grouped key: outputs decrypt to f(m), a subsample is
+    bit-identical to the oracle, the output noise stays far below half a message step."""
+    orc, keys, ctx = _mk_prime(918, seed=7, ms_zeros=1449, grouped=True)
+    try:
+        lwe_sk, glwe_sk, bskg, ksk = keys
+        pb = orc.prepare_bsk_qp_grouped(bskg)
+        r = Rng(seed_bytes(30))
+        f = [lambda x: x, lambda x: (x * x + 3) % 16]
+        luts_o = [orc.make_lut(g) for g in f]
+        luts_g = np.stack([ctx.make_lut(g) for g in f])
+        B = 600                                       # more than two per CU: a full-occupancy launch
+        msgs = [int(r.u64() % 16) for _ in range(B)]
+        cts = np.stack([orc.encrypt_block(glwe_sk, m, r) for m in msgs])
+        idx = np.array([i % 2 for i in range(B)], dtype=np.uint32)
+        out = ctx.pbs_batch(cts, luts_g, idx)
+        worst = 0
+        for i in range(B):
+            want = f[idx[i]](msgs[i]) % 16
+            assert orc.decrypt_block(glwe_sk, out[i]) == want, i
+            e = (orc.lwe_phase(glwe_sk, out[i]) - orc.encode(want)) % (1 << 64)
+            worst = max(worst, min(e, (1 << 64) - e))
+        assert worst < 1 << 53            # half a message step is 2^58
+        for i in (0, 1, 333, 599):
+            assert np.array_equal(out[i], orc.pbs_qp(ksk, pb, cts[i], luts_o[idx[i]])), i
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("params_id", [1, 2, 3])
 def test_library_keygen_round_trip(params_id):
     """Keys made by the library itself (both bootstrapping-key moduli): encrypt -> bootstrap ->
     decrypt, and the oracle decrypts library ciphertexts with the exported secret key."""

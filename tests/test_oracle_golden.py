@@ -227,3 +227,49 @@ def test_ntt_definition_is_the_transform_the_product_uses():
     psi_inv = pow(int(psi), p - 2, p)
     got = [(ninv * sum(int(Cc[j]) * pow(psi_inv, (2 * j + 1) * n, p) for j in range(N))) % p for n in range(N)]
     assert got == list(want)
+
+
+@pytest.mark.parametrize("n", [12, 13])
+def test_grouped_key_blind_rotation_over_prime_modulus(n):
+    """Two key bits per step (three GGSWs per pair, identity pattern noiseless): the bootstrap
+    evaluates the table, and the accumulator is the rotated table up to noise -- for an even and an
+    odd key length (the odd one pads the last pair with a zero bit)."""
+    orc = Oracle(Params(lwe_dim=n))
+    lwe_sk, glwe_sk, _, ksk = orc.gen_keys(seed_bytes(21))
+    bskg = orc.gen_bsk_qp_grouped(lwe_sk, glwe_sk, seed_bytes(21))
+    assert bskg.size == 3 * ((n + 1) // 2) * orc.ggsw_words()
+    assert int(bskg.max()) < orc.qp
+    pb = orc.prepare_bsk_qp_grouped(bskg)
+    pb1 = orc.prepare_bsk_qp(orc.gen_bsk_qp(lwe_sk, glwe_sk, seed_bytes(21)))
+    r = Rng(seed_bytes(22))
+    f = lambda x: (7 * x + 2) % 16
+    lut = orc.make_lut(f)
+    q = orc.qp
+    for m in range(16):
+        ct = orc.encrypt_block(glwe_sk, m, r)
+        out = orc.pbs_qp(ksk, pb, ct, lut)
+        assert orc.decrypt_block(glwe_sk, out) == f(m)
+        # the grouped and the one-bit rotation end on the same plaintext polynomial: their
+        # accumulators differ by noise only
+        small = orc.keyswitch(ksk, ct)
+        a2 = orc.blind_rotate_qp(pb, small, lut).astype(object)
+        a1 = orc.blind_rotate_qp(pb1, small, lut).astype(object)
+        def phase(acc):   # b - a (*) s over Z_q'
+            a, b = acc[:orc.N], acc[orc.N:]
+            out = list(b)
+            s = [int(v) for v in glwe_sk]
+            for i, si in enumerate(s):
+                if si:
+                    for j in range(orc.N):
+                        k = i + j
+                        if k < orc.N:
+                            out[k] -= a[j]
+                        else:
+                            out[k - orc.N] += a[j]
+            return [int(v) % q for v in out]
+        if m < 2:
+            d = [(x - y) % q for x, y in zip(phase(a2), phase(a1))]
+            assert max(min(v, q - v) for v in d) < q >> 8
+    # all-zero mask: no step runs, the accumulator is the table itself, rotated by the body
+    small = np.zeros(n + 1, dtype=np.uint64)
+    assert np.array_equal(orc.blind_rotate_qp(pb, small, lut), orc.blind_rotate_qp(pb1, small, lut))
