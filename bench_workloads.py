@@ -29,7 +29,8 @@ def main():
     ap.add_argument("--bids", type=int, default=1000, help="total over all GPUs")
     ap.add_argument("--mul-batch", type=int, default=256,
                     help="random pairs, total over all GPUs (the reference's vectors are added)")
-    ap.add_argument("--bsk-modulus", choices=["q64", "prime"], default="prime")
+    ap.add_argument("--bsk-modulus", choices=["q64", "prime", "grouped"], default="grouped",
+                    help="bootstrapping key: over 2^64, over the NTT prime, or over the prime with the key bits in pairs")
     args = ap.parse_args()
 
     import torch
@@ -51,7 +52,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     seed = bytes((11 * i + 5) & 0xFF for i in range(32))
-    ctx, keep = replicated_context(dist, rank, world, dev, seed, 2 if args.bsk_modulus == "prime" else 1)
+    ctx, keep = replicated_context(dist, rank, world, dev, seed, {"q64": 1, "prime": 2, "grouped": 3}[args.bsk_modulus])
 
     def timed(fn):
         """Wall time of fn over all ranks: barrier on both sides, maximum over ranks."""

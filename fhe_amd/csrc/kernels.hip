@@ -10,6 +10,7 @@
 // rest.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <utility>
 
 #include "engine.h"
@@ -541,7 +542,9 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q_wide(Tables T, con
 // exchange buffer), multiplies, transforms back and REPLACES the accumulator -- no rotated reads,
 // hence no accumulator copy in LDS.  (n + 1) / 2 steps of one external product each.
 // ------------------------------------------------------------------------------------------------
-static constexpr size_t LDS_BYTES_G2 = LDS_BYTES + (size_t)MONO_WORDS * sizeof(double);
+// MODE 0: table of psi^k - 1 (k < 2N) in LDS; 1: psi^k (k < N) in LDS; 2: the full table read from global memory
+template <int MODE>
+static constexpr size_t LDS_BYTES_G2 = LDS_BYTES + (size_t)(MODE == 2 ? 0 : MODE == 1 ? N : MONO_WORDS) * sizeof(double);
 
 template <int... PH>
 __device__ __forceinline__ void epq_run_range(EpState& s, double* lds, unsigned t, const Tables& T,
@@ -551,6 +554,7 @@ __device__ __forceinline__ void epq_run_range(EpState& s, double* lds, unsigned 
 template <int FIRST, int... K>
 constexpr auto phase_range(std::integer_sequence<int, K...>) { return std::integer_sequence<int, (FIRST + K)...>{}; }
 
+template <int MODE>
 __global__ void __launch_bounds__(NT, LFHE_BRQ_WAVES) k_blind_rotate_q2(Tables T, const double* __restrict__ bsk,
                                                                         const u64* __restrict__ lwe_small, int n,
                                                                         const u64* __restrict__ luts,
@@ -563,8 +567,11 @@ __global__ void __launch_bounds__(NT, LFHE_BRQ_WAVES) k_blind_rotate_q2(Tables T
     const Prime P = T.pr[0];
     const u64* __restrict__ lwe = lwe_small + ct * (size_t)(n + 1);
     const u64* __restrict__ lut = luts + (size_t)(lut_index ? lut_index[omap.ops ? ct % omap.ops : ct] : 0) * N;
-    double* mono = lds_dyn + LDS_WORDS;
-    for (unsigned i = t; i < (unsigned)MONO_WORDS; i += NT) mono[i] = T.mono[i];
+    constexpr bool HALF = MODE == 1;
+    double* mono_lds = lds_dyn + LDS_WORDS;
+    if constexpr (MODE == 1) { for (unsigned i = t; i < (unsigned)N; i += NT) mono_lds[i] = T.mono[MONO_WORDS + i]; }
+    if constexpr (MODE == 0) { for (unsigned i = t; i < (unsigned)MONO_WORDS; i += NT) mono_lds[i] = T.mono[i]; }
+    const double* mono = MODE == 2 ? T.mono : mono_lds;
 
     double acc[2][E];
     {
@@ -598,7 +605,7 @@ __global__ void __launch_bounds__(NT, LFHE_BRQ_WAVES) k_blind_rotate_q2(Tables T
         load_tw8(T.tw_fwd[0], base2(tt), s.tw);   // twiddles of the next pass, one phase ahead
         __syncthreads();
         epq_run_range(s, lds_dyn, t, T, phase_range<1>(std::make_integer_sequence<int, 4>{}));
-        ep_group2_phase5(s, lds_dyn, t, T, mono, bsk + (size_t)3 * g * BSKQ_ROW, a0, a1, gconst);
+        ep_group2_phase5<HALF>(s, lds_dyn, t, T, mono, bsk + (size_t)3 * g * BSKQ_ROW, a0, a1, gconst);
         __syncthreads();
         epq_run_range(s, lds_dyn, t, T, phase_range<6>(std::make_integer_sequence<int, 5>{}));
         ep_phase<11, false, true>(s, lds_dyn, t, T, nullptr);
@@ -628,6 +635,143 @@ __global__ void __launch_bounds__(NT, LFHE_BRQ_WAVES) k_blind_rotate_q2(Tables T
     }
 }
 
+// The grouped blind rotation for launches too small to fill the GPU: 512 threads per ciphertext, one
+// half per polynomial as in k_blind_rotate_q_wide.  Each half forms the two entries of the step's
+// GGSW that feed its own output polynomial.  Results are bit-identical to k_blind_rotate_q2.
+__global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q2_wide(Tables T, const double* __restrict__ bsk,
+                                                                    const u64* __restrict__ lwe_small, int n,
+                                                                    const u64* __restrict__ luts,
+                                                                    const u32* __restrict__ lut_index,
+                                                                    u64* __restrict__ glwe_out,
+                                                                    u64* __restrict__ lwe_out, BlockMap omap,
+                                                                    double inv_g, double gconst) {
+    const unsigned h = threadIdx.x >> 8;   // polynomial of this half (wave-uniform)
+    const unsigned t0 = threadIdx.x & (NT - 1);
+    const size_t ct = blockIdx.x;
+    const Prime P = T.pr[0];
+    const u64* __restrict__ lwe = lwe_small + ct * (size_t)(n + 1);
+    const u64* __restrict__ lut = luts + (size_t)(lut_index ? lut_index[omap.ops ? ct % omap.ops : ct] : 0) * N;
+    double* mine = lds_dyn + h * POLY_STRIDE;
+    double* theirs = lds_dyn + (1 - h) * POLY_STRIDE;
+    double* mono = lds_dyn + LDS_WORDS;    // psi^k, k < N
+    const double* __restrict__ twf = T.tw_fwd[0];
+    const double* __restrict__ twi = T.tw_inv[0];
+    for (unsigned i = threadIdx.x; i < (unsigned)N; i += 2 * NT) mono[i] = T.mono[MONO_WORDS + i];
+
+    double acc[E], x[E], w[7];
+    {
+        const unsigned bt = modswitch_2n(lwe[n]);
+        const unsigned a = (2 * N - bt) & (2 * N - 1);  // multiply by X^-b~
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            bool neg;
+            const double v = torus_to_qp(lut[rot_index(own1(t0, j), a, neg)]);
+            acc[j] = h ? (neg ? -v : v) : 0.0;
+        }
+    }
+    __syncthreads();
+
+    const int groups = (n + 1) / 2;
+    for (int g = 0; g < groups; ++g) {
+        const unsigned a0 = modswitch_2n(lwe[2 * g]);
+        const unsigned a1 = 2 * g + 1 < n ? modswitch_2n(lwe[2 * g + 1]) : 0u;
+        if ((a0 | a1) == 0) continue;
+        unsigned t = t0;
+        asm volatile("" : "+v"(t));  // addresses are recomputed per step instead of living in registers
+        // this step's key words go into registers now (the point-wise stage is half a step away):
+        // kx multiplies this half's own digits, ky the other half's; polynomial index q = j_in * 2 + c_out
+        double kx[3][E], ky[3][E];
+        {
+            const double* __restrict__ rows = bsk + (size_t)3 * g * BSKQ_ROW;
+#pragma unroll
+            for (unsigned m = 0; m < 3; ++m)
+#pragma unroll
+                for (unsigned c4 = 0; c4 < 4; ++c4) {
+                    const unsigned o0 = m * (unsigned)BSKQ_ROW + bsk_off(0, 3 * h, c4, t);
+                    const unsigned o1 = m * (unsigned)BSKQ_ROW + bsk_off(0, 2 - h, c4, t);
+#pragma unroll
+                    for (unsigned k = 0; k < 2; ++k) { kx[m][2 * c4 + k] = ldt(rows, o0 + k); ky[m][2 * c4 + k] = ldt(rows, o1 + k); }
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < E; ++j) x[j] = __builtin_rint(acc[j] * inv_g);
+        ct_radix8(x, twf, 1, P);
+        st_o1p12(mine, t, x); load_tw8(twf, base2(t), w);
+        __syncthreads();
+        ld_o2p12(mine, t, x); ct_radix8(x, w, P);
+        __syncthreads();
+        st_o2p23(mine, t, x); load_tw8(twf, base3(t), w);
+        __syncthreads();
+        ld_o3p23(mine, t, x); ct_radix8(x, w, P);
+        __syncthreads();
+        st_o3p34(mine, t, x); load_tw4x2(twf, t, w);
+        __syncthreads();
+        ld_o4p34(mine, t, x); ct_radix4x2(x, w, P);
+#pragma unroll
+        for (int j = 0; j < E; ++j) x[j] = mnorm(x[j], P);
+        // publish the transformed digits (a thread rewrites the words it has just read) and fetch
+        // the other polynomial's
+        st_o4p34(mine, t, x); load_tw4x2(twi, t, w);
+        __syncthreads();
+        {
+            double y[E];
+            ld_o4p34(theirs, t, y);
+            const unsigned ut = 2 * rev8(t) + 1;
+            const unsigned am[3] = {a0, a1, (a0 + a1) & (2 * N - 1)};
+            constexpr unsigned R3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+            double o[E];
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                double bx = 0, by = 0;
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    const unsigned idx = (am[m] * ut + ((am[m] * R3[j]) << 9)) & (2 * N - 1);
+                    const double M = mono_at<true>(mono, idx);
+                    const double vx = mmul(M, kx[m][j], P), vy = mmul(M, ky[m][j], P);
+                    bx = m == 0 ? vx : bx + vx;
+                    by = m == 0 ? vy : by + vy;
+                }
+                o[j] = mmul(bx + gconst, x[j], P) + mmul(by, y[j], P);
+            }
+#pragma unroll
+            for (int j = 0; j < E; ++j) x[j] = o[j];
+        }
+        gs_radix4x2<GS_NORM_PASS4[0], GS_NORM_PASS4[1]>(x, w, P);
+        __syncthreads();                      // the other half has read this buffer
+        st_o4p34(mine, t, x); load_tw8(twi, base3(t), w);
+        __syncthreads();
+        ld_o3p34(mine, t, x); gs_radix8<GS_NORM_PASS3[0], GS_NORM_PASS3[1], GS_NORM_PASS3[2]>(x, w, P);
+        __syncthreads();
+        st_o3p23(mine, t, x); load_tw8(twi, base2(t), w);
+        __syncthreads();
+        ld_o2p23(mine, t, x); gs_radix8<GS_NORM_PASS2[0], GS_NORM_PASS2[1], GS_NORM_PASS2[2]>(x, w, P);
+        __syncthreads();
+        st_o2p12(mine, t, x);
+        __syncthreads();
+        ld_o1p12(mine, t, x); gs_radix8<GS_NORM_PASS1[0], GS_NORM_PASS1[1], GS_NORM_PASS1[2]>(x, twi, 1, P);
+#pragma unroll
+        for (int j = 0; j < E; ++j) acc[j] = qp_canon(x[j], P);
+        __syncthreads();                      // the last pass's reads are done before the buffer is reused
+    }
+
+    if (glwe_out) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const double c = acc[j];
+            glwe_out[(ct * 2 + h) * N + own1(t0, j)] = c < 0 ? QP_U - (u64)(-c) : (u64)c;
+        }
+    }
+    if (lwe_out) {  // sample extraction of coefficient 0, every word switched back to 2^64
+        u64* o = lwe_out + omap.block(ct) * (size_t)(N + 1);
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const unsigned e = own1(t0, j);
+            if (h == 0) o[e == 0 ? 0 : N - e] = qp_to_torus(e == 0 ? acc[j] : -acc[j]);
+            else if (e == 0) o[N] = qp_to_torus(acc[j]);
+        }
+    }
+}
+
 void launch_bskq_prepare(const Tables& T, const u64* in, double* out, size_t polys, hipStream_t st) {
     hipLaunchKernelGGL(k_bskq_prepare, dim3((unsigned)polys), dim3(NT), LDS_BYTES, st, T, in, out);
 }
@@ -640,9 +784,22 @@ void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_sm
                            const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
                            const BlockMap& omap, double inv_g, int wide_below, int grouping, double gconst,
                            hipStream_t st) {
+    if (grouping == 2 && count <= (size_t)wide_below) {
+        hipLaunchKernelGGL(k_blind_rotate_q2_wide, dim3((unsigned)count), dim3(2 * NT), LDS_BYTES_G2<1>, st, T, bsk,
+                           lwe_small, n, luts, lut_index, glwe_out, lwe_out, omap, inv_g, gconst);
+        return;
+    }
     if (grouping == 2) {
-        hipLaunchKernelGGL(k_blind_rotate_q2, dim3((unsigned)count), dim3(NT), LDS_BYTES_G2, st, T, bsk, lwe_small, n,
-                           luts, lut_index, glwe_out, lwe_out, omap, inv_g, gconst);
+        static const int mode = [] { const char* e = std::getenv("LFHE_G2_MODE"); return e ? std::atoi(e) : 1; }();
+        if (mode == 2)
+            hipLaunchKernelGGL(k_blind_rotate_q2<2>, dim3((unsigned)count), dim3(NT), LDS_BYTES_G2<2>, st, T, bsk,
+                               lwe_small, n, luts, lut_index, glwe_out, lwe_out, omap, inv_g, gconst);
+        else if (mode == 1)
+            hipLaunchKernelGGL(k_blind_rotate_q2<1>, dim3((unsigned)count), dim3(NT), LDS_BYTES_G2<1>, st, T, bsk,
+                               lwe_small, n, luts, lut_index, glwe_out, lwe_out, omap, inv_g, gconst);
+        else
+            hipLaunchKernelGGL(k_blind_rotate_q2<0>, dim3((unsigned)count), dim3(NT), LDS_BYTES_G2<0>, st, T, bsk,
+                               lwe_small, n, luts, lut_index, glwe_out, lwe_out, omap, inv_g, gconst);
         return;
     }
     // up to two ciphertexts per CU: latency matters more than throughput, use 512 threads each

@@ -15,7 +15,7 @@ struct Tables {
     double two32[2];           // 2^32 mod p, centred
     double ninv[2];            // N^-1 mod p, centred
     double p0inv_mod_p1;       // centred
-    const double* mono;        // [2N] psi^k - 1 over prime 0, centred (grouped blind rotation)
+    const double* mono;        // [2N] psi^k - 1 over prime 0, centred, then [N] psi^k (grouped blind rotation)
 };
 
 // Bootstrapping key on the device: f64 residues, N^-1 folded in, transform (bit-reversed) order,
@@ -191,6 +191,18 @@ LFHE_HD unsigned rev8(unsigned t) {
 #endif
 }
 
+// HALF: `mono` holds psi^k for k < N only (half the LDS); psi^(k+N) = -psi^k and the -1 are applied here
+template <bool HALF>
+LFHE_HD double mono_at(const double* mono, unsigned idx) {
+    if constexpr (HALF) {
+        const double v = mono[idx & (N - 1)];
+        return ((idx & N) ? -v : v) - 1.0;
+    } else {
+        return mono[idx];
+    }
+}
+
+template <bool HALF = false>
 LFHE_HD void ep_group2_phase5(EpState& s, double* lds, unsigned t, const Tables& T, const double* mono,
                               const double* __restrict__ rows, unsigned a1, unsigned a2, double gconst) {
     const Prime P = T.pr[0];
@@ -236,7 +248,7 @@ LFHE_HD void ep_group2_phase5(EpState& s, double* lds, unsigned t, const Tables&
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const unsigned idx = (base[m] + ((am[m] * R3[2 * c4 + h]) << 9)) & (2 * N - 1);
-                const double M = mono[idx];
+                const double M = mono_at<HALF>(mono, idx);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const double v = mmul(M, kc[q][h], P);
@@ -252,11 +264,11 @@ LFHE_HD void ep_group2_phase5(EpState& s, double* lds, unsigned t, const Tables&
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int j = 2 * c4 + h;
-            const double B00 = mnorm(B[0][h] + gconst, P), B01 = mnorm(B[1][h], P);
-            const double B10 = mnorm(B[2][h], P), B11 = mnorm(B[3][h] + gconst, P);
-            const double d0 = s.x[0][j], d1 = s.x[1][j];
-            s.x[0][j] = mmul(d0, B00, P) + mmul(d1, B10, P);
-            s.x[1][j] = mmul(d0, B01, P) + mmul(d1, B11, P);
+            // the transformed digits are brought to |d| <= p/2 (two reductions per point instead of
+            // four for B); B enters as the wide operand, |B| < 2.2 p
+            const double d0 = mnorm(s.x[0][j], P), d1 = mnorm(s.x[1][j], P);
+            s.x[0][j] = mmul(B[0][h] + gconst, d0, P) + mmul(B[2][h], d1, P);
+            s.x[1][j] = mmul(B[1][h], d0, P) + mmul(B[3][h] + gconst, d1, P);
         }
     }
     gs_radix4x2<GS_NORM_PASS4[0], GS_NORM_PASS4[1]>(s.x[0], s.tw, P);

@@ -291,12 +291,13 @@ def test_prime_modulus_pbs_full_parameters(wide):
         ctx.close()
 
 
+@pytest.mark.parametrize("wide", [True, False], ids=["512-thread", "256-thread"])
 @pytest.mark.parametrize("n", [12, 13])
-def test_grouped_key_blind_rotation_bit_exact(n):
+def test_grouped_key_blind_rotation_bit_exact(n, wide):
     """Two key bits per step: accumulators and bootstrapped ciphertexts equal the oracle's bit for
     bit, for an even and an odd key length, including all-zero masks (every step skipped) and masks
     whose pairs cancel (a + a' = 2N)."""
-    orc, keys, ctx = _mk_prime(n, seed=6, grouped=True)
+    orc, keys, ctx = _mk_prime(n, seed=6, grouped=True, wide=wide)
     try:
         lwe_sk, glwe_sk, bskg, ksk = keys
         pb = orc.prepare_bsk_qp_grouped(bskg)
@@ -348,6 +349,8 @@ def test_grouped_key_pbs_full_parameters():
         assert worst < 1 << 53            # half a message step is 2^58
         for i in (0, 1, 333, 599):
             assert np.array_equal(out[i], orc.pbs_qp(ksk, pb, cts[i], luts_o[idx[i]])), i
+        # a small launch takes the 512-thread kernel: same bits
+        assert np.array_equal(ctx.pbs_batch(cts[:8], luts_g, idx[:8]), out[:8])
     finally:
         ctx.close()
 

@@ -78,6 +78,10 @@ def check_header(path):
     f = forward()
     assert f[-1] < LIMIT and forward(0.5)[-1] < LIMIT        # digits, and canonical inputs (key preparation)
     w, x, n = inverse(schedule_from_header(path), 2 * prod(f[-1]))
+    # grouped blind rotation: the step's GGSW entry is a sum of three products of operands <= p/2
+    # plus the gadget constant (<= p/2), and multiplies a normalised digit: the point-wise sum is
+    # smaller than the one the schedule was checked for
+    assert 2 * prod(3 * prod(0.5) + 0.5) <= 2 * prod(f[-1])
     return w, max(x), n
 
 
