@@ -44,7 +44,7 @@ Engine::Engine(int device, const EngineParams& p) : device_(device), prm_(p) {
 
     HostTables H;
     build_host_tables(H);
-    HC(hipMalloc(&d_tw_, sizeof(double) * (4 * N + MONO_WORDS + N)));
+    HC(hipMalloc(&d_tw_, sizeof(double) * (4 * N + MONO_WORDS + 8)));
     for (int r = 0; r < 2; ++r) {
         HC(hipMemcpy(d_tw_ + (2 * r) * N, H.tw_fwd[r].data(), sizeof(double) * N, hipMemcpyHostToDevice));
         HC(hipMemcpy(d_tw_ + (2 * r + 1) * N, H.tw_inv[r].data(), sizeof(double) * N, hipMemcpyHostToDevice));
@@ -56,12 +56,13 @@ Engine::Engine(int device, const EngineParams& p) : device_(device), prm_(p) {
         T_.ninv[r] = H.ninv[r];
     }
     T_.p0inv_mod_p1 = H.p0inv_mod_p1;
-    {   // psi^k - 1 over prime 0 for every exponent k of X^k (k < 2N), and the identity's diagonal
-        std::vector<double> mono(MONO_WORDS + N);
+    {   // psi^k over prime 0 for every exponent k of X^k (k < 2N), the 8th roots of unity, and the
+        // diagonal of the identity GGSW
+        std::vector<double> mono(MONO_WORDS + 8);
         u64 w = 1;
         for (int k = 0; k < MONO_WORDS; ++k) {
-            mono[k] = h_centred((w + H.p[0] - 1) % H.p[0], H.p[0]);
-            if (k < N) mono[MONO_WORDS + k] = h_centred(w, H.p[0]);
+            mono[k] = h_centred(w, H.p[0]);
+            if (k % (N / 4) == 0) mono[MONO_WORDS + k / (N / 4)] = h_centred(w, H.p[0]);
             w = h_mulmod(w, H.psi[0], H.p[0]);
         }
         HC(hipMemcpy(d_tw_ + 4 * N, mono.data(), sizeof(double) * mono.size(), hipMemcpyHostToDevice));

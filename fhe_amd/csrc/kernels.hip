@@ -538,14 +538,9 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q_wide(Tables T, con
 // ------------------------------------------------------------------------------------------------
 // Blind rotation with two mask elements per step (grouped key, pbs_phases.h: ep_group2_phase5).
 // The accumulator lives in registers only: a step decomposes it, transforms the digits, forms the
-// step's GGSW point by point from three key rows and the monomial table (kept in LDS behind the
-// exchange buffer), multiplies, transforms back and REPLACES the accumulator -- no rotated reads,
-// hence no accumulator copy in LDS.  (n + 1) / 2 steps of one external product each.
+// step's GGSW point by point from three key rows and the monomial factors, multiplies, transforms
+// back and REPLACES the accumulator -- no rotated reads, hence no accumulator copy in LDS.  (n + 1) / 2 steps of one external product each.
 // ------------------------------------------------------------------------------------------------
-// MODE 0: table of psi^k - 1 (k < 2N) in LDS; 1: psi^k (k < N) in LDS; 2: the full table read from global memory
-template <int MODE>
-static constexpr size_t LDS_BYTES_G2 = LDS_BYTES + (size_t)(MODE == 2 ? 0 : MODE == 1 ? N : MONO_WORDS) * sizeof(double);
-
 template <int... PH>
 __device__ __forceinline__ void epq_run_range(EpState& s, double* lds, unsigned t, const Tables& T,
                                               std::integer_sequence<int, PH...>) {
@@ -554,8 +549,7 @@ __device__ __forceinline__ void epq_run_range(EpState& s, double* lds, unsigned 
 template <int FIRST, int... K>
 constexpr auto phase_range(std::integer_sequence<int, K...>) { return std::integer_sequence<int, (FIRST + K)...>{}; }
 
-template <int MODE>
-__global__ void __launch_bounds__(NT, LFHE_BRQ_WAVES) k_blind_rotate_q2(Tables T, const double* __restrict__ bsk,
+__global__ void __launch_bounds__(NT, 4) k_blind_rotate_q2(Tables T, const double* __restrict__ bsk,
                                                                         const u64* __restrict__ lwe_small, int n,
                                                                         const u64* __restrict__ luts,
                                                                         const u32* __restrict__ lut_index,
@@ -567,11 +561,6 @@ __global__ void __launch_bounds__(NT, LFHE_BRQ_WAVES) k_blind_rotate_q2(Tables T
     const Prime P = T.pr[0];
     const u64* __restrict__ lwe = lwe_small + ct * (size_t)(n + 1);
     const u64* __restrict__ lut = luts + (size_t)(lut_index ? lut_index[omap.ops ? ct % omap.ops : ct] : 0) * N;
-    constexpr bool HALF = MODE == 1;
-    double* mono_lds = lds_dyn + LDS_WORDS;
-    if constexpr (MODE == 1) { for (unsigned i = t; i < (unsigned)N; i += NT) mono_lds[i] = T.mono[MONO_WORDS + i]; }
-    if constexpr (MODE == 0) { for (unsigned i = t; i < (unsigned)MONO_WORDS; i += NT) mono_lds[i] = T.mono[i]; }
-    const double* mono = MODE == 2 ? T.mono : mono_lds;
 
     double acc[2][E];
     {
@@ -605,7 +594,7 @@ __global__ void __launch_bounds__(NT, LFHE_BRQ_WAVES) k_blind_rotate_q2(Tables T
         load_tw8(T.tw_fwd[0], base2(tt), s.tw);   // twiddles of the next pass, one phase ahead
         __syncthreads();
         epq_run_range(s, lds_dyn, t, T, phase_range<1>(std::make_integer_sequence<int, 4>{}));
-        ep_group2_phase5<HALF>(s, lds_dyn, t, T, mono, bsk + (size_t)3 * g * BSKQ_ROW, a0, a1, gconst);
+        ep_group2_phase5(s, lds_dyn, t, T, bsk + (size_t)3 * g * BSKQ_ROW, a0, a1, gconst);
         __syncthreads();
         epq_run_range(s, lds_dyn, t, T, phase_range<6>(std::make_integer_sequence<int, 5>{}));
         ep_phase<11, false, true>(s, lds_dyn, t, T, nullptr);
@@ -653,10 +642,8 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q2_wide(Tables T, co
     const u64* __restrict__ lut = luts + (size_t)(lut_index ? lut_index[omap.ops ? ct % omap.ops : ct] : 0) * N;
     double* mine = lds_dyn + h * POLY_STRIDE;
     double* theirs = lds_dyn + (1 - h) * POLY_STRIDE;
-    double* mono = lds_dyn + LDS_WORDS;    // psi^k, k < N
     const double* __restrict__ twf = T.tw_fwd[0];
     const double* __restrict__ twi = T.tw_inv[0];
-    for (unsigned i = threadIdx.x; i < (unsigned)N; i += 2 * NT) mono[i] = T.mono[MONO_WORDS + i];
 
     double acc[E], x[E], w[7];
     {
@@ -718,21 +705,33 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q2_wide(Tables T, co
             ld_o4p34(theirs, t, y);
             const unsigned ut = 2 * rev8(t) + 1;
             const unsigned am[3] = {a0, a1, (a0 + a1) & (2 * N - 1)};
-            constexpr unsigned R3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
-            double o[E];
+            const double* __restrict__ w8 = T.mono + MONO_WORDS;
+            double base[3];
 #pragma unroll
-            for (int j = 0; j < E; ++j) {
-                double bx = 0, by = 0;
+            for (int m = 0; m < 3; ++m) base[m] = ldt(T.mono, (am[m] * ut) & (2 * N - 1));
+            double o[E];
+            auto chunk = [&](auto c4_tag) {
+                constexpr int c4 = decltype(c4_tag)::value;
+                double bx[2], by[2];
 #pragma unroll
                 for (int m = 0; m < 3; ++m) {
-                    const unsigned idx = (am[m] * ut + ((am[m] * R3[j]) << 9)) & (2 * N - 1);
-                    const double M = mono_at<true>(mono, idx);
-                    const double vx = mmul(M, kx[m][j], P), vy = mmul(M, ky[m][j], P);
-                    bx = m == 0 ? vx : bx + vx;
-                    by = m == 0 ? vy : by + vy;
+                    double M[2];
+                    mono_pair<c4>(base[m], w8, am[m], P, M[0], M[1]);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const double vx = mmul(M[k], kx[m][2 * c4 + k], P), vy = mmul(M[k], ky[m][2 * c4 + k], P);
+                        bx[k] = m == 0 ? vx : bx[k] + vx;
+                        by[k] = m == 0 ? vy : by[k] + vy;
+                    }
                 }
-                o[j] = mmul(bx + gconst, x[j], P) + mmul(by, y[j], P);
-            }
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    o[2 * c4 + k] = mmul(bx[k] + gconst, x[2 * c4 + k], P) + mmul(by[k], y[2 * c4 + k], P);
+            };
+            chunk(std::integral_constant<int, 0>{});
+            chunk(std::integral_constant<int, 1>{});
+            chunk(std::integral_constant<int, 2>{});
+            chunk(std::integral_constant<int, 3>{});
 #pragma unroll
             for (int j = 0; j < E; ++j) x[j] = o[j];
         }
@@ -785,21 +784,13 @@ void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_sm
                            const BlockMap& omap, double inv_g, int wide_below, int grouping, double gconst,
                            hipStream_t st) {
     if (grouping == 2 && count <= (size_t)wide_below) {
-        hipLaunchKernelGGL(k_blind_rotate_q2_wide, dim3((unsigned)count), dim3(2 * NT), LDS_BYTES_G2<1>, st, T, bsk,
+        hipLaunchKernelGGL(k_blind_rotate_q2_wide, dim3((unsigned)count), dim3(2 * NT), LDS_BYTES, st, T, bsk,
                            lwe_small, n, luts, lut_index, glwe_out, lwe_out, omap, inv_g, gconst);
         return;
     }
     if (grouping == 2) {
-        static const int mode = [] { const char* e = std::getenv("LFHE_G2_MODE"); return e ? std::atoi(e) : 1; }();
-        if (mode == 2)
-            hipLaunchKernelGGL(k_blind_rotate_q2<2>, dim3((unsigned)count), dim3(NT), LDS_BYTES_G2<2>, st, T, bsk,
-                               lwe_small, n, luts, lut_index, glwe_out, lwe_out, omap, inv_g, gconst);
-        else if (mode == 1)
-            hipLaunchKernelGGL(k_blind_rotate_q2<1>, dim3((unsigned)count), dim3(NT), LDS_BYTES_G2<1>, st, T, bsk,
-                               lwe_small, n, luts, lut_index, glwe_out, lwe_out, omap, inv_g, gconst);
-        else
-            hipLaunchKernelGGL(k_blind_rotate_q2<0>, dim3((unsigned)count), dim3(NT), LDS_BYTES_G2<0>, st, T, bsk,
-                               lwe_small, n, luts, lut_index, glwe_out, lwe_out, omap, inv_g, gconst);
+        hipLaunchKernelGGL(k_blind_rotate_q2, dim3((unsigned)count), dim3(NT), LDS_BYTES, st, T, bsk, lwe_small, n,
+                           luts, lut_index, glwe_out, lwe_out, omap, inv_g, gconst);
         return;
     }
     // up to two ciphertexts per CU: latency matters more than throughput, use 512 threads each

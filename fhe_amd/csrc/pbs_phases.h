@@ -3,6 +3,8 @@
 // kernels run phase, __syncthreads(), phase, ...; the host build runs each phase for all 256
 // threads in turn.  Same code, same LDS image.
 #pragma once
+#include <type_traits>
+
 #include "pbs_device.h"
 
 namespace lfhe {
@@ -15,7 +17,7 @@ struct Tables {
     double two32[2];           // 2^32 mod p, centred
     double ninv[2];            // N^-1 mod p, centred
     double p0inv_mod_p1;       // centred
-    const double* mono;        // [2N] psi^k - 1 over prime 0, centred, then [N] psi^k (grouped blind rotation)
+    const double* mono;        // [2N] psi^k over prime 0, centred, then [8] psi^(N k / 4) (grouped blind rotation)
 };
 
 // Bootstrapping key on the device: f64 residues, N^-1 folded in, transform (bit-reversed) order,
@@ -191,19 +193,21 @@ LFHE_HD unsigned rev8(unsigned t) {
 #endif
 }
 
-// HALF: `mono` holds psi^k for k < N only (half the LDS); psi^(k+N) = -psi^k and the -1 are applied here
-template <bool HALF>
-LFHE_HD double mono_at(const double* mono, unsigned idx) {
-    if constexpr (HALF) {
-        const double v = mono[idx & (N - 1)];
-        return ((idx & N) ? -v : v) - 1.0;
-    } else {
-        return mono[idx];
-    }
+// The factors psi^(e u) - 1 of X^e at the two positions 8 t + 2 c4 + {0, 1}, whose exponents are
+// u = u_t + 512 r and u_t + 512 (r + 4) with r = bitrev3(2 c4) in {0, 2, 1, 3}, u_t odd:
+// psi^(e u_t) comes from the table of all 2N powers once per thread (`base`); psi^(512 e r) =
+// w8^(e r mod 8) is one of the eight 8th roots of unity, the same for every thread of the
+// ciphertext (a scalar); and psi^(2048 e) = (-1)^e turns the first position's power into the
+// second's.  One modular product per pair of positions, none for c4 = 0.
+template <int C4>
+LFHE_HD void mono_pair(double base, const double* __restrict__ w8, unsigned e, const Prime& P, double& m0, double& m1) {
+    constexpr unsigned R[4] = {0, 2, 1, 3};
+    const double pw = C4 == 0 ? base : mmul(base, w8[(e * R[C4]) & 7u], P);
+    m0 = pw - 1.0;
+    m1 = __builtin_fma(pw, (e & 1u) ? -1.0 : 1.0, -1.0);
 }
 
-template <bool HALF = false>
-LFHE_HD void ep_group2_phase5(EpState& s, double* lds, unsigned t, const Tables& T, const double* mono,
+LFHE_HD void ep_group2_phase5(EpState& s, double* lds, unsigned t, const Tables& T,
                               const double* __restrict__ rows, unsigned a1, unsigned a2, double gconst) {
     const Prime P = T.pr[0];
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -211,28 +215,32 @@ LFHE_HD void ep_group2_phase5(EpState& s, double* lds, unsigned t, const Tables&
     asm volatile("" : "+v"(t));
     asm volatile("" : "+s"(zero));
     const double* __restrict__ twi = T.tw_inv[0] + zero;
+    const double* __restrict__ mono = T.mono + zero;
 #else
     const double* __restrict__ twi = T.tw_inv[0];
+    const double* __restrict__ mono = T.mono;
 #endif
+    // psi^(e u_t) for the three exponents, u_t = 2 rev8(t) + 1: three gathers, in flight during the
+    // last forward pass
+    const unsigned ut = 2 * rev8(t) + 1;
+    const unsigned am[3] = {a1, a2, (a1 + a2) & (2 * N - 1)};
+    double base[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) base[m] = ldt(mono, (am[m] * ut) & (2 * N - 1));
     double* b0 = lds;
     double* b1 = lds + POLY_STRIDE;
     ld_o4p34(b0, t, s.x[0]); ld_o4p34(b1, t, s.x[1]);
     ct_radix4x2(s.x[0], s.tw, P); ct_radix4x2(s.x[1], s.tw, P);
     load_tw4x2(twi, t, s.tw);   // for the inverse pass below
     // position 8 t + j evaluates at psi^(2 bitrev11(8 t + j) + 1) = psi^(512 bitrev3(j) + 2 rev8(t) + 1)
-    const unsigned ut = 2 * rev8(t) + 1;
-    const unsigned am[3] = {a1, a2, (a1 + a2) & (2 * N - 1)};
-    unsigned base[3];
-#pragma unroll
-    for (int m = 0; m < 3; ++m) base[m] = am[m] * ut;
-    constexpr unsigned R3[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+    const double* __restrict__ w8 = mono + MONO_WORDS;
     // key words of unit u = 3 c4 + m: row m, the four polynomials q, positions 8 t + 2 c4 + {0, 1};
     // the next unit's four 16-byte loads are in flight while this one is multiplied
     double kc[4][2], kn[4][2];
 #pragma unroll
     for (unsigned q = 0; q < 4; ++q) { const unsigned o = bsk_off(0, q, 0, t); kc[q][0] = LFHE_LDK(rows, o); kc[q][1] = LFHE_LDK(rows, o + 1); }
-#pragma unroll
-    for (int c4 = 0; c4 < 4; ++c4) {
+    auto chunk = [&](auto c4_tag) {
+        constexpr int c4 = decltype(c4_tag)::value;
         double B[4][2];
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
@@ -245,16 +253,15 @@ LFHE_HD void ep_group2_phase5(EpState& s, double* lds, unsigned t, const Tables&
                     kn[q][0] = LFHE_LDK(rows, o); kn[q][1] = LFHE_LDK(rows, o + 1);
                 }
             }
+            double M[2];
+            mono_pair<c4>(base[m], w8, am[m], P, M[0], M[1]);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const unsigned idx = (base[m] + ((am[m] * R3[2 * c4 + h]) << 9)) & (2 * N - 1);
-                const double M = mono_at<HALF>(mono, idx);
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const double v = mmul(M, kc[q][h], P);
+                    const double v = mmul(M[h], kc[q][h], P);
                     B[q][h] = m == 0 ? v : B[q][h] + v;
                 }
-            }
 #if defined(__HIP_DEVICE_COMPILE__)
             asm volatile("" ::: "memory");
 #endif
@@ -270,7 +277,11 @@ LFHE_HD void ep_group2_phase5(EpState& s, double* lds, unsigned t, const Tables&
             s.x[0][j] = mmul(B[0][h] + gconst, d0, P) + mmul(B[2][h], d1, P);
             s.x[1][j] = mmul(B[1][h], d0, P) + mmul(B[3][h] + gconst, d1, P);
         }
-    }
+    };
+    chunk(std::integral_constant<int, 0>{});
+    chunk(std::integral_constant<int, 1>{});
+    chunk(std::integral_constant<int, 2>{});
+    chunk(std::integral_constant<int, 3>{});
     gs_radix4x2<GS_NORM_PASS4[0], GS_NORM_PASS4[1]>(s.x[0], s.tw, P);
     gs_radix4x2<GS_NORM_PASS4[0], GS_NORM_PASS4[1]>(s.x[1], s.tw, P);
 }

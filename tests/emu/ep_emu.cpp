@@ -98,7 +98,7 @@ static void make_bskq_rows(const HostTables& H, const u64* ggsw3, std::vector<do
         }
 }
 
-static int run_group_case(const orc_ctx* oc, const HostTables& H, const Tables& T, const std::vector<double>& mono,
+static int run_group_case(const orc_ctx* oc, const HostTables& H, const Tables& T,
                           const u64* ggsw3, const u64* acc_in, unsigned a0, unsigned a1, const char* name) {
     std::vector<double> rows;
     make_bskq_rows(H, ggsw3, rows);
@@ -113,7 +113,7 @@ static int run_group_case(const orc_ctx* oc, const HostTables& H, const Tables& 
             for (int j = 0; j < E; ++j)
                 st[t].x[q][j] = __builtin_rint(h_centred(acc_in[q * N + own1(t, j)], p) * inv_g);
     run_phases_q<0, 5>(st, lds.data(), T);
-    for (int t = 0; t < NT; ++t) ep_group2_phase5(st[t], lds.data(), t, T, mono.data(), rows.data(), a0, a1, gconst);
+    for (int t = 0; t < NT; ++t) ep_group2_phase5(st[t], lds.data(), t, T, rows.data(), a0, a1, gconst);
     run_phases_q<6, 12>(st, lds.data(), T);
     std::vector<u64> want(acc_in, acc_in + 2 * N);
     orc_group_step_qp(oc, ggsw3, a0, a1, want.data());
@@ -180,18 +180,22 @@ int main() {
     // grouped step over the prime ring modulus
     {
         const u64 p = H.p[0];
-        std::vector<double> mono(MONO_WORDS);
-        for (int k = 0; k < MONO_WORDS; ++k) mono[k] = h_centred((h_powmod(H.psi[0], k, p) + p - 1) % p, p);
-        T.mono = mono.data();
+        // the table as the engine lays it out: psi^k (k < 2N), then the 8th roots of unity
+        std::vector<double> table(MONO_WORDS + 8);
+        for (int k = 0; k < MONO_WORDS; ++k) {
+            table[k] = h_centred(h_powmod(H.psi[0], k, p), p);
+            if (k % (N / 4) == 0) table[MONO_WORDS + k / (N / 4)] = table[k];
+        }
+        T.mono = table.data();
         std::vector<u64> g3(3 * 4 * N), acc(2 * N);
         for (auto& v : g3) v = rnd() % p;
         for (auto& v : acc) v = rnd() % p;
-        bad += run_group_case(oc, H, T, mono, g3.data(), acc.data(), 1234, 3071, "grouped random");
-        bad += run_group_case(oc, H, T, mono, g3.data(), acc.data(), 0, 4095, "grouped a0 = 0");
-        bad += run_group_case(oc, H, T, mono, g3.data(), acc.data(), 2048, 2048, "grouped a0 + a1 = 2N");
+        bad += run_group_case(oc, H, T, g3.data(), acc.data(), 1234, 3071, "grouped random");
+        bad += run_group_case(oc, H, T, g3.data(), acc.data(), 0, 4095, "grouped a0 = 0");
+        bad += run_group_case(oc, H, T, g3.data(), acc.data(), 2048, 2048, "grouped a0 + a1 = 2N");
         for (auto& v : g3) v = p / 2;
         for (int i = 0; i < 2 * N; ++i) acc[i] = (i & 1) ? p / 2 : p / 2 + 1;
-        bad += run_group_case(oc, H, T, mono, g3.data(), acc.data(), 4095, 1, "grouped extreme");
+        bad += run_group_case(oc, H, T, g3.data(), acc.data(), 4095, 1, "grouped extreme");
     }
     orc_ctx_free(oc);
     if (bad) { printf("FAIL\n"); return 1; }
