@@ -56,8 +56,7 @@ Engine::Engine(int device, const EngineParams& p) : device_(device), prm_(p) {
         T_.ninv[r] = H.ninv[r];
     }
     T_.p0inv_mod_p1 = H.p0inv_mod_p1;
-    {   // psi^k over prime 0 for every exponent k of X^k (k < 2N), the 8th roots of unity, and the
-        // diagonal of the identity GGSW
+    {   // psi^k over prime 0 for every exponent k of X^k (k < 2N), then the 8th roots of unity
         std::vector<double> mono(MONO_WORDS + 8);
         u64 w = 1;
         for (int k = 0; k < MONO_WORDS; ++k) {
@@ -67,7 +66,6 @@ Engine::Engine(int device, const EngineParams& p) : device_(device), prm_(p) {
         }
         HC(hipMemcpy(d_tw_ + 4 * N, mono.data(), sizeof(double) * mono.size(), hipMemcpyHostToDevice));
         T_.mono = d_tw_ + 4 * N;
-        gconst_ = h_centred(h_mulmod(qp_gadget() % H.p[0], h_powmod(N, H.p[0] - 2, H.p[0]), H.p[0]), H.p[0]);
     }
 }
 
@@ -235,7 +233,7 @@ void Engine::blind_rotate(const u64* lwe_small, const u64* luts, const u32* lut_
     HC(hipSetDevice(device_));
     if (single_modulus())
         launch_blind_rotate_q(T_, d_bsk_, lwe_small, (int)prm_.lwe_dim, luts, lut_index, glwe_out, lwe_out, count, omap,
-                              1.0 / (double)qp_gadget(), wide_below_, (int)prm_.bsk_grouping, gconst_, stream_);
+                              1.0 / (double)qp_gadget(), wide_below_, (int)prm_.bsk_grouping, stream_);
     else
         launch_blind_rotate(T_, d_bsk_, lwe_small, (int)prm_.lwe_dim, luts, lut_index, glwe_out, lwe_out, count, omap,
                             stream_);

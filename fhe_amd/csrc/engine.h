@@ -40,7 +40,7 @@ struct EngineParams {
     // lift), QP_U = the NTT prime itself (single transform, modulus switch on the way in and out)
     uint64_t bsk_modulus = 0;
     // key bits per blind-rotation step: 1, or 2 (needs the prime ring modulus): the key then holds
-    // three GGSWs per pair of bits and a step is one external product for two mask elements
+    // four GGSWs per pair of bits and a step is one external product for two mask elements
     uint32_t bsk_grouping = 1;
 };
 
@@ -57,8 +57,7 @@ void launch_external_product_q(const Tables& T, const double* bsk, const u32* id
                                size_t count, double inv_g, hipStream_t st);
 void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
                            const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
-                           const BlockMap& omap, double inv_g, int wide_below, int grouping, double gconst,
-                           hipStream_t st);
+                           const BlockMap& omap, double inv_g, int wide_below, int grouping, hipStream_t st);
 void launch_lin_batch(u64* arena, const LinOp* ops, int nops, size_t instances, size_t inst_stride_blocks, u64 delta,
                       hipStream_t st);
 void launch_ksk_colsum(const u64* ksk, int rows, int cols, int half_base, u64* colsum, hipStream_t st);
@@ -86,7 +85,7 @@ public:
     bool has_keys() const { return d_bsk_ && d_ksk_; }
 
     // GGSWs in the bootstrapping key
-    size_t bsk_ggsw_count() const { return prm_.bsk_grouping == 2 ? 3 * (((size_t)prm_.lwe_dim + 1) / 2) : prm_.lwe_dim; }
+    size_t bsk_ggsw_count() const { return prm_.bsk_grouping == 2 ? 4 * (((size_t)prm_.lwe_dim + 1) / 2) : prm_.lwe_dim; }
     size_t bsk_raw_words() const { return bsk_ggsw_count() * 4 * N; }
     size_t ksk_words() const { return (size_t)N * prm_.ks_level * (prm_.lwe_dim + 1); }
     bool single_modulus() const { return prm_.bsk_modulus != 0; }
@@ -154,7 +153,6 @@ private:
     size_t ksdig_cap_ = 0;
     MsParams ms_{};
     int cu_count_ = 256;
-    double gconst_ = 0;     // gadget * N^-1 mod q', centred (grouped blind rotation)
     int wide_below_ = -1;   // launches of at most this many ciphertexts use 512 threads each
     void set_ms_params(u32 zcount);
     u64* ms_zeros_dev() const { return d_ksk_ + ksk_words() + prm_.lwe_dim + 1 + 1; }

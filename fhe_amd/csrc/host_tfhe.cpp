@@ -122,13 +122,14 @@ void gen_bsk_qp(const EngineParams& p, const uint64_t* lwe_sk, const uint64_t* g
     const uint64_t Q = QP_U;
     const uint64_t G = (Q + (1ull << (p.pbs_base_log - 1))) >> p.pbs_base_log;
     const uint64_t E = (uint64_t)((((unsigned __int128)1 << p.glwe_noise_log2) * Q + ((unsigned __int128)1 << 63)) >> 64);
-    // the bit each GGSW encrypts: the key bits themselves, or per pair (s, s') the three products
-    // s(1-s'), (1-s)s', s s' (s' = 0 past the end of an odd-length key)
+    // the bit each GGSW encrypts: the key bits themselves, or per pair (s, s') the four products
+    // (1-s)(1-s'), s(1-s'), (1-s)s', s s' (s' = 0 past the end of an odd-length key)
     std::vector<uint64_t> msg;
     if (p.bsk_grouping == 2) {
         for (uint32_t g = 0; 2 * g < p.lwe_dim; ++g) {
             const uint64_t s0 = lwe_sk[2 * g], s1 = 2 * g + 1 < p.lwe_dim ? lwe_sk[2 * g + 1] : 0;
-            msg.push_back(s0 & (1 - s1)); msg.push_back((1 - s0) & s1); msg.push_back(s0 & s1);
+            msg.push_back((1 - s0) & (1 - s1)); msg.push_back(s0 & (1 - s1));
+            msg.push_back((1 - s0) & s1); msg.push_back(s0 & s1);
         }
     } else {
         msg.assign(lwe_sk, lwe_sk + p.lwe_dim);

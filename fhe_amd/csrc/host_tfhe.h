@@ -37,7 +37,7 @@ uint64_t lwe_phase(const uint64_t* sk, size_t dim, const uint64_t* ct);
 void gen_bsk(const EngineParams& p, const uint64_t* lwe_sk, const uint64_t* glwe_sk, const uint8_t seed[32],
              uint64_t* bsk, int threads);
 // the bootstrapping key over the prime ring modulus (EngineParams::bsk_modulus), same layout; with
-// EngineParams::bsk_grouping == 2 three GGSWs per pair of key bits: bsk[group][3][row][poly][N]
+// EngineParams::bsk_grouping == 2 four GGSWs per pair of key bits: bsk[group][4][row][poly][N]
 void gen_bsk_qp(const EngineParams& p, const uint64_t* lwe_sk, const uint64_t* glwe_sk, const uint8_t seed[32],
                 uint64_t* bsk, int threads);
 // stream_base separates the generator streams of different keys made from one seed

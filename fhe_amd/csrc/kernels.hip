@@ -541,10 +541,15 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q_wide(Tables T, con
 // step's GGSW point by point from three key rows and the monomial factors, multiplies, transforms
 // back and REPLACES the accumulator -- no rotated reads, hence no accumulator copy in LDS.  (n + 1) / 2 steps of one external product each.
 // ------------------------------------------------------------------------------------------------
+#ifdef LFHE_ABLATE_NO_BARRIER   // timing experiment only: results are wrong
+#define LFHE_G2_SYNC() ((void)0)
+#else
+#define LFHE_G2_SYNC() __syncthreads()
+#endif
 template <int... PH>
 __device__ __forceinline__ void epq_run_range(EpState& s, double* lds, unsigned t, const Tables& T,
                                               std::integer_sequence<int, PH...>) {
-    ((ep_phase<PH, false, true>(s, lds, t, T, nullptr), __syncthreads()), ...);
+    ((ep_phase<PH, false, true>(s, lds, t, T, nullptr), LFHE_G2_SYNC()), ...);
 }
 template <int FIRST, int... K>
 constexpr auto phase_range(std::integer_sequence<int, K...>) { return std::integer_sequence<int, (FIRST + K)...>{}; }
@@ -555,7 +560,7 @@ __global__ void __launch_bounds__(NT, 4) k_blind_rotate_q2(Tables T, const doubl
                                                                         const u32* __restrict__ lut_index,
                                                                         u64* __restrict__ glwe_out,
                                                                         u64* __restrict__ lwe_out, BlockMap omap,
-                                                                        double inv_g, double gconst) {
+                                                                        double inv_g) {
     const unsigned t = threadIdx.x;
     const size_t ct = blockIdx.x;
     const Prime P = T.pr[0];
@@ -574,7 +579,7 @@ __global__ void __launch_bounds__(NT, 4) k_blind_rotate_q2(Tables T, const doubl
             acc[1][j] = neg ? -v : v;
         }
     }
-    __syncthreads();
+    LFHE_G2_SYNC();
 
     EpState s;
     const int groups = (n + 1) / 2;
@@ -592,17 +597,17 @@ __global__ void __launch_bounds__(NT, 4) k_blind_rotate_q2(Tables T, const doubl
         ct_radix8(s.x[1], T.tw_fwd[0], 1, P);
         st_o1p12(lds_dyn, tt, s.x[0]); st_o1p12(lds_dyn + POLY_STRIDE, tt, s.x[1]);
         load_tw8(T.tw_fwd[0], base2(tt), s.tw);   // twiddles of the next pass, one phase ahead
-        __syncthreads();
+        LFHE_G2_SYNC();
         epq_run_range(s, lds_dyn, t, T, phase_range<1>(std::make_integer_sequence<int, 4>{}));
-        ep_group2_phase5(s, lds_dyn, t, T, bsk + (size_t)3 * g * BSKQ_ROW, a0, a1, gconst);
-        __syncthreads();
+        ep_group2_phase5(s, lds_dyn, t, T, bsk + (size_t)4 * g * BSKQ_ROW, a0, a1);
+        LFHE_G2_SYNC();
         epq_run_range(s, lds_dyn, t, T, phase_range<6>(std::make_integer_sequence<int, 5>{}));
         ep_phase<11, false, true>(s, lds_dyn, t, T, nullptr);
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int j = 0; j < E; ++j) acc[q][j] = qp_canon(s.x[q][j], P);
-        __syncthreads();  // the last pass's reads are done before the next step overwrites the buffer
+        LFHE_G2_SYNC();  // the last pass's reads are done before the next step overwrites the buffer
     }
     if (glwe_out) {
 #pragma unroll
@@ -633,7 +638,7 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q2_wide(Tables T, co
                                                                     const u32* __restrict__ lut_index,
                                                                     u64* __restrict__ glwe_out,
                                                                     u64* __restrict__ lwe_out, BlockMap omap,
-                                                                    double inv_g, double gconst) {
+                                                                    double inv_g) {
     const unsigned h = threadIdx.x >> 8;   // polynomial of this half (wave-uniform)
     const unsigned t0 = threadIdx.x & (NT - 1);
     const size_t ct = blockIdx.x;
@@ -667,11 +672,11 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q2_wide(Tables T, co
         asm volatile("" : "+v"(t));  // addresses are recomputed per step instead of living in registers
         // this step's key words go into registers now (the point-wise stage is half a step away):
         // kx multiplies this half's own digits, ky the other half's; polynomial index q = j_in * 2 + c_out
-        double kx[3][E], ky[3][E];
+        double kx[4][E], ky[4][E];
         {
-            const double* __restrict__ rows = bsk + (size_t)3 * g * BSKQ_ROW;
+            const double* __restrict__ rows = bsk + (size_t)4 * g * BSKQ_ROW;
 #pragma unroll
-            for (unsigned m = 0; m < 3; ++m)
+            for (unsigned m = 0; m < 4; ++m)
 #pragma unroll
                 for (unsigned c4 = 0; c4 < 4; ++c4) {
                     const unsigned o0 = m * (unsigned)BSKQ_ROW + bsk_off(0, 3 * h, c4, t);
@@ -712,21 +717,20 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q2_wide(Tables T, co
             double o[E];
             auto chunk = [&](auto c4_tag) {
                 constexpr int c4 = decltype(c4_tag)::value;
-                double bx[2], by[2];
+                double bx[2] = {kx[0][2 * c4], kx[0][2 * c4 + 1]}, by[2] = {ky[0][2 * c4], ky[0][2 * c4 + 1]};
 #pragma unroll
-                for (int m = 0; m < 3; ++m) {
+                for (int m = 1; m < 4; ++m) {
                     double M[2];
-                    mono_pair<c4>(base[m], w8, am[m], P, M[0], M[1]);
+                    mono_pair<c4>(base[m - 1], w8, am[m - 1], P, M[0], M[1]);
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
-                        const double vx = mmul(M[k], kx[m][2 * c4 + k], P), vy = mmul(M[k], ky[m][2 * c4 + k], P);
-                        bx[k] = m == 0 ? vx : bx[k] + vx;
-                        by[k] = m == 0 ? vy : by[k] + vy;
+                        bx[k] += mmul(M[k], kx[m][2 * c4 + k], P);
+                        by[k] += mmul(M[k], ky[m][2 * c4 + k], P);
                     }
                 }
 #pragma unroll
                 for (int k = 0; k < 2; ++k)
-                    o[2 * c4 + k] = mmul(bx[k] + gconst, x[2 * c4 + k], P) + mmul(by[k], y[2 * c4 + k], P);
+                    o[2 * c4 + k] = mmul(bx[k], x[2 * c4 + k], P) + mmul(by[k], y[2 * c4 + k], P);
             };
             chunk(std::integral_constant<int, 0>{});
             chunk(std::integral_constant<int, 1>{});
@@ -781,16 +785,15 @@ void launch_external_product_q(const Tables& T, const double* bsk, const u32* id
 }
 void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
                            const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
-                           const BlockMap& omap, double inv_g, int wide_below, int grouping, double gconst,
-                           hipStream_t st) {
+                           const BlockMap& omap, double inv_g, int wide_below, int grouping, hipStream_t st) {
     if (grouping == 2 && count <= (size_t)wide_below) {
         hipLaunchKernelGGL(k_blind_rotate_q2_wide, dim3((unsigned)count), dim3(2 * NT), LDS_BYTES, st, T, bsk,
-                           lwe_small, n, luts, lut_index, glwe_out, lwe_out, omap, inv_g, gconst);
+                           lwe_small, n, luts, lut_index, glwe_out, lwe_out, omap, inv_g);
         return;
     }
     if (grouping == 2) {
         hipLaunchKernelGGL(k_blind_rotate_q2, dim3((unsigned)count), dim3(NT), LDS_BYTES, st, T, bsk, lwe_small, n,
-                           luts, lut_index, glwe_out, lwe_out, omap, inv_g, gconst);
+                           luts, lut_index, glwe_out, lwe_out, omap, inv_g);
         return;
     }
     // up to two ciphertexts per CU: latency matters more than throughput, use 512 threads each

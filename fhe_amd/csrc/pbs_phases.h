@@ -172,14 +172,13 @@ LFHE_HD void ep_phase(EpState& s, double* lds, unsigned t, const Tables& T, cons
 
 // ------------------------------------------------------------------------------------------------
 // Blind rotation with two mask elements per step (single ring modulus).  The key holds, per pair of
-// key bits (s, s'), GGSWs G0, G1, G2 of s(1-s'), (1-s)s', s s' as three consecutive rows of the
-// single-modulus layout; the step is  acc <- B [.] acc  with
-//     B = I + (X^a - 1) G0 + (X^a' - 1) G1 + (X^(a+a') - 1) G2 .
+// key bits (s, s'), GGSWs G0..G3 of (1-s)(1-s'), s(1-s'), (1-s)s', s s' as four consecutive rows of
+// the single-modulus layout; the step is  acc <- B [.] acc  with
+//     B = G0 + X^a G1 + X^a' G2 + X^(a+a') G3 .
 // In the transform domain X^e is the point-wise factor psi^(e (2 bitrev(pos) + 1)) at position pos,
-// so B is formed point by point from the three key rows and a table of psi^k - 1, and the step
-// costs ONE external product: the transforms of phases 0-4 and 6-11 above, with this function in
-// place of phase 5's point-wise stage.  `gconst` is the diagonal of I, the gadget times N^-1 (the
-// key rows carry N^-1 too).
+// so B is formed point by point from the four key rows and powers of psi, and the step costs ONE
+// external product: the transforms of phases 0-4 and 6-11 above, with ep_group2_phase5 in place of
+// phase 5's point-wise stage.
 // ------------------------------------------------------------------------------------------------
 constexpr int MONO_WORDS = 2 * N;
 
@@ -193,7 +192,7 @@ LFHE_HD unsigned rev8(unsigned t) {
 #endif
 }
 
-// The factors psi^(e u) - 1 of X^e at the two positions 8 t + 2 c4 + {0, 1}, whose exponents are
+// The factors psi^(e u) of X^e at the two positions 8 t + 2 c4 + {0, 1}, whose exponents are
 // u = u_t + 512 r and u_t + 512 (r + 4) with r = bitrev3(2 c4) in {0, 2, 1, 3}, u_t odd:
 // psi^(e u_t) comes from the table of all 2N powers once per thread (`base`); psi^(512 e r) =
 // w8^(e r mod 8) is one of the eight 8th roots of unity, the same for every thread of the
@@ -202,13 +201,12 @@ LFHE_HD unsigned rev8(unsigned t) {
 template <int C4>
 LFHE_HD void mono_pair(double base, const double* __restrict__ w8, unsigned e, const Prime& P, double& m0, double& m1) {
     constexpr unsigned R[4] = {0, 2, 1, 3};
-    const double pw = C4 == 0 ? base : mmul(base, w8[(e * R[C4]) & 7u], P);
-    m0 = pw - 1.0;
-    m1 = __builtin_fma(pw, (e & 1u) ? -1.0 : 1.0, -1.0);
+    m0 = C4 == 0 ? base : mmul(base, w8[(e * R[C4]) & 7u], P);
+    m1 = (e & 1u) ? -m0 : m0;
 }
 
 LFHE_HD void ep_group2_phase5(EpState& s, double* lds, unsigned t, const Tables& T,
-                              const double* __restrict__ rows, unsigned a1, unsigned a2, double gconst) {
+                              const double* __restrict__ rows, unsigned a1, unsigned a2) {
     const Prime P = T.pr[0];
 #if defined(__HIP_DEVICE_COMPILE__)
     unsigned zero = 0;
@@ -234,7 +232,7 @@ LFHE_HD void ep_group2_phase5(EpState& s, double* lds, unsigned t, const Tables&
     load_tw4x2(twi, t, s.tw);   // for the inverse pass below
     // position 8 t + j evaluates at psi^(2 bitrev11(8 t + j) + 1) = psi^(512 bitrev3(j) + 2 rev8(t) + 1)
     const double* __restrict__ w8 = mono + MONO_WORDS;
-    // key words of unit u = 3 c4 + m: row m, the four polynomials q, positions 8 t + 2 c4 + {0, 1};
+    // key words of unit u = 4 c4 + m: row m, the four polynomials q, positions 8 t + 2 c4 + {0, 1};
     // the next unit's four 16-byte loads are in flight while this one is multiplied
     double kc[4][2], kn[4][2];
 #pragma unroll
@@ -243,25 +241,29 @@ LFHE_HD void ep_group2_phase5(EpState& s, double* lds, unsigned t, const Tables&
         constexpr int c4 = decltype(c4_tag)::value;
         double B[4][2];
 #pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            const int u = 3 * c4 + m;
-            if (u < 11) {
-                const unsigned c4n = (unsigned)(u + 1) / 3, mn = (unsigned)(u + 1) % 3;
+        for (int m = 0; m < 4; ++m) {
+            const int u = 4 * c4 + m;
+            if (u < 15) {
+                const unsigned c4n = (unsigned)(u + 1) / 4, mn = (unsigned)(u + 1) % 4;
 #pragma unroll
                 for (unsigned q = 0; q < 4; ++q) {
                     const unsigned o = mn * (unsigned)BSKQ_ROW + bsk_off(0, q, c4n, t);
                     kn[q][0] = LFHE_LDK(rows, o); kn[q][1] = LFHE_LDK(rows, o + 1);
                 }
             }
-            double M[2];
-            mono_pair<c4>(base[m], w8, am[m], P, M[0], M[1]);
+            if (m == 0) {   // X^0: the row enters as it is
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const double v = mmul(M[h], kc[q][h], P);
-                    B[q][h] = m == 0 ? v : B[q][h] + v;
-                }
+                    for (int q = 0; q < 4; ++q) B[q][h] = kc[q][h];
+            } else {
+                double M[2];
+                mono_pair<c4>(base[m - 1], w8, am[m - 1], P, M[0], M[1]);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) B[q][h] += mmul(M[h], kc[q][h], P);
+            }
 #if defined(__HIP_DEVICE_COMPILE__)
             asm volatile("" ::: "memory");
 #endif
@@ -274,8 +276,8 @@ LFHE_HD void ep_group2_phase5(EpState& s, double* lds, unsigned t, const Tables&
             // the transformed digits are brought to |d| <= p/2 (two reductions per point instead of
             // four for B); B enters as the wide operand, |B| < 2.2 p
             const double d0 = mnorm(s.x[0][j], P), d1 = mnorm(s.x[1][j], P);
-            s.x[0][j] = mmul(B[0][h] + gconst, d0, P) + mmul(B[2][h], d1, P);
-            s.x[1][j] = mmul(B[1][h], d0, P) + mmul(B[3][h] + gconst, d1, P);
+            s.x[0][j] = mmul(B[0][h], d0, P) + mmul(B[2][h], d1, P);
+            s.x[1][j] = mmul(B[1][h], d0, P) + mmul(B[3][h], d1, P);
         }
     };
     chunk(std::integral_constant<int, 0>{});

@@ -39,11 +39,12 @@ extern "C" {
 #define LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK 2u
 #define LFHE_BSK_MODULUS_PRIME 703687441727489ull
 /* the prime-modulus set with the LWE key bits taken two at a time in the blind rotation: the
- * bootstrapping key holds three GGSWs per pair of bits (of s(1-s'), (1-s)s', s s'), a step multiplies
- * the accumulator by I + (X^a - 1) G0 + (X^a' - 1) G1 + (X^(a+a') - 1) G2 -- one external product
- * for two mask elements (the multi-bit blind rotation of tfhe-rs with grouping factor 2, the
- * all-zero pattern being the noiseless identity).  Ciphertexts, secret keys, key switch, encodings
- * and every interface are those of the named set; only the server's bootstrapping key differs. */
+ * bootstrapping key holds four GGSWs per pair of bits (of (1-s)(1-s'), s(1-s'), (1-s)s', s s'), a
+ * step multiplies the accumulator by G0 + X^a G1 + X^a' G2 + X^(a+a') G3 -- one external product
+ * for two mask elements (the multi-bit blind rotation of tfhe-rs with grouping factor 2).
+ * Ciphertexts, secret keys, key switch, encodings and every interface are those of the named set;
+ * only the server's bootstrapping key differs (twice the words, 1.4 times the blind-rotation
+ * noise variance). */
 #define LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK_GROUPED 3u
 
 typedef struct lfhe_ctx lfhe_ctx;
@@ -74,7 +75,7 @@ typedef struct {
      * tfhe-rs programmable_bootstrap_ntt64_lwe_ciphertext) */
     uint64_t bsk_modulus;
     /* LWE key bits per blind-rotation step: 1, or 2 (with LFHE_BSK_MODULUS_PRIME only; the
-     * bootstrapping key then has 3 * ceil(lwe_dim / 2) GGSWs) */
+     * bootstrapping key then has 4 * ceil(lwe_dim / 2) GGSWs) */
     uint32_t bsk_grouping;
     uint32_t reserved;        /* 0 */
 } lfhe_params;

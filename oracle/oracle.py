@@ -378,7 +378,7 @@ class Oracle:
         return bsk
 
     def gen_bsk_qp_grouped(self, lwe_sk: np.ndarray, glwe_sk: np.ndarray, seed: bytes) -> np.ndarray:
-        """Grouped key over q': three GGSWs per pair of key bits (tfhe_oracle.h)."""
+        """Grouped key over q': four GGSWs per pair of key bits (tfhe_oracle.h)."""
         count = lib().orc_bsk_qp_grouped_count(C.byref(self._cp))
         bsk = np.zeros(count * self.ggsw_words(), dtype=np.uint64)
         lib().orc_gen_bsk_qp_grouped(self._ctx, lwe_sk, glwe_sk, Rng(seed, 7).ref, bsk)

@@ -845,8 +845,8 @@ void orc_gen_bsk_qp(const orc_ctx* c, const uint64_t* lwe_sk, const uint64_t* gl
 }
 
 /* Grouped key: the LWE key bits are taken in pairs (s, s') = (s_2g, s_2g+1) (s' = 0 past the end of
- * an odd-length key); group g holds three GGSWs, of s(1-s'), (1-s)s' and s s'. */
-size_t orc_bsk_qp_grouped_count(const orc_params* p) { return 3 * (((size_t)p->lwe_dim + 1) / 2); }
+ * an odd-length key); group g holds four GGSWs, of (1-s)(1-s'), s(1-s'), (1-s)s' and s s'. */
+size_t orc_bsk_qp_grouped_count(const orc_params* p) { return 4 * (((size_t)p->lwe_dim + 1) / 2); }
 
 void orc_gen_bsk_qp_grouped(const orc_ctx* c, const uint64_t* lwe_sk, const uint64_t* glwe_sk, orc_rng* r,
                             uint64_t* bsk) {
@@ -856,8 +856,8 @@ void orc_gen_bsk_qp_grouped(const orc_ctx* c, const uint64_t* lwe_sk, const uint
     u64* tmp = (u64*)malloc(sizeof(u64) * P->poly_size);
     for (u32 g = 0; g < groups; ++g) {
         const u64 s0 = lwe_sk[2 * g], s1 = 2 * g + 1 < P->lwe_dim ? lwe_sk[2 * g + 1] : 0;
-        const u64 msg[3] = {s0 & (1 - s1), (1 - s0) & s1, s0 & s1};
-        for (u32 m = 0; m < 3; ++m) gen_ggsw_qp(c, msg[m], glwe_sk, r, bsk + ((size_t)3 * g + m) * per, tmp);
+        const u64 msg[4] = {(1 - s0) & (1 - s1), s0 & (1 - s1), (1 - s0) & s1, s0 & s1};
+        for (u32 m = 0; m < 4; ++m) gen_ggsw_qp(c, msg[m], glwe_sk, r, bsk + ((size_t)4 * g + m) * per, tmp);
     }
     free(tmp);
 }
@@ -933,26 +933,24 @@ static void qp_monomial_mul(u64* out, const u64* in, u32 rot, u32 N) {
 }
 
 /* Two mask elements per step:  acc <- B [.] acc  with the GGSW
- *     B = I + (X^a - 1) GGSW(s(1-s')) + (X^a' - 1) GGSW((1-s)s') + (X^(a+a') - 1) GGSW(s s'),
- * an encryption of X^(a s + a' s'); I is the noiseless GGSW of 1 (gadget on the diagonal).  B is
- * formed in the transform domain, where a monomial is a point-wise factor, so a step costs one
- * external product.  The accumulator is replaced, not added to: what the gadget decomposition
- * rounds away (|.| <= G/2 per coefficient and step) stays in the error instead of being carried. */
-/* one step: acc <- B [.] acc for the three NTT-domain GGSWs at hat3 and the exponents a0, a1 */
-static void group_step_hat(const orc_ctx* c, const u64* hat3, size_t per, u32 a0, u32 a1, u64* acc) {
+ *     B = GGSW((1-s)(1-s')) + X^a GGSW(s(1-s')) + X^a' GGSW((1-s)s') + X^(a+a') GGSW(s s'),
+ * an encryption of X^(a s + a' s') (exactly one of the four bits is 1).  B is formed in the
+ * transform domain, where a monomial is a point-wise factor, so a step costs one external product.
+ * The accumulator is replaced, not added to: what the gadget decomposition rounds away
+ * (|.| <= G/2 per coefficient and step) stays in the error instead of being carried. */
+/* one step: acc <- B [.] acc for the four NTT-domain GGSWs at hat4 and the exponents a0, a1 */
+static void group_step_hat(const orc_ctx* c, const u64* hat4, size_t per, u32 a0, u32 a1, u64* acc) {
     const orc_params* P = &c->prm;
     const u32 N = P->poly_size, k1 = P->glwe_dim + 1;
     const mont_t* M = &c->qp.m;
-    const u64 G = orc_qp_gadget(c) % ORC_QP;
-    const u32 a[3] = {a0, a1, (a0 + a1) % (2 * N)};
-    u64* tmp = (u64*)malloc(sizeof(u64) * ((size_t)k1 * N * 2 + 3 * (size_t)N));
+    const u32 a[4] = {0, a0, a1, (a0 + a1) % (2 * N)};
+    u64* tmp = (u64*)malloc(sizeof(u64) * ((size_t)k1 * N * 2 + 4 * (size_t)N));
     u64 *dig = tmp, *out = tmp + (size_t)k1 * N, *mono = tmp + (size_t)2 * k1 * N;
-    /* transform of X^a - 1, Montgomery form */
-    for (u32 m = 0; m < 3; ++m) {
+    /* transform of X^a, Montgomery form */
+    for (u32 m = 0; m < 4; ++m) {
         u64* mm = mono + (size_t)m * N;
         memset(mm, 0, sizeof(u64) * N);
         if (a[m] < N) mm[a[m]] = 1; else mm[a[m] - N] = ORC_QP - 1;
-        mm[0] = qp_sub(mm[0], 1);
         ntt_fwd(&c->qp, mm, N);
         for (u32 j = 0; j < N; ++j) mm[j] = to_mont(M, mm[j]);
     }
@@ -969,10 +967,10 @@ static void group_step_hat(const orc_ctx* c, const u64* hat3, size_t per, u32 a0
         for (u32 j = 0; j < N; ++j) {
             u64 sum = 0;
             for (u32 rr = 0; rr < k1; ++rr) {
-                u64 b = rr == cc ? G : 0;
-                for (u32 m = 0; m < 3; ++m) {
+                u64 b = 0;
+                for (u32 m = 0; m < 4; ++m) {
                     /* both factors are Montgomery forms: two reductions give the plain product */
-                    const u64 h = hat3[(size_t)m * per + ((size_t)rr * k1 + cc) * N + j];
+                    const u64 h = hat4[(size_t)m * per + ((size_t)rr * k1 + cc) * N + j];
                     b = qp_add(b, mont_mul(M, mont_mul(M, mono[(size_t)m * N + j], h), 1));
                 }
                 sum = qp_add(sum, mont_mul(M, dig[(size_t)rr * N + j], to_mont(M, b)));
@@ -985,11 +983,11 @@ static void group_step_hat(const orc_ctx* c, const u64* hat3, size_t per, u32 a0
     free(tmp);
 }
 
-void orc_group_step_qp(const orc_ctx* c, const uint64_t* ggsw3, uint32_t a0, uint32_t a1, uint64_t* acc) {
+void orc_group_step_qp(const orc_ctx* c, const uint64_t* ggsw4, uint32_t a0, uint32_t a1, uint64_t* acc) {
     const u32 N = c->prm.poly_size, k1 = c->prm.glwe_dim + 1;
     const size_t per = (size_t)k1 * k1 * N;
-    u64* hat = (u64*)malloc(sizeof(u64) * 3 * per);
-    for (u32 m = 0; m < 3; ++m) ggsw_qp_to_hat(c, ggsw3 + (size_t)m * per, hat + (size_t)m * per);
+    u64* hat = (u64*)malloc(sizeof(u64) * 4 * per);
+    for (u32 m = 0; m < 4; ++m) ggsw_qp_to_hat(c, ggsw4 + (size_t)m * per, hat + (size_t)m * per);
     group_step_hat(c, hat, per, a0, a1, acc);
     free(hat);
 }
@@ -1008,8 +1006,8 @@ static void blind_rotate_qp_grouped(const orc_ctx* c, const orc_prepared_bsk* pb
     for (u32 g = 0; g < groups; ++g) {
         const u32 a0 = orc_modswitch(lwe_small[2 * g], log2n);
         const u32 a1 = 2 * g + 1 < n ? orc_modswitch(lwe_small[2 * g + 1], log2n) : 0;
-        if (a0 == 0 && a1 == 0) continue;   /* B = I: skipped, the accumulator is left as it is */
-        group_step_hat(c, pb->hat + (size_t)3 * g * pb->per_ggsw, pb->per_ggsw, a0, a1, acc);
+        if (a0 == 0 && a1 == 0) continue;   /* B encrypts 1: skipped, the accumulator is left as it is */
+        group_step_hat(c, pb->hat + (size_t)4 * g * pb->per_ggsw, pb->per_ggsw, a0, a1, acc);
     }
 }
 

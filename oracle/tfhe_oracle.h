@@ -197,19 +197,18 @@ void orc_gen_bsk_qp(const orc_ctx* c, const uint64_t* lwe_sk, const uint64_t* gl
 void orc_external_product_qp(const orc_ctx* c, const uint64_t* ggsw, const uint64_t* glwe, uint64_t* out);
 orc_prepared_bsk* orc_bsk_qp_prepare(const orc_ctx* c, const uint64_t* bsk);
 /* Grouped key over q': the key bits in pairs (s, s') = (s_2g, s_2g+1), s' = 0 past the end of an
- * odd-length key; bsk[g][m][row][poly][N] with GGSW m = 0, 1, 2 of s(1-s'), (1-s)s', s s'.  A blind
- * rotation with a prepared grouped key takes one external product per PAIR of mask elements:
- * acc <- (I + (X^a - 1) G0 + (X^a' - 1) G1 + (X^(a+a') - 1) G2) [.] acc, the sum formed in the
- * transform domain (tfhe-rs calls this family multi-bit blind rotation; here the all-zero pattern
- * is the noiseless identity instead of a fourth GGSW).  orc_blind_rotate_qp / orc_pbs_qp /
- * orc_pbs_batch_qp take either kind of prepared key. */
+ * odd-length key; bsk[g][m][row][poly][N] with GGSW m = 0..3 of (1-s)(1-s'), s(1-s'), (1-s)s', s s'.
+ * A blind rotation with a prepared grouped key takes one external product per PAIR of mask
+ * elements: acc <- (G0 + X^a G1 + X^a' G2 + X^(a+a') G3) [.] acc, the sum formed in the transform
+ * domain (the multi-bit blind rotation of tfhe-rs, grouping factor 2; a pair with a = a' = 0 is
+ * skipped).  orc_blind_rotate_qp / orc_pbs_qp / orc_pbs_batch_qp take either kind of prepared key. */
 size_t orc_bsk_qp_grouped_count(const orc_params* p);   /* GGSWs in the grouped key */
 void orc_gen_bsk_qp_grouped(const orc_ctx* c, const uint64_t* lwe_sk, const uint64_t* glwe_sk, orc_rng* r,
                             uint64_t* bsk);
 orc_prepared_bsk* orc_bsk_qp_grouped_prepare(const orc_ctx* c, const uint64_t* bsk);
-/* one step on its own: ggsw3 = three GGSWs over q' in the coefficient domain, acc (k+1 polys of
+/* one step on its own: ggsw4 = four GGSWs over q' in the coefficient domain, acc (k+1 polys of
  * residues) is replaced by B [.] acc for the exponents a0, a1 in [0, 2N) */
-void orc_group_step_qp(const orc_ctx* c, const uint64_t* ggsw3, uint32_t a0, uint32_t a1, uint64_t* acc);
+void orc_group_step_qp(const orc_ctx* c, const uint64_t* ggsw4, uint32_t a0, uint32_t a1, uint64_t* acc);
 /* lut: the 2^64-scale accumulator ((k+1) polys); acc_out: (k+1) polys of residues in [0, q') */
 void orc_blind_rotate_qp(const orc_ctx* c, const orc_prepared_bsk* pb, const uint64_t* lwe_small,
                          const uint64_t* lut, uint64_t* acc_out);

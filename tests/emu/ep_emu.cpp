@@ -83,14 +83,14 @@ static void run_phases_q(std::vector<EpState>& st, double* lds, const Tables& T)
     }
 }
 
-static void make_bskq_rows(const HostTables& H, const u64* ggsw3, std::vector<double>& rows) {
-    rows.assign(3 * BSKQ_ROW, 0.0);
+static void make_bskq_rows(const HostTables& H, const u64* ggsw4, std::vector<double>& rows) {
+    rows.assign(4 * BSKQ_ROW, 0.0);
     const u64 p = H.p[0];
     const u64 ninv = h_powmod(N, p - 2, p);
     std::vector<u64> out(N);
-    for (int m = 0; m < 3; ++m)
+    for (int m = 0; m < 4; ++m)
         for (int q = 0; q < 4; ++q) {
-            orc_ntt_definition(p, H.psi[0], ggsw3 + ((size_t)m * 4 + q) * N, out.data(), N);
+            orc_ntt_definition(p, H.psi[0], ggsw4 + ((size_t)m * 4 + q) * N, out.data(), N);
             for (int e = 0; e < N; ++e) {
                 const u64 v = h_mulmod(out[h_bitrev((u32)e, LOGN)], ninv, p);
                 rows[(size_t)m * BSKQ_ROW + bsk_off(0, q, (e & 7) >> 1, e >> 3) + (e & 1)] = h_centred(v, p);
@@ -99,13 +99,12 @@ static void make_bskq_rows(const HostTables& H, const u64* ggsw3, std::vector<do
 }
 
 static int run_group_case(const orc_ctx* oc, const HostTables& H, const Tables& T,
-                          const u64* ggsw3, const u64* acc_in, unsigned a0, unsigned a1, const char* name) {
+                          const u64* ggsw4, const u64* acc_in, unsigned a0, unsigned a1, const char* name) {
     std::vector<double> rows;
-    make_bskq_rows(H, ggsw3, rows);
+    make_bskq_rows(H, ggsw4, rows);
     const u64 p = H.p[0];
     const u64 G = orc_qp_gadget(oc);
     const double inv_g = 1.0 / (double)G;
-    const double gconst = h_centred(h_mulmod(G % p, h_powmod(N, p - 2, p), p), p);
     std::vector<EpState> st(NT);
     std::vector<double> lds(LDS_WORDS, 0.0);
     for (int t = 0; t < NT; ++t)
@@ -113,10 +112,10 @@ static int run_group_case(const orc_ctx* oc, const HostTables& H, const Tables& 
             for (int j = 0; j < E; ++j)
                 st[t].x[q][j] = __builtin_rint(h_centred(acc_in[q * N + own1(t, j)], p) * inv_g);
     run_phases_q<0, 5>(st, lds.data(), T);
-    for (int t = 0; t < NT; ++t) ep_group2_phase5(st[t], lds.data(), t, T, rows.data(), a0, a1, gconst);
+    for (int t = 0; t < NT; ++t) ep_group2_phase5(st[t], lds.data(), t, T, rows.data(), a0, a1);
     run_phases_q<6, 12>(st, lds.data(), T);
     std::vector<u64> want(acc_in, acc_in + 2 * N);
-    orc_group_step_qp(oc, ggsw3, a0, a1, want.data());
+    orc_group_step_qp(oc, ggsw4, a0, a1, want.data());
     int bad = 0;
     for (int t = 0; t < NT; ++t)
         for (int q = 0; q < 2; ++q)
@@ -187,7 +186,7 @@ int main() {
             if (k % (N / 4) == 0) table[MONO_WORDS + k / (N / 4)] = table[k];
         }
         T.mono = table.data();
-        std::vector<u64> g3(3 * 4 * N), acc(2 * N);
+        std::vector<u64> g3(4 * 4 * N), acc(2 * N);
         for (auto& v : g3) v = rnd() % p;
         for (auto& v : acc) v = rnd() % p;
         bad += run_group_case(oc, H, T, g3.data(), acc.data(), 1234, 3071, "grouped random");

@@ -194,7 +194,7 @@ def test_ms_noise_reduction_bit_exact(full):
 # ---- bootstrap over the prime ring modulus (bootstrapping key and accumulator in Z_q') ------------
 def _mk_prime(n, seed, ms_zeros=0, wide=True, grouped=False):
     """wide=False forces the 256-thread blind rotation for small launches too (by default launches
-    of up to two ciphertexts per CU take the 512-thread kernel).  grouped: the key with three GGSWs
+    of up to two ciphertexts per CU take the 512-thread kernel).  grouped: the key with four GGSWs
     per pair of key bits, blind rotation in (n + 1) / 2 steps."""
     import os
     from fhe_amd.native import Context, Params, default_params, BSK_MODULUS_PRIME

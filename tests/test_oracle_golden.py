@@ -231,13 +231,13 @@ def test_ntt_definition_is_the_transform_the_product_uses():
 
 @pytest.mark.parametrize("n", [12, 13])
 def test_grouped_key_blind_rotation_over_prime_modulus(n):
-    """Two key bits per step (three GGSWs per pair, identity pattern noiseless): the bootstrap
+    """Two key bits per step (four GGSWs per pair, one per bit pattern): the bootstrap
     evaluates the table, and the accumulator is the rotated table up to noise -- for an even and an
     odd key length (the odd one pads the last pair with a zero bit)."""
     orc = Oracle(Params(lwe_dim=n))
     lwe_sk, glwe_sk, _, ksk = orc.gen_keys(seed_bytes(21))
     bskg = orc.gen_bsk_qp_grouped(lwe_sk, glwe_sk, seed_bytes(21))
-    assert bskg.size == 3 * ((n + 1) // 2) * orc.ggsw_words()
+    assert bskg.size == 4 * ((n + 1) // 2) * orc.ggsw_words()
     assert int(bskg.max()) < orc.qp
     pb = orc.prepare_bsk_qp_grouped(bskg)
     pb1 = orc.prepare_bsk_qp(orc.gen_bsk_qp(lwe_sk, glwe_sk, seed_bytes(21)))
