@@ -29,9 +29,9 @@ WIDTHS = (1, 8, 16, 32, 64, 128, 160, 256)
 class GpuBackend:
     """liblfhe behind the HTTP surface: one context, requests serialised on it."""
 
-    def __init__(self, seed: bytes = bytes(32), device: int = 0):
+    def __init__(self, seed: bytes = bytes(32), device: int = 0, params_id: int = 1):
         from .native import Context
-        self.ctx = Context(seed=seed, device=device)
+        self.ctx = Context(seed=seed, device=device, params_id=params_id)
         self.ctx.keygen()
         self._pk = None
 
@@ -196,10 +196,14 @@ def main(argv=None):
     ap.add_argument("-threshold", "--threshold", action="store_true")
     ap.add_argument("-parties", "--parties", type=int, default=1)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--bootstrapping-key", choices=["q64", "prime", "grouped"], default="grouped",
+                    help="server-side bootstrapping key (include/lfhe.h parameter set ids 1, 2, 3): over 2^64, over the "
+                         "NTT prime, or over the prime with the key bits in pairs (fastest); clients see no difference")
     args = ap.parse_args(argv)
     if args.threshold:
         raise SystemExit("threshold decryption is outside this backend's scope: run without -threshold")
-    srv = serve(GpuBackend(device=args.device), args.addr, False, args.parties)
+    params_id = {"q64": 1, "prime": 2, "grouped": 3}[args.bootstrapping_key]
+    srv = serve(GpuBackend(device=args.device, params_id=params_id), args.addr, False, args.parties)
     print(f"fhe-server (gfx950) listening on {args.addr}")
     srv.serve_forever()
 
