@@ -41,6 +41,7 @@ Engine::Engine(int device, const EngineParams& p) : device_(device), prm_(p) {
     cu_count_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     wide_below_ = 2 * cu_count_;
     if (const char* e = std::getenv("LFHE_WIDE_BELOW")) wide_below_ = std::atoi(e);   // tuning / A-B runs
+    if (const char* e = std::getenv("LFHE_BR_CHUNK")) br_chunk_ = std::atoi(e);       // 0: automatic
 
     HostTables H;
     build_host_tables(H);
@@ -226,18 +227,57 @@ void Engine::lin_layer(u64* arena, size_t instances, size_t inst_stride_blocks, 
     HC(hipGetLastError());
 }
 
+// Ciphertexts per blind-rotation launch.  The workgroups of a launch walk the bootstrapping key in
+// near lock step, which is what keeps the key row of the current step in L2; over a long launch they
+// drift apart, the resident workgroups end up spread over the whole key and the key reads fall
+// through to HBM (measured: 86.7 ciphertexts/ms in launches of 4096, 70.7 in one launch of 65536).
+// Long batches are therefore cut into launches of about four rounds of resident workgroups, a
+// whole number of program instances each (so that block maps and table indices shift by pointer
+// arithmetic alone), picked to fill its last round as well as possible.
+static size_t launch_chunk(size_t count, size_t ops, size_t slots) {
+    const size_t target = 4 * slots;
+    if (count <= target + target / 2) return count;
+    if (ops == 0) return target;
+    if (ops >= target) return ops;
+    size_t best = 0;
+    double best_fill = -1;
+    for (size_t m = (target / 2 + ops - 1) / ops; m * ops <= 2 * target; ++m) {
+        const size_t c = m * ops, rounds = (c + slots - 1) / slots;
+        const double fill = (double)c / (double)(rounds * slots);
+        if (fill > best_fill + 1e-9) { best_fill = fill; best = c; }
+    }
+    return best ? best : ops;
+}
+
 void Engine::blind_rotate(const u64* lwe_small, const u64* luts, const u32* lut_index, u64* glwe_out, u64* lwe_out,
                           size_t count, const BlockMap& omap) {
     if (!d_bsk_) throw std::runtime_error("no bootstrapping key loaded");
     if (!count) return;
     HC(hipSetDevice(device_));
-    if (single_modulus())
-        launch_blind_rotate_q(T_, d_bsk_, lwe_small, (int)prm_.lwe_dim, luts, lut_index, glwe_out, lwe_out, count, omap,
-                              1.0 / (double)qp_gadget(), wide_below_, (int)prm_.bsk_grouping, stream_);
-    else
-        launch_blind_rotate(T_, d_bsk_, lwe_small, (int)prm_.lwe_dim, luts, lut_index, glwe_out, lwe_out, count, omap,
-                            stream_);
-    HC(hipGetLastError());
+    const size_t n1 = (size_t)prm_.lwe_dim + 1;
+    const size_t slots = (size_t)(single_modulus() ? 4 : 2) * (size_t)cu_count_;   // resident workgroups
+    if (omap.idx && !omap.ops) throw std::logic_error("block map without a period");
+    const size_t chunk = br_chunk_ > 0 ? (omap.ops ? ((size_t)br_chunk_ + omap.ops - 1) / omap.ops * omap.ops : (size_t)br_chunk_)
+                                       : launch_chunk(count, omap.ops, slots);
+    for (size_t c0 = 0; c0 < count; c0 += chunk) {
+        const size_t cnt = count - c0 < chunk ? count - c0 : chunk;
+        // the launch sees ciphertext c0 as its ciphertext 0: shift every per-ciphertext pointer
+        const u64* in = lwe_small + c0 * n1;
+        u64* gout = glwe_out ? glwe_out + c0 * 2 * N : nullptr;
+        u64* lout = lwe_out;
+        const u32* li = lut_index;
+        if (omap.idx) { if (lout) lout += (c0 / omap.ops) * omap.inst_stride * (size_t)(N + 1); }
+        else {
+            if (lout) lout += c0 * (size_t)(N + 1);
+            if (li && !omap.ops) li += c0;   // with a period the launch starts on a multiple of it
+        }
+        if (single_modulus())
+            launch_blind_rotate_q(T_, d_bsk_, in, (int)prm_.lwe_dim, luts, li, gout, lout, cnt, omap,
+                                  1.0 / (double)qp_gadget(), wide_below_, (int)prm_.bsk_grouping, stream_);
+        else
+            launch_blind_rotate(T_, d_bsk_, in, (int)prm_.lwe_dim, luts, li, gout, lout, cnt, omap, stream_);
+        HC(hipGetLastError());
+    }
 }
 
 void Engine::pbs_batch(const u64* lwe_in, const u64* luts, const u32* lut_index, u64* lwe_out, size_t count) {

@@ -153,6 +153,7 @@ private:
     size_t ksdig_cap_ = 0;
     MsParams ms_{};
     int cu_count_ = 256;
+    int br_chunk_ = 0;      // ciphertexts per blind-rotation launch; 0: about four rounds of resident workgroups
     int wide_below_ = -1;   // launches of at most this many ciphertexts use 512 threads each
     void set_ms_params(u32 zcount);
     u64* ms_zeros_dev() const { return d_ksk_ + ksk_words() + prm_.lwe_dim + 1 + 1; }
