@@ -183,6 +183,44 @@ def test_batches_larger_than_the_arena_budget_run_in_chunks(ctx):
         del os.environ["LFHE_ARENA_BYTES"]
 
 
+@pytest.mark.parametrize("params_id", [2, 3], ids=["bsk_prime", "bsk_prime_grouped"])
+def test_long_batches_cut_into_several_launches_give_the_same_bits(params_id):
+    """Blind-rotation batches are cut into launches of a few rounds of workgroups (whole program
+    instances each); forcing tiny launches must not change a single bit, for arena block maps and
+    for contiguous batches with a table index per ciphertext."""
+    import os
+    import random
+    import numpy as np
+    from fhe_amd.native import Context
+    seed = bytes(range(32))
+    ref = Context(seed=seed, params_id=params_id)
+    os.environ["LFHE_BR_CHUNK"] = "600"      # above the 512-thread kernel's limit, below every batch here
+    try:
+        cut = Context(seed=seed, params_id=params_id)
+    finally:
+        del os.environ["LFHE_BR_CHUNK"]
+    try:
+        ref.keygen()
+        cut.keygen()                          # same seed, same keys
+        rnd = random.Random(12)
+        n = 40
+        xs = [rnd.randrange(1 << 32) for _ in range(n)]
+        ys = [rnd.randrange(1 << 32) for _ in range(n)]
+        A, B = [ref.encrypt(x, 32) for x in xs], [ref.encrypt(y, 32) for y in ys]
+        for op in ("add", "gt"):
+            want = ref.evaluate_batch(op, 32, A, B)
+            got = cut.evaluate_batch(op, 32, A, B)
+            assert got == want, op
+        assert [ref.decrypt(o) for o in cut.evaluate_batch("add", 32, A, B)] == [(x + y) & 0xFFFFFFFF for x, y in zip(xs, ys)]
+        blocks = np.concatenate([np.frombuffer(a[16:], dtype=np.uint64).reshape(16, 2049) for a in A + B])   # 1280
+        luts = np.stack([ref.make_lut(lambda x, j=j: (x + j) % 16) for j in range(3)])
+        idx = np.array([i % 3 for i in range(len(blocks))], dtype=np.uint32)
+        assert np.array_equal(cut.pbs_batch(blocks, luts, idx), ref.pbs_batch(blocks, luts, idx))
+    finally:
+        ref.close()
+        cut.close()
+
+
 def test_error_paths(ctx):
     from fhe_amd.native import LfheError
     a8, a16 = ctx.encrypt(1, 8), ctx.encrypt(1, 16)
