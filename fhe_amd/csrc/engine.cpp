@@ -42,6 +42,8 @@ Engine::Engine(int device, const EngineParams& p) : device_(device), prm_(p) {
     wide_below_ = 2 * cu_count_;
     if (const char* e = std::getenv("LFHE_WIDE_BELOW")) wide_below_ = std::atoi(e);   // tuning / A-B runs
     if (const char* e = std::getenv("LFHE_BR_CHUNK")) br_chunk_ = std::atoi(e);       // 0: automatic
+    if (const char* e = std::getenv("LFHE_KS_MFMA_MIN")) ksm_min_ = std::atoi(e);     // 0: VALU key switch only
+    if (!ksm_supported(N, (int)p.ks_level, (int)p.lwe_dim)) ksm_min_ = 0;
 
     HostTables H;
     build_host_tables(H);
@@ -78,6 +80,9 @@ Engine::~Engine() {
     (void)hipFree(d_tw_);
     (void)hipFree(d_small_);
     (void)hipFree(d_ksdig_);
+    (void)hipFree(d_ksk_limbs_);
+    (void)hipFree(d_ksm_dig_);
+    (void)hipFree(d_ksm_prod_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -134,8 +139,16 @@ void Engine::load_ksk(const u64* host_ksk, const u64* ms_zeros) {
     HC(hipMemcpyAsync(ms_zeros_dev() - 1, &zc, sizeof zc, hipMemcpyHostToDevice, stream_));
     if (zc) HC(hipMemcpyAsync(ms_zeros_dev(), ms_zeros, ms_zeros_words() * sizeof(u64), hipMemcpyHostToDevice, stream_));
     else if (ms_zeros_words()) HC(hipMemsetAsync(ms_zeros_dev(), 0, ms_zeros_words() * sizeof(u64), stream_));
+    build_ksk_limbs();
     HC(hipStreamSynchronize(stream_));
     set_ms_params((u32)zc);
+}
+
+void Engine::build_ksk_limbs() {
+    if (!ksm_min_) return;
+    if (!d_ksk_limbs_) HC(hipMalloc(&d_ksk_limbs_, ksm_limb_bytes(N, (int)prm_.ks_level, (int)prm_.lwe_dim)));
+    launch_ksm_key_limbs(d_ksk_, d_ksk_limbs_, N, (int)prm_.ks_level, (int)prm_.lwe_dim, stream_);
+    HC(hipGetLastError());
 }
 
 void Engine::attach_device_keys(double* bsk_dev, u64* ksk_dev_image) {
@@ -151,6 +164,8 @@ void Engine::attach_device_keys(double* bsk_dev, u64* ksk_dev_image) {
     HC(hipMemcpy(&zc, ms_zeros_dev() - 1, sizeof zc, hipMemcpyDeviceToHost));
     if (zc != 0 && zc != prm_.ms_zeros_count) throw std::runtime_error("attached key image does not match the parameter set");
     set_ms_params((u32)zc);
+    build_ksk_limbs();
+    HC(hipStreamSynchronize(stream_));
 }
 
 void Engine::ms_noise_reduce(u64* lwe_small, size_t count, int* chosen) {
@@ -196,6 +211,30 @@ void Engine::keyswitch(const u64* lwe_in, u64* lwe_small_out, size_t count, cons
     if (!key) throw std::runtime_error("no key-switching key loaded");
     if (!count) return;
     HC(hipSetDevice(device_));
+    if (!with_cast_key && ksm_min_ > 0 && d_ksk_limbs_ && count >= (size_t)ksm_min_) {
+        // large batch: int8 matrix product on the matrix cores, in launches of about 4096
+        // ciphertexts (whole program instances each, so that the block map shifts by pointer arithmetic)
+        if (imap.idx && !imap.ops) throw std::logic_error("block map without a period");
+        size_t chunk = 4096;
+        if (imap.idx) chunk = imap.ops >= chunk ? imap.ops : chunk / imap.ops * imap.ops;
+        if (chunk > count) chunk = count;
+        if (chunk > ksm_cap_) {
+            HC(hipStreamSynchronize(stream_));
+            (void)hipFree(d_ksm_dig_); (void)hipFree(d_ksm_prod_);
+            d_ksm_dig_ = nullptr; d_ksm_prod_ = nullptr; ksm_cap_ = 0;
+            HC(hipMalloc(&d_ksm_dig_, ksm_digit_bytes(chunk, N, (int)prm_.ks_level)));
+            HC(hipMalloc(&d_ksm_prod_, ksm_product_bytes(chunk, (int)prm_.lwe_dim)));
+            ksm_cap_ = chunk;
+        }
+        for (size_t c0 = 0; c0 < count; c0 += chunk) {
+            const size_t cnt = count - c0 < chunk ? count - c0 : chunk;
+            const u64* in = lwe_in + (imap.idx ? (c0 / imap.ops) * imap.inst_stride : c0) * (size_t)(N + 1);
+            launch_keyswitch_mfma(d_ksk_limbs_, in, d_ksm_dig_, d_ksm_prod_, lwe_small_out + c0 * (prm_.lwe_dim + 1), cnt, N,
+                                  (int)prm_.lwe_dim, (int)prm_.ks_base_log, (int)prm_.ks_level, imap, stream_);
+            HC(hipGetLastError());
+        }
+        return;
+    }
     const size_t need = keyswitch_scratch_words(count, N);
     if (need > ksdig_cap_) {
         HC(hipStreamSynchronize(stream_));

@@ -65,6 +65,14 @@ void launch_ksk_colsum(const u64* ksk, int rows, int cols, int half_base, u64* c
 void launch_keyswitch(const u64* ksk, const u64* colsum, const u64* in, u32* dig_scratch, u64* out, size_t count,
                       int big, int n, int base_log, int levels, const BlockMap& imap, hipStream_t st);
 size_t keyswitch_scratch_words(size_t count, int big);
+// the same key switch as an int8 matrix product on the matrix cores (ks_mfma.hip), for large batches
+bool ksm_supported(int big, int levels, int n);
+size_t ksm_limb_bytes(int big, int levels, int n);            // key image: eight signed bytes per key word
+size_t ksm_digit_bytes(size_t count, int big, int levels);    // scratch: signed digits of a batch
+size_t ksm_product_bytes(size_t count, int n);                // scratch: the int32 partial products
+void launch_ksm_key_limbs(const u64* ksk, int8_t* limbs, int big, int levels, int n, hipStream_t st);
+void launch_keyswitch_mfma(const int8_t* limbs, const u64* in, int8_t* dig, int* prod, u64* out, size_t count, int big,
+                           int n, int base_log, int levels, const BlockMap& imap, hipStream_t st);
 void launch_ms_noise_reduce(u64* lwe_small, int n, const u64* zeros, const MsParams& m, int* chosen, size_t count,
                             hipStream_t st);
 void launch_lwe_linear(const u64* a, const u64* b, u64* out, size_t count, int dim1, u64 ca, u64 cb, u64 add_body,
@@ -151,6 +159,14 @@ private:
     size_t small_cap_ = 0;
     u32* d_ksdig_ = nullptr;   // packed key-switch digits of the launch in flight
     size_t ksdig_cap_ = 0;
+    // matrix-core key switch: byte limbs of the key (built from d_ksk_, always owned), scratch for
+    // one launch of at most ksm_cap_ ciphertexts, batch size from which it is used (0: never)
+    int8_t* d_ksk_limbs_ = nullptr;
+    int8_t* d_ksm_dig_ = nullptr;
+    int* d_ksm_prod_ = nullptr;
+    size_t ksm_cap_ = 0;
+    int ksm_min_ = 1024;
+    void build_ksk_limbs();
     MsParams ms_{};
     int cu_count_ = 256;
     int br_chunk_ = 0;      // ciphertexts per blind-rotation launch; 0: about four rounds of resident workgroups

@@ -114,6 +114,45 @@ def test_keyswitch_bit_exact(base_log, level):
         ctx.close()
 
 
+@pytest.mark.parametrize("n,base_log,level", [(40, 4, 4), (33, 3, 3), (918, 4, 4), (100, 7, 2)])
+def test_keyswitch_on_the_matrix_cores_bit_exact(n, base_log, level):
+    """Large batches key-switch as an int8 matrix product (v_mfma_i32_32x32x32_i8) over byte limbs of
+    the key; forced here for a small ragged batch: every word equals the oracle's, including inputs
+    whose digits are all extreme (largest partial sums) and the VALU kernel's output."""
+    import os
+    os.environ["LFHE_KS_MFMA_MIN"] = "1"
+    try:
+        orc, keys, ctx = _mk(n, base_log, level, seed=8)
+    finally:
+        del os.environ["LFHE_KS_MFMA_MIN"]
+    orc2, keys2, ctx_valu = None, None, None
+    try:
+        r = Rng(seed_bytes(31))
+        cts = np.stack([r.u64s(N + 1) for _ in range(131)])  # ragged: not a multiple of the 128-row tile
+        cts[1][:] = 0
+        cts[2][:] = M64
+        cts[3][:] = (1 << 63) - (1 << 47)                    # decomposition carries ripple to the top
+        half = 1 << (base_log - 1)
+        word = 0
+        for lv in range(level):                              # every digit -B/2: the most negative sums
+            word |= half << (64 - base_log * (lv + 1))
+        cts[4][:] = word
+        cts[5][:] = (word - (1 << (64 - base_log * level))) & M64   # every digit B/2 - 1 (level > 1: carries aside)
+        got = ctx.keyswitch(cts)
+        for c in list(range(8)) + [64, 127, 128, 130]:
+            assert np.array_equal(got[c], orc.keyswitch(keys[3], cts[c])), c
+        os.environ["LFHE_KS_MFMA_MIN"] = "0"
+        try:
+            orc2, keys2, ctx_valu = _mk(n, base_log, level, seed=8)
+        finally:
+            del os.environ["LFHE_KS_MFMA_MIN"]
+        assert np.array_equal(got, ctx_valu.keyswitch(cts))
+    finally:
+        ctx.close()
+        if ctx_valu is not None:
+            ctx_valu.close()
+
+
 def test_blind_rotate_and_pbs_bit_exact_small_n(small):
     orc, keys, ctx = small
     lwe_sk, glwe_sk, bsk, ksk = keys
