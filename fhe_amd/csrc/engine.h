@@ -165,7 +165,7 @@ private:
     int8_t* d_ksm_dig_ = nullptr;
     int* d_ksm_prod_ = nullptr;
     size_t ksm_cap_ = 0;
-    int ksm_min_ = 1024;
+    int ksm_min_ = 128;
     void build_ksk_limbs();
     MsParams ms_{};
     int cu_count_ = 256;
