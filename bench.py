@@ -36,9 +36,12 @@ MODMUL_PER_PBS_GROUPED = 459 * (4 * 11264 + 16 * 2048)
 PEAK_GBFLY_PER_PRIME = 4748.0
 # memory-side traffic of one 4096-ciphertext blind-rotation launch, from separate rocprofv3 --pmc passes
 # (profiles/r01/pmc_hbm_v5.txt): (2 * FETCH_SIZE + WRITE_SIZE) * 1024, Infinity-Cache hits included
-TRAFFIC_BYTES_4096 = {"prime": (2 * 3808307 + 196800) * 1024, "q64": (2 * 7909668 + 196739) * 1024}
+TRAFFIC_BYTES_4096 = {"prime": (2 * 3808307 + 196800) * 1024, "q64": (2 * 7909668 + 196739) * 1024,
+                      "grouped": (2 * 14541630 + 67674) * 1024}   # profiles/r01/pmc_grouped_v10.txt
 # algorithmic bytes of one batch launch: both keys once + one ciphertext in and out per bootstrap
 BSK_BYTES, KSK_BYTES, CT_BYTES = 60162048, 60227584, 16392
+# device image of the bootstrapping key (f64 residues in the transform domain)
+KEY_IMAGE_BYTES = {"q64": 918 * 131072, "prime": 918 * 65536, "grouped": 1836 * 65536}
 
 
 # bootstrapping-key flavour -> (parameter set id, label, kernel, VALU peak in butterflies/s per GPU)
@@ -221,7 +224,11 @@ def main():
                          "unit": "Gmodmul/s", "frac": achieved / peak, "modmul_per_pbs": modmul,
                          "traffic": TRAFFIC_BYTES_4096.get(flavour) if B == BATCH else None,
                          "hbm": {"achieved": algo_bytes / ((ks_ms + br_ms) * 1e-3) / 1e9, "peak": 8000.0,
-                                 "unit": "GB/s", "algorithmic_bytes": algo_bytes}},
+                                 "unit": "GB/s", "algorithmic_bytes": algo_bytes},
+                         # key words the workgroups request per launch (served by L2): every ciphertext
+                         # streams the whole device key image once
+                         "key_stream": {"bytes": B * KEY_IMAGE_BYTES[flavour],
+                                        "achieved": B * KEY_IMAGE_BYTES[flavour] / br_s / 1e9, "unit": "GB/s"}},
         }
         if alts:
             res["other_bootstrapping_keys"] = alts
