@@ -417,3 +417,44 @@ def test_library_keygen_round_trip(params_id):
             assert [orc.decrypt_block(glwe_sk, b) for b in out] == [(d + 5) % 16 for d in digits]
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("params_id", [2, 3], ids=["bsk_prime", "bsk_prime_grouped"])
+def test_full_size_batch_properties(params_id):
+    """The benchmark's configuration (4096 blocks, 16 distinct tables) through size-independent
+    properties: every output decrypts to f(m); a second pass gives the same bits (no dependence on
+    scheduling); bootstrapping the identity's outputs with f equals bootstrapping the inputs with
+    f as decrypted values; the output noise stays far inside the decision margin."""
+    from fhe_amd.native import Context, KEY_CLIENT
+    ctx = Context(seed=seed_bytes(90), params_id=params_id)
+    try:
+        ctx.keygen()
+        blob = ctx.export_keys(KEY_CLIENT)
+        sk = np.frombuffer(blob[-(918 + 2048) * 8:], dtype=np.uint64)[918:].copy()
+        B = 4096
+        rng = np.random.default_rng(17)
+        vals = rng.integers(0, 256, size=B // 4)
+        blocks = np.concatenate([np.frombuffer(ctx.encrypt(int(v), 8)[16:], dtype=np.uint64).reshape(4, N + 1)
+                                 for v in vals])
+        msgs = np.array([(int(vals[i // 4]) >> (2 * (i % 4))) & 3 for i in range(B)])
+        f = [(lambda x, j=j: ((2 * j + 1) * x + j) % 16) for j in range(16)]
+        luts = np.stack([ctx.make_lut(g) for g in f])
+        idx = (np.arange(B) % 16).astype(np.uint32)
+        want = np.array([f[idx[i]](int(msgs[i])) for i in range(B)], dtype=np.uint64)
+
+        def decode(cts):
+            with np.errstate(over="ignore"):
+                phase = cts[:, N] - (cts[:, :N] * sk[None, :]).sum(axis=1, dtype=np.uint64)
+            m = ((phase + np.uint64(1 << 58)) >> np.uint64(59)) & np.uint64(15)
+            err = (phase - (m << np.uint64(59))).astype(np.int64)
+            return m, np.abs(err).max()
+        out = ctx.pbs_batch(blocks, luts, idx)
+        got, worst = decode(out)
+        assert np.array_equal(got, want)
+        assert worst < 1 << 53
+        assert np.array_equal(ctx.pbs_batch(blocks, luts, idx), out)
+        ident = ctx.pbs_batch(blocks, luts[:1])
+        got2, _ = decode(ctx.pbs_batch(ident, luts, idx))
+        assert np.array_equal(got2, want)
+    finally:
+        ctx.close()
