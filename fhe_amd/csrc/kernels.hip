@@ -1018,6 +1018,28 @@ void launch_fill_trivial(u64* arena, size_t instances, size_t inst_stride_blocks
                        first_block, m, bodies);
 }
 
+// Ciphertext arrays as the caller holds them (per ciphertext: header words, then its blocks) <-> arena
+// blocks.  One workgroup per (block, ciphertext); `idx` lists the arena block of every ciphertext
+// block, or is null for consecutive blocks starting at `first`.  With these the executor moves a
+// whole operand or result array across PCIe in ONE copy instead of one copy per block and instance.
+__global__ void __launch_bounds__(256) k_blocks_move(u64* __restrict__ arena, size_t inst_stride_blocks,
+                                                     const u32* __restrict__ idx, u32 first, u64* __restrict__ flat,
+                                                     size_t ct_words, u32 header_words, int to_arena) {
+    const u32 j = blockIdx.x;
+    const size_t inst = blockIdx.y;
+    u64* a = arena + (inst * inst_stride_blocks + (idx ? idx[j] : first + j)) * (size_t)(N + 1);
+    u64* f = flat + inst * ct_words + header_words + (size_t)j * (N + 1);
+    if (to_arena) { for (int w = threadIdx.x; w <= N; w += blockDim.x) a[w] = f[w]; }
+    else { for (int w = threadIdx.x; w <= N; w += blockDim.x) f[w] = a[w]; }
+}
+
+void launch_blocks_move(u64* arena, size_t instances, size_t inst_stride_blocks, const u32* idx, u32 first, u32 nblocks,
+                        u64* flat, size_t ct_words, u32 header_words, bool to_arena, hipStream_t st) {
+    if (!instances || !nblocks) return;
+    hipLaunchKernelGGL(k_blocks_move, dim3(nblocks, (unsigned)instances), dim3(256), 0, st, arena, inst_stride_blocks, idx,
+                       first, flat, ct_words, header_words, to_arena ? 1 : 0);
+}
+
 void launch_lin_batch(u64* arena, const LinOp* ops, int nops, size_t instances, size_t inst_stride_blocks, u64 delta,
                       hipStream_t st) {
     hipLaunchKernelGGL(k_lin_batch, dim3((unsigned)(instances * nops)), dim3(256), 0, st, arena, ops, nops,

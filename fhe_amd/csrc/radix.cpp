@@ -194,6 +194,25 @@ void cast_one(lfhe_ctx* ctx, const uint8_t* in, uint64_t in_len, uint32_t to_wid
     (void)ctx;
 }
 
+// Operand and result arrays cross PCIe whole: one copy between the caller's array and a device
+// staging buffer of the same layout, one kernel between the staging buffer and the arena blocks.
+constexpr uint32_t CT_HEADER_WORDS = 2;
+
+void upload_array(Engine& E, u64* staging, u64* arena, uint32_t nblocks_inst, const uint8_t* src, uint64_t ct_stride,
+                  uint32_t first, uint32_t nb, uint64_t n) {
+    HC(hipMemcpyAsync(staging, src, n * ct_stride, hipMemcpyHostToDevice, E.stream()));
+    launch_blocks_move(arena, n, nblocks_inst, nullptr, first, nb, staging, ct_stride / 8, CT_HEADER_WORDS, true, E.stream());
+    HC(hipGetLastError());
+}
+
+// blocks: device copy of the arena block numbers of the result's blocks
+void download_array(Engine& E, u64* staging, u64* arena, uint32_t nblocks_inst, const u32* blocks, uint32_t nb,
+                    uint8_t* dst, uint64_t ct_stride, uint64_t n) {
+    launch_blocks_move(arena, n, nblocks_inst, blocks, 0, nb, staging, ct_stride / 8, CT_HEADER_WORDS, false, E.stream());
+    HC(hipGetLastError());
+    HC(hipMemcpyAsync(dst, staging, n * ct_stride, hipMemcpyDeviceToHost, E.stream()));
+}
+
 void run_batch(lfhe_ctx* ctx, uint32_t op, uint32_t width, uint64_t n, const uint8_t* lhs, const uint8_t* rhs,
                bool rhs_scalar, const uint8_t* cond, uint8_t* out) {
     if (!width_ok(width)) throw std::invalid_argument("unsupported bit width");
@@ -228,9 +247,10 @@ void run_batch(lfhe_ctx* ctx, uint32_t op, uint32_t width, uint64_t n, const uin
         return;
     }
     DevBuf<u64> arena(n * (size_t)P.nblocks * BLK_WORDS);
+    const uint64_t out_stride = ct_bytes(P.out_width);
+    DevBuf<u64> staging(n * std::max<uint64_t>({in_stride, ct_bytes(rhs_width), out_stride}) / 8);
     auto upload = [&](const uint8_t* src, uint64_t sstride, uint32_t first, uint32_t nb) {
-        HC(hipMemcpy2DAsync(reinterpret_cast<uint8_t*>(arena.p) + (size_t)first * BLK_BYTES, inst_bytes,
-                            src + sizeof(CtHeader), sstride, (size_t)nb * BLK_BYTES, n, hipMemcpyHostToDevice, st));
+        upload_array(E, staging.p, arena.p, P.nblocks, src, sstride, first, nb, n);
     };
     upload(lhs, in_stride, P.lhs[0], m);
     DevBuf<u64> scal;
@@ -256,11 +276,9 @@ void run_batch(lfhe_ctx* ctx, uint32_t op, uint32_t width, uint64_t n, const uin
     if (op == LFHE_OP_SELECT) upload(cond, ct_bytes(1), P.cond[0], 1);
 
     replay(ctx, C, arena.p, n);
-    const uint64_t out_stride = ct_bytes(P.out_width);
-    for (size_t j = 0; j < P.out.size(); ++j)
-        HC(hipMemcpy2DAsync(out + sizeof(CtHeader) + j * BLK_BYTES, out_stride,
-                            reinterpret_cast<uint8_t*>(arena.p) + (size_t)P.out[j] * BLK_BYTES, inst_bytes, BLK_BYTES, n,
-                            hipMemcpyDeviceToHost, st));
+    DevBuf<u32> out_blocks(P.out.size());
+    HC(hipMemcpyAsync(out_blocks.p, P.out.data(), P.out.size() * sizeof(u32), hipMemcpyHostToDevice, st));
+    download_array(E, staging.p, arena.p, P.nblocks, out_blocks.p, (uint32_t)P.out.size(), out, out_stride, n);
     E.sync();
     CtHeader h{CT_MAGIC, 1, (uint16_t)P.out_width, (uint32_t)P.out.size(), P.out_noise, P.out_degree, 0};
     for (uint64_t i = 0; i < n; ++i) std::memcpy(out + i * out_stride, &h, sizeof h);
@@ -331,18 +349,20 @@ void run_fused(lfhe_ctx* ctx, const lfhe_step* steps, uint32_t nsteps, uint32_t 
         return;
     }
     DevBuf<u64> arena(n * (size_t)P.nblocks * BLK_WORDS);
+    uint64_t widest = 0;
+    for (uint32_t i = 0; i < n_inputs; ++i) widest = std::max(widest, ct_bytes(widths[i]));
+    for (uint32_t o = 0; o < n_outputs; ++o) widest = std::max(widest, ct_bytes(P.out_widths[o]));
+    DevBuf<u64> staging(n * widest / 8);
     for (uint32_t i = 0; i < n_inputs; ++i)
-        HC(hipMemcpy2DAsync(reinterpret_cast<uint8_t*>(arena.p) + (size_t)P.ins[i][0] * BLK_BYTES, inst_bytes,
-                            inputs[i] + sizeof(CtHeader), ct_bytes(widths[i]), (size_t)blocks_of(widths[i]) * BLK_BYTES, n,
-                            hipMemcpyHostToDevice, st));
+        upload_array(E, staging.p, arena.p, P.nblocks, inputs[i], ct_bytes(widths[i]), P.ins[i][0], blocks_of(widths[i]), n);
     replay(ctx, C, arena.p, n);
+    std::vector<DevBuf<u32>> out_blocks;
     for (uint32_t o = 0; o < n_outputs; ++o) {
         if (!outs[o]) throw std::invalid_argument("null output");
-        const uint64_t stride = ct_bytes(P.out_widths[o]);
-        for (size_t j = 0; j < P.outs[o].size(); ++j)
-            HC(hipMemcpy2DAsync(outs[o] + sizeof(CtHeader) + j * BLK_BYTES, stride,
-                                reinterpret_cast<uint8_t*>(arena.p) + (size_t)P.outs[o][j] * BLK_BYTES, inst_bytes,
-                                BLK_BYTES, n, hipMemcpyDeviceToHost, st));
+        out_blocks.emplace_back(P.outs[o].size());
+        HC(hipMemcpyAsync(out_blocks.back().p, P.outs[o].data(), P.outs[o].size() * sizeof(u32), hipMemcpyHostToDevice, st));
+        download_array(E, staging.p, arena.p, P.nblocks, out_blocks.back().p, (uint32_t)P.outs[o].size(), outs[o],
+                       ct_bytes(P.out_widths[o]), n);
     }
     E.sync();
     for (uint32_t o = 0; o < n_outputs; ++o) {

@@ -364,11 +364,11 @@ class Context:
         Cn = None if cond is None else np.frombuffer(b"".join(cond), dtype=np.uint8)
         out_w = 1 if op in COMPARISONS else bit_width
         sz = self.ciphertext_size(out_w)
-        out = np.zeros(n * sz, dtype=np.uint8)
+        out = np.empty(n * sz, dtype=np.uint8)   # every byte is written by the library
         self._ck(self._L.lfhe_evaluate_batch(self._h, OPS[op], bit_width, n, _ptr(A), _ptr(B), 1 if scalar else 0,
                                              _ptr(Cn), _ptr(out)))
-        raw = out.tobytes()
-        return [raw[i * sz:(i + 1) * sz] for i in range(n)]
+        view = memoryview(out)
+        return [bytes(view[i * sz:(i + 1) * sz]) for i in range(n)]
 
     def rand(self, bit_width: int, seed: bytes, random_bits: int | None = None) -> bytes:
         """Oblivious pseudo-random ciphertext: uniform below 2^random_bits (default: the full width)."""
@@ -392,14 +392,14 @@ class Context:
         ins = [np.frombuffer(b"".join(col), dtype=np.uint8) for col in inputs]
         in_ptrs = (C.c_void_p * len(ins))(*[a.ctypes.data for a in ins])
         sizes = [self.ciphertext_size(x) for x in out_widths]
-        outs = [np.zeros(n * sz, dtype=np.uint8) for sz in sizes]
+        outs = [np.empty(n * sz, dtype=np.uint8) for sz in sizes]   # every byte is written by the library
         out_ptrs = (C.c_void_p * len(outs))(*[a.ctypes.data for a in outs])
         self._ck(self._L.lfhe_evaluate_fused(self._h, arr, len(steps), len(in_widths), w, n, in_ptrs, o, len(outputs),
                                              out_ptrs))
         res = []
         for a, sz in zip(outs, sizes):
-            raw = a.tobytes()
-            res.append([raw[i * sz:(i + 1) * sz] for i in range(n)])
+            view = memoryview(a)
+            res.append([bytes(view[i * sz:(i + 1) * sz]) for i in range(n)])
         return res
 
     def pbs_count(self) -> int:

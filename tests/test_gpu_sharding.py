@@ -9,20 +9,24 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("params_id", [1, 2, 3], ids=["bsk_q64", "bsk_prime", "bsk_prime_grouped"])
 def test_attached_key_images_bootstrap_like_the_originals(params_id):
-    import torch
+    import ctypes as C
     from fhe_amd.native import Context, KEY_CLIENT
-    from fhe_amd.sharding import _DevMem
-    dev = torch.device("cuda", 0)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    D2D = 3
     src = Context(seed=bytes(range(32)), params_id=params_id)
     dst = Context(seed=bytes(range(32)), params_id=params_id)
+    tb, tk = C.c_void_p(), C.c_void_p()
     try:
         src.keygen()
         bp, bsk_bytes, kp, ksk_bytes = src.device_keys()
         assert (bsk_bytes, ksk_bytes) == dst.device_keys_size()
-        tb = torch.as_tensor(_DevMem(bp, bsk_bytes), device=dev).clone()
-        tk = torch.as_tensor(_DevMem(kp, ksk_bytes), device=dev).clone()
-        torch.cuda.synchronize()
-        dst.attach_device_keys(tb.data_ptr(), tk.data_ptr())
+        assert hip.hipMalloc(C.byref(tb), bsk_bytes) == 0 and hip.hipMalloc(C.byref(tk), ksk_bytes) == 0
+        assert hip.hipMemcpy(tb, C.c_void_p(bp), bsk_bytes, D2D) == 0      # synchronous
+        assert hip.hipMemcpy(tk, C.c_void_p(kp), ksk_bytes, D2D) == 0
+        dst.attach_device_keys(tb.value, tk.value)
         dst.import_keys(KEY_CLIENT, src.export_keys(KEY_CLIENT))
         rng = np.random.default_rng(3)
         vals = [int(v) for v in rng.integers(0, 256, size=80)]           # 320 blocks: the matrix-core key switch
@@ -38,4 +42,5 @@ def test_attached_key_images_bootstrap_like_the_originals(params_id):
     finally:
         dst.close()
         src.close()
-        del tb, tk
+        hip.hipFree(tb)
+        hip.hipFree(tk)
