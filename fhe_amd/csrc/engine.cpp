@@ -39,7 +39,10 @@ Engine::Engine(int device, const EngineParams& p) : device_(device), prm_(p) {
     hipDeviceProp_t prop;
     HC(hipGetDeviceProperties(&prop, device_));
     cu_count_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    wide_below_ = 2 * cu_count_;
+    // the 512-thread kernels hold one ciphertext per CU at a time (grouped key: 207 registers) or two
+    // (one key bit per step); measured with the grouped key: 4.2 vs 4.5 ms at 64 ciphertexts, 4.6 vs 4.8 at
+    // 256, but 8.8 vs 7.4 ms at 512
+    wide_below_ = (p.bsk_grouping == 2 ? 1 : 2) * cu_count_;
     if (const char* e = std::getenv("LFHE_WIDE_BELOW")) wide_below_ = std::atoi(e);   // tuning / A-B runs
     if (const char* e = std::getenv("LFHE_BR_CHUNK")) br_chunk_ = std::atoi(e);       // 0: automatic
     if (const char* e = std::getenv("LFHE_KS_MFMA_MIN")) ksm_min_ = std::atoi(e);     // 0: VALU key switch only
