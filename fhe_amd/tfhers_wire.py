@@ -1,16 +1,38 @@
-"""Reading the key blobs the reference's SDK produces (tfhe-rs `safe_serialize`, node-tfhe
+"""Reading and writing the key blobs of the reference's SDK (tfhe-rs `safe_serialize`, node-tfhe
 1.4.0-alpha.3: sdk/relayer/generateKeys.js:20-66 writes privateKey.bin / publicKey.bin).
 
 Not a general bincode reader: the blobs are walked for their length-prefixed u64 vectors, which is
 enough to lift out the secret keys and the compact public key; the numeric parameters sit at fixed
 positions behind the LWE secret key (layout observed in the reference's own fixtures,
-sdk/relayer/src/test/keys/).  Emitting these formats is not implemented.
+sdk/relayer/src/test/keys/).
+
+Writing works for that one parameter set (PARAM_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128 with its
+dedicated public-key parameters): the framing around the key vectors -- serialization header,
+version tags, parameter structs -- is the fixtures' own (extracted as data by
+tools/extract_wire_framing.py), the vectors are the caller's.  Re-emitting the fixtures' vectors
+reproduces the fixtures byte for byte (tests/test_reference_keys.py).
 """
 from __future__ import annotations
 
+import base64
 import struct
 
 import numpy as np
+
+# framing of high_level_api::ClientKey: before the GLWE key, between GLWE and LWE key, between the
+# LWE key and the public-key-encryption secret key (the compute parameters), after it (its parameters)
+CLIENT_KEY_FRAMING = (
+    "AwAAAAAAAAAwLjUAAAAAAwAAAAAAAAAwLjEZAAAAAAAAAGhpZ2hfbGV2ZWxfYXBpOjpDbGllbnRLZXkBAAAAAwAAAAAAAAAAAAAAAAAAAAAIAAAAAAAA",
+    "AAAAAAAIAAAAAAAAAAAAAJYDAAAAAAAA",
+    "AAAAAAAAAAAAAAAAAAAAAAAAAAABAAAAAAAAAJYDAAAAAAAAAAAAAAEAAAAAAAAAAAAAAAAIAAAAAAAAAAAAAAEAAAAAAAAALQAAAAAAAAABAAAAAAAAABEAAAAAAAAAFwAAAAAAAAAAAAAAAQAAAAAAAAAAAAAABAAAAAAAAAAAAAAABAAAAAAAAAAAAAAABAAAAAAAAAAAAAAABAAAAAAAAAAAAAAABQAAAAAAAADYppQh5CRgwAAAAAAAAAAAAAAAAAAAAAAAAAAAQAAAAAAAAAAAAAAAAAAAAAEAAAAAAAAAAKkFAAAAAAAAAAAAAAAAAAAAAJBDAAAAAGEQK5kVXCpAAAAAAM823pD6ppE+AQAAAAAAAAAAAAAAAAAIAAAAAAAA",
+    "AQAAAAAAAAAACAAAAAAAAAAAAAABAAAAAAAAABEAAAAAAAAABAAAAAAAAAAAAAAABAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAEAAAAAAAAAAAAAAAAAAAAAAAAAAAgAAAAAAAAAAAAAABAAAAAAAAAAAAAAABAAAAAAAAAAAAAAAAQAAAAAAAAAAAAAAAAAAAAA=",
+)
+# framing of high_level_api::CompactPublicKey: before and after the mask||body vector
+COMPACT_PUBLIC_KEY_FRAMING = (
+    "AwAAAAAAAAAwLjUAAAAAAwAAAAAAAAAwLjEgAAAAAAAAAGhpZ2hfbGV2ZWxfYXBpOjpDb21wYWN0UHVibGljS2V5AQAAAAAAAAAAAAAAAQAAAAAAAAAAAAAAABAAAAAAAAA=",
+    "AAAAAAAIAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAABAAAAAAAAAAAEAAAAAAAAAAAgAAAAAAAAAAAAAAQAAAAAAAAARAAAAAAAAAAQAAAAAAAAAAAAAAAQAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAABAAAAAAAAAAAAAAAAAAAAAAAAAAAIAAAAAAAAAAAAAAAAAAAA=",
+)
+CLIENT_KEY_DIMS = (2048, 918, 2048)      # GLWE key, LWE key, public-key-encryption secret key
 
 
 def _u64_vectors(blob: bytes, accept, min_len: int = 512):
@@ -78,3 +100,44 @@ def compact_public_key_to_lfpk(blob: bytes, noise_log2: int = 17) -> bytes:
         raise ValueError("only polynomial size 2048 is supported")
     hdr = struct.pack("<IIII", 0x4B50464C, 2048, noise_log2, 1)
     return hdr + mask.astype("<u8").tobytes() + body.astype("<u8").tobytes()
+
+
+def emit_client_key(glwe_sk, lwe_sk, pke_sk) -> bytes:
+    """Serialized high_level_api::ClientKey of the reference's parameter set holding these binary keys."""
+    keys = [np.ascontiguousarray(k, dtype="<u8") for k in (glwe_sk, lwe_sk, pke_sk)]
+    for k, n in zip(keys, CLIENT_KEY_DIMS):
+        if k.shape != (n,) or int(k.max(initial=0)) > 1:
+            raise ValueError("keys must be binary vectors of 2048, 918 and 2048 words")
+    out = bytearray()
+    for frame, k in zip(CLIENT_KEY_FRAMING, keys + [None]):
+        out += base64.b64decode(frame)
+        if k is not None:
+            out += k.tobytes()
+    return bytes(out)
+
+
+def emit_compact_public_key(mask, body) -> bytes:
+    """Serialized high_level_api::CompactPublicKey (tfhe-rs convention: body = mask (*) rev(s) + e)."""
+    v = np.concatenate([np.ascontiguousarray(mask, dtype="<u8"), np.ascontiguousarray(body, dtype="<u8")])
+    if v.shape != (4096,):
+        raise ValueError("mask and body must have 2048 words each")
+    return base64.b64decode(COMPACT_PUBLIC_KEY_FRAMING[0]) + v.tobytes() + base64.b64decode(COMPACT_PUBLIC_KEY_FRAMING[1])
+
+
+def make_compact_public_key(pke_sk, seed: bytes, noise_log2: int = 17):
+    """(mask, body) of a fresh compact public key under the binary secret `pke_sk` in the convention of
+    tfhe-rs: body = mask (*) rev(s) + e over Z_2^64[X]/(X^N+1), rev(s)_i = s_{N-1-i}, e uniform in
+    [-2^noise_log2, 2^noise_log2]."""
+    s = np.ascontiguousarray(pke_sk, dtype=np.uint64)
+    n = len(s)
+    rng = np.random.default_rng(list(seed))
+    mask = rng.integers(0, 1 << 64, size=n, dtype=np.uint64)
+    e = rng.integers(-(1 << noise_log2), (1 << noise_log2) + 1, size=n, dtype=np.int64).astype(np.uint64)
+    body = e.copy()
+    rev = s[::-1]
+    with np.errstate(over="ignore"):
+        for i in np.nonzero(rev)[0]:          # body += X^i * mask (negacyclic)
+            i = int(i)
+            body[i:] += mask[:n - i]
+            body[:i] -= mask[n - i:]
+    return mask, body

@@ -46,6 +46,71 @@ def test_client_key_blob_is_read():
     assert struct.unpack("<IIII", lfpk[:16]) == (0x4B50464C, 2048, 17, 1) and len(lfpk) == 16 + 2 * 2048 * 8
 
 
+def test_key_blobs_are_written_in_the_reference_format():
+    """Emission is pinned by the fixtures themselves: their vectors, re-emitted, give the fixtures back
+    byte for byte; other keys round-trip through the reader; a public key made here for a secret key
+    has the residual body - mask (*) rev(s) the reference's own public key has (noise of 2^17)."""
+    priv, pub = _blobs()
+    k = W.parse_client_key(priv)
+    assert W.emit_client_key(k["glwe_sk"], k["lwe_sk"], k["pke_sk"]) == priv
+    mask, body = W.parse_compact_public_key(pub)
+    assert W.emit_compact_public_key(mask, body) == pub
+    rng = np.random.default_rng(4)
+    mine = [rng.integers(0, 2, size=n, dtype=np.uint64) for n in W.CLIENT_KEY_DIMS]
+    blob = W.emit_client_key(*mine)
+    assert len(blob) == len(priv)
+    back = W.parse_client_key(blob)
+    assert all(np.array_equal(a, b) for a, b in zip(mine, (back["glwe_sk"], back["lwe_sk"], back["pke_sk"])))
+    assert back["params"] == k["params"]
+    with pytest.raises(ValueError):
+        W.emit_client_key(mine[0][:-1], mine[1], mine[2])
+    with pytest.raises(ValueError):
+        W.emit_client_key(mine[0] + np.uint64(1), mine[1], mine[2])
+
+    def residual(mask, body, s):
+        n = len(s)
+        acc = body.copy()
+        with np.errstate(over="ignore"):
+            for i in np.nonzero(s[::-1])[0]:
+                i = int(i)
+                acc[i:] -= mask[:n - i]
+                acc[:i] += mask[n - i:]
+        return np.abs(acc.astype(np.int64)).max()
+    assert residual(mask, body, k["pke_sk"]) <= 1 << 17                       # the reference's own key
+    m2, b2 = W.make_compact_public_key(mine[2], bytes(range(16)))
+    assert residual(m2, b2, mine[2]) <= 1 << 17
+    m3, b3 = W.parse_compact_public_key(W.emit_compact_public_key(m2, b2))
+    assert np.array_equal(m3, m2) and np.array_equal(b3, b2)
+
+
+@pytest.mark.gpu
+def test_keys_exported_in_the_reference_format_come_back_and_work():
+    """Library keys -> reference-format ClientKey / CompactPublicKey blobs -> read back like the
+    reference's own fixtures: encryption under the emitted public key, cast, computation, decryption."""
+    from fhe_amd.native import Context, KEY_CLIENT
+    src = Context(seed=bytes(range(32)), params_id=3)
+    ctx = Context(seed=bytes(range(1, 33)), params_id=3)
+    try:
+        src.keygen()
+        words = np.frombuffer(src.export_keys(KEY_CLIENT)[-(918 + 2048) * 8:], dtype=np.uint64)
+        lwe_sk, glwe_sk = words[:918].copy(), words[918:].copy()
+        pke_sk = np.random.default_rng(9).integers(0, 2, size=2048, dtype=np.uint64)
+        priv = W.emit_client_key(glwe_sk, lwe_sk, pke_sk)
+        pub = W.emit_compact_public_key(*W.make_compact_public_key(pke_sk, bytes(range(16))))
+        k = W.parse_client_key(priv)
+        ctx.import_client_keys_raw(k["lwe_sk"], k["glwe_sk"])
+        ctx.keygen_server()
+        ctx.set_pke_key(k["pke_sk"])
+        lfpk = W.compact_public_key_to_lfpk(pub)
+        a = ctx.cast_from_pke(ctx.encrypt_public(lfpk, 0xC0DE, 16))
+        assert ctx.decrypt(a) == 0xC0DE
+        assert src.decrypt(a) == 0xC0DE                      # the same compute key as the exporting context's
+        assert ctx.decrypt(ctx.evaluate("add", 16, a, a)) == (2 * 0xC0DE) & 0xFFFF
+    finally:
+        src.close()
+        ctx.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("params_id", [1, 2])
 def test_reference_client_key_drives_the_backend(params_id):
