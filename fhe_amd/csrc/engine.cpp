@@ -86,6 +86,8 @@ Engine::~Engine() {
     (void)hipFree(d_ksk_limbs_);
     (void)hipFree(d_ksm_dig_);
     (void)hipFree(d_ksm_prod_);
+    (void)hipFree(d_pack_limbs_);
+    (void)hipFree(d_decomp_bsk_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -101,20 +103,79 @@ void Engine::load_bsk(const u64* host_bsk) {
         HC(hipMalloc(&d_bsk_, bsk_dev_bytes()));
         own_keys_ = true;
     }
+    build_bsk_image(host_bsk, bsk_ggsw_count(), d_bsk_);
+}
+
+void Engine::build_bsk_image(const u64* host_bsk, size_t total, double* dst) {
     // upload and transform in slabs of 64 GGSWs to bound the staging buffer
     const size_t slab = 64;
+    const size_t row = single_modulus() ? BSKQ_ROW : BSK_ROW;
     u64* d_raw = nullptr;
     HC(hipMalloc(&d_raw, slab * 4 * N * sizeof(u64)));
-    const size_t total = bsk_ggsw_count();
     for (size_t i0 = 0; i0 < total; i0 += slab) {
         const size_t cnt = (total - i0) < slab ? (total - i0) : slab;
         HC(hipMemcpyAsync(d_raw, host_bsk + i0 * 4 * N, cnt * 4 * N * sizeof(u64), hipMemcpyHostToDevice, stream_));
-        if (single_modulus()) launch_bskq_prepare(T_, d_raw, d_bsk_ + i0 * BSKQ_ROW, cnt * 4, stream_);
-        else launch_ntt_forward(T_, d_raw, d_bsk_ + i0 * BSK_ROW, cnt * 4, 1, stream_);
+        if (single_modulus()) launch_bskq_prepare(T_, d_raw, dst + i0 * row, cnt * 4, stream_);
+        else launch_ntt_forward(T_, d_raw, dst + i0 * row, cnt * 4, 1, stream_);
         HC(hipGetLastError());
         HC(hipStreamSynchronize(stream_));
     }
     HC(hipFree(d_raw));
+}
+
+void Engine::load_compression_keys(const CompShape& shape, const u64* host_pksk, const u64* host_decomp_bsk) {
+    HC(hipSetDevice(device_));
+    if (shape.glwe_words() % 16 || ((size_t)N * shape.ks_level) % 64 || shape.nc > 256 || shape.small_dim() > 4096 ||
+        shape.storage_log != LOGN + 1)
+        throw std::runtime_error("unsupported compression shape");
+    comp_ = shape;
+    const size_t K = (size_t)N * shape.ks_level, cols = (size_t)shape.glwe_words();
+    if (!d_pack_limbs_) HC(hipMalloc(&d_pack_limbs_, 8 * cols * K));
+    u64* d_raw = nullptr;
+    HC(hipMalloc(&d_raw, shape.pksk_words() * sizeof(u64)));
+    HC(hipMemcpyAsync(d_raw, host_pksk, shape.pksk_words() * sizeof(u64), hipMemcpyHostToDevice, stream_));
+    launch_pack_key_limbs(d_raw, d_pack_limbs_, N, shape.ks_level, shape.kc, shape.nc, stream_);
+    HC(hipGetLastError());
+    HC(hipStreamSynchronize(stream_));
+    HC(hipFree(d_raw));
+    const size_t row = single_modulus() ? BSKQ_ROW : BSK_ROW;
+    if (!d_decomp_bsk_) HC(hipMalloc(&d_decomp_bsk_, decomp_bsk_ggsw_count() * row * sizeof(double)));
+    build_bsk_image(host_decomp_bsk, decomp_bsk_ggsw_count(), d_decomp_bsk_);
+}
+
+void Engine::compress(const u64* blocks, size_t count, uint16_t* out, u64 scale) {
+    if (!has_compression_keys()) throw std::runtime_error("no compression keys loaded");
+    if (!count) return;
+    HC(hipSetDevice(device_));
+    // launches of at most 4096 blocks (a multiple of the GLWE capacity), one scratch pair
+    const size_t chunk = 4096;
+    const size_t cap = count < chunk ? count : chunk;
+    int8_t* dig = nullptr;
+    int* prod = nullptr;
+    HC(hipMalloc(&dig, ksm_rows_pad(cap) * (size_t)N * comp_.ks_level));
+    HC(hipMalloc(&prod, ksm_rows_pad(cap) * 8 * (size_t)comp_.glwe_words() * sizeof(int)));
+    for (size_t c0 = 0; c0 < count; c0 += chunk) {
+        const size_t cnt = count - c0 < chunk ? count - c0 : chunk;
+        launch_pack(d_pack_limbs_, blocks + c0 * (size_t)(N + 1), dig, prod, out + (c0 / comp_.nc) * (size_t)comp_.glwe_words(),
+                    cnt, N, comp_.kc, comp_.nc, comp_.ks_base_log, comp_.ks_level, comp_.storage_log, scale, BlockMap(), stream_);
+        HC(hipGetLastError());
+    }
+    HC(hipStreamSynchronize(stream_));
+    HC(hipFree(dig));
+    HC(hipFree(prod));
+}
+
+void Engine::decompress(const uint16_t* glwe, size_t count, const u64* lut, u64* blocks_out) {
+    if (!has_compression_keys()) throw std::runtime_error("no compression keys loaded");
+    if (!count) return;
+    HC(hipSetDevice(device_));
+    u64* small = nullptr;
+    HC(hipMalloc(&small, count * ((size_t)comp_.small_dim() + 1) * sizeof(u64)));
+    launch_unpack_extract(glwe, small, count, comp_.kc, comp_.nc, comp_.storage_log, stream_);
+    HC(hipGetLastError());
+    blind_rotate_with(d_decomp_bsk_, (uint32_t)comp_.small_dim(), small, lut, nullptr, nullptr, blocks_out, count);
+    HC(hipStreamSynchronize(stream_));
+    HC(hipFree(small));
 }
 
 void Engine::set_ms_params(u32 zcount) {
@@ -294,9 +355,14 @@ static size_t launch_chunk(size_t count, size_t ops, size_t slots) {
 void Engine::blind_rotate(const u64* lwe_small, const u64* luts, const u32* lut_index, u64* glwe_out, u64* lwe_out,
                           size_t count, const BlockMap& omap) {
     if (!d_bsk_) throw std::runtime_error("no bootstrapping key loaded");
+    blind_rotate_with(d_bsk_, prm_.lwe_dim, lwe_small, luts, lut_index, glwe_out, lwe_out, count, omap);
+}
+
+void Engine::blind_rotate_with(const double* bsk, uint32_t n, const u64* lwe_small, const u64* luts, const u32* lut_index,
+                               u64* glwe_out, u64* lwe_out, size_t count, const BlockMap& omap) {
     if (!count) return;
     HC(hipSetDevice(device_));
-    const size_t n1 = (size_t)prm_.lwe_dim + 1;
+    const size_t n1 = (size_t)n + 1;
     const size_t slots = (size_t)(single_modulus() ? 4 : 2) * (size_t)cu_count_;   // resident workgroups
     if (omap.idx && !omap.ops) throw std::logic_error("block map without a period");
     const size_t chunk = br_chunk_ > 0 ? (omap.ops ? ((size_t)br_chunk_ + omap.ops - 1) / omap.ops * omap.ops : (size_t)br_chunk_)
@@ -314,10 +380,10 @@ void Engine::blind_rotate(const u64* lwe_small, const u64* luts, const u32* lut_
             if (li && !omap.ops) li += c0;   // with a period the launch starts on a multiple of it
         }
         if (single_modulus())
-            launch_blind_rotate_q(T_, d_bsk_, in, (int)prm_.lwe_dim, luts, li, gout, lout, cnt, omap,
+            launch_blind_rotate_q(T_, bsk, in, (int)n, luts, li, gout, lout, cnt, omap,
                                   1.0 / (double)qp_gadget(), wide_below_, (int)prm_.bsk_grouping, stream_);
         else
-            launch_blind_rotate(T_, d_bsk_, in, (int)prm_.lwe_dim, luts, li, gout, lout, cnt, omap, stream_);
+            launch_blind_rotate(T_, bsk, in, (int)n, luts, li, gout, lout, cnt, omap, stream_);
         HC(hipGetLastError());
     }
 }

@@ -80,6 +80,27 @@ void launch_ms_noise_reduce(u64* lwe_small, int n, const u64* zeros, const MsPar
 void launch_lwe_linear(const u64* a, const u64* b, u64* out, size_t count, int dim1, u64 ca, u64 cb, u64 add_body,
                        hipStream_t st);
 
+// ciphertext compression (ks_mfma.hip)
+void launch_pack(const int8_t* limbs, const u64* in, int8_t* dig, int* prod, uint16_t* out, size_t count, int big, int kc,
+                 int nc, int base_log, int levels, int storage_log, u64 scale, const BlockMap& imap, hipStream_t st);
+void launch_pack_key_limbs(const u64* pksk, int8_t* limbs, int big, int levels, int kc, int nc, hipStream_t st);
+void launch_unpack_extract(const uint16_t* glwe, u64* small, size_t count, int kc, int nc, int storage_log, hipStream_t st);
+size_t ksm_rows_pad(size_t count);
+
+// Shape of the compression scheme: packing key switch into GLWE ciphertexts of dimension kc and
+// polynomial size nc (nc blocks per GLWE), stored modulo 2^storage_log; decompression bootstraps
+// under a key for the flattened GLWE secret (kc * nc bits).  The numbers are those of tfhe-rs'
+// COMP_PARAM_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128.
+struct CompShape {
+    int kc = 4, nc = 256;
+    int ks_base_log = 4, ks_level = 3;
+    int storage_log = 12;
+    uint32_t noise_log2 = 43;
+    int small_dim() const { return kc * nc; }
+    int glwe_words() const { return (kc + 1) * nc; }
+    size_t pksk_words() const { return (size_t)N * ks_level * glwe_words(); }
+};
+
 class Engine {
 public:
     // throws std::runtime_error on unsupported parameters or HIP failure
@@ -95,7 +116,8 @@ public:
     bool has_keys() const { return d_bsk_ && d_ksk_; }
 
     // GGSWs in the bootstrapping key
-    size_t bsk_ggsw_count() const { return prm_.bsk_grouping == 2 ? 4 * (((size_t)prm_.lwe_dim + 1) / 2) : prm_.lwe_dim; }
+    size_t ggsw_count_for(uint32_t n) const { return prm_.bsk_grouping == 2 ? 4 * (((size_t)n + 1) / 2) : n; }
+    size_t bsk_ggsw_count() const { return ggsw_count_for(prm_.lwe_dim); }
     size_t bsk_raw_words() const { return bsk_ggsw_count() * 4 * N; }
     size_t ksk_words() const { return (size_t)N * prm_.ks_level * (prm_.lwe_dim + 1); }
     bool single_modulus() const { return prm_.bsk_modulus != 0; }
@@ -139,6 +161,20 @@ public:
     void pbs_layer(u64* arena, size_t instances, size_t inst_stride_blocks, const u32* in_idx, const u32* out_idx,
                    const u32* lut_of_op, u32 ops, const u64* luts);
     void lin_layer(u64* arena, size_t instances, size_t inst_stride_blocks, const LinOp* ops, int nops, u64 delta);
+    // the same blind rotation under another bootstrapping key image of this engine's flavour, for
+    // small ciphertexts of dimension n
+    void blind_rotate_with(const double* bsk, uint32_t n, const u64* lwe_small, const u64* luts, const u32* lut_index,
+                           u64* glwe_out, u64* lwe_out, size_t count, const BlockMap& omap = BlockMap());
+    // ---- compression: host keys in (packing key [N][level][(kc+1) nc]; bootstrapping key for the
+    // flattened compression secret, same layout and flavour as load_bsk takes)
+    void load_compression_keys(const CompShape& shape, const u64* host_pksk, const u64* host_decomp_bsk);
+    bool has_compression_keys() const { return d_pack_limbs_ && d_decomp_bsk_; }
+    const CompShape& comp_shape() const { return comp_; }
+    size_t decomp_bsk_ggsw_count() const { return ggsw_count_for((uint32_t)comp_.small_dim()); }
+    // count blocks (device, contiguous) -> ceil(count / nc) GLWEs of (kc+1) nc 16-bit words (device)
+    void compress(const u64* blocks, size_t count, uint16_t* out, u64 scale);
+    // stored GLWEs (device) -> count blocks under the compute key, table applied by the bootstrap
+    void decompress(const uint16_t* glwe, size_t count, const u64* lut, u64* blocks_out);
     void external_product(const u32* ggsw_index, const u64* glwe, u64* out, size_t count);
     void ntt_forward(const u64* polys, double* out, size_t count);
     void ntt_inverse(const double* in, u64* out, size_t count);
@@ -169,6 +205,11 @@ private:
     size_t ksm_cap_ = 0;
     int ksm_min_ = 128;
     void build_ksk_limbs();
+    // compression: byte limbs of the packing key, bootstrapping key image for the compression secret
+    CompShape comp_{};
+    int8_t* d_pack_limbs_ = nullptr;
+    double* d_decomp_bsk_ = nullptr;
+    void build_bsk_image(const u64* host_bsk, size_t ggsw_count, double* dst);
     MsParams ms_{};
     int cu_count_ = 256;
     int br_chunk_ = 0;      // ciphertexts per blind-rotation launch; 0: about four rounds of resident workgroups

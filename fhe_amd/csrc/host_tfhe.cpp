@@ -172,6 +172,29 @@ void gen_ksk(const EngineParams& p, const uint64_t* glwe_sk, const uint64_t* lwe
     });
 }
 
+void gen_packing_ksk(const CompShape& c, const uint64_t* glwe_sk, const uint64_t* comp_sk, const uint8_t seed[32],
+                     uint64_t* out, int threads) {
+    const size_t nc = (size_t)c.nc, words = (size_t)c.glwe_words();
+    parallel_for((size_t)N * c.ks_level, threads, [&](size_t row) {
+        ChaCha r(seed, 0x700000000ull + row);
+        uint64_t* g = out + row * words;
+        uint64_t* body = g + (size_t)c.kc * nc;
+        for (size_t j = 0; j < (size_t)c.kc * nc; ++j) g[j] = r.next();
+        for (size_t j = 0; j < nc; ++j) body[j] = r.tuniform(c.noise_log2);
+        for (int p = 0; p < c.kc; ++p) {        // body += a_p (*) S_p, negacyclic, S_p binary
+            const uint64_t* a = g + (size_t)p * nc;
+            const uint64_t* s = comp_sk + (size_t)p * nc;
+            for (size_t i = 0; i < nc; ++i) {
+                if (!s[i]) continue;
+                for (size_t j = 0; j < nc - i; ++j) body[j + i] += a[j];
+                for (size_t j = nc - i; j < nc; ++j) body[j + i - nc] -= a[j];
+            }
+        }
+        const size_t i = row / c.ks_level, lv = row % c.ks_level;
+        body[0] += glwe_sk[i] << (64 - c.ks_base_log * (lv + 1));
+    });
+}
+
 void gen_ms_zeros(const EngineParams& p, const uint64_t* lwe_sk, const uint8_t seed[32], uint64_t* zeros, int threads) {
     const size_t n1 = (size_t)p.lwe_dim + 1;
     parallel_for((size_t)p.ms_zeros_count, threads, [&](size_t i) {

@@ -44,6 +44,12 @@ void gen_bsk_qp(const EngineParams& p, const uint64_t* lwe_sk, const uint64_t* g
 void gen_ksk(const EngineParams& p, const uint64_t* glwe_sk, const uint64_t* lwe_sk, const uint8_t seed[32],
              uint64_t* ksk, int threads, uint64_t stream_base = 0x200000000ull);
 
+// packing key-switching key of the compression scheme: for every bit i of the big (GLWE-flattened)
+// key and level lv a GLWE encryption, under the compression secret comp_sk[kc][nc], of the constant
+// polynomial s_i * 2^(64 - base_log (lv + 1)); out[N][level][(kc + 1) nc] (mask polynomials, then body)
+void gen_packing_ksk(const CompShape& c, const uint64_t* glwe_sk, const uint64_t* comp_sk, const uint8_t seed[32],
+                     uint64_t* out, int threads);
+
 // encryptions of zero under the small key for the modulus-switch noise reduction:
 // zeros[ms_zeros_count][n+1]
 void gen_ms_zeros(const EngineParams& p, const uint64_t* lwe_sk, const uint8_t seed[32], uint64_t* zeros, int threads);

@@ -46,8 +46,10 @@ __global__ void __launch_bounds__(256) k_ksm_key_limbs(const u64* __restrict__ k
 }
 
 // ---- digits of a batch: D[ct][i * levels + lv] (signed), rows count..m_pad-1 zero
+// (`scale` multiplies every input word first: 1 for the key switch of the bootstrap)
 __global__ void __launch_bounds__(256) k_ksm_digits(const u64* __restrict__ in, int8_t* __restrict__ D, int count,
-                                                    int m_pad, int big, int base_log, int levels, BlockMap imap) {
+                                                    int m_pad, int big, int base_log, int levels, BlockMap imap,
+                                                    u64 scale) {
     const size_t total = (size_t)m_pad * big;
     const int rep = base_log * levels;
     const u64 mask = (1ull << base_log) - 1;
@@ -55,7 +57,7 @@ __global__ void __launch_bounds__(256) k_ksm_digits(const u64* __restrict__ in, 
         const int i = (int)(id % big), ct = (int)(id / big);
         int8_t d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (ct < count) {
-            const u64 x = in[imap.block(ct) * (size_t)(big + 1) + i];
+            const u64 x = in[imap.block(ct) * (size_t)(big + 1) + i] * scale;
             u64 state = (((x >> (64 - rep - 1)) + 1) >> 1) & ((1ull << rep) - 1);
             for (int lv = levels - 1; lv >= 0; --lv) {   // lv = 0 most significant
                 const u64 o = state & mask;
@@ -178,13 +180,91 @@ void launch_keyswitch_mfma(const int8_t* limbs, const u64* in, int8_t* dig, int*
     size_t dthreads = (size_t)M * big;
     unsigned dblocks = (unsigned)((dthreads + 255) / 256);
     if (dblocks > 16384) dblocks = 16384;
-    hipLaunchKernelGGL(k_ksm_digits, dim3(dblocks), dim3(256), 0, st, in, dig, (int)count, M, big, base_log, levels, imap);
+    hipLaunchKernelGGL(k_ksm_digits, dim3(dblocks), dim3(256), 0, st, in, dig, (int)count, M, big, base_log, levels, imap,
+                       (u64)1);
     hipLaunchKernelGGL(k_ksm_gemm, dim3(N / KSM_TILE, M / KSM_TILE), dim3(256), 0, st, dig, limbs, prod, K, N);
     const size_t total = count * (size_t)(n + 1);
     unsigned cblocks = (unsigned)((total + 255) / 256);
     if (cblocks > 16384) cblocks = 16384;
     hipLaunchKernelGGL(k_ksm_combine, dim3(cblocks), dim3(256), 0, st, prod, in, out, (int)count, big, n, N,
                        (int)ksm_cols_pad(n), imap);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ciphertext compression: packing key switch of up to `per` = N_c blocks into one GLWE ciphertext
+// of dimension k_c and polynomial size N_c, then modulus switch to 2^storage_log.
+//   G = sum_j X^j * ( (0, .., 0, s b_j) - sum_k d[j][k] * PKSK[k] ),   d = digits of s a_j,
+// s = `scale` (the message modulus: moves the message up into the carry bits, which the storage
+// modulus keeps).  The inner sums are the same int8 matrix product as the key switch above with the
+// (k_c + 1) N_c words of a GLWE ciphertext as columns; k_pack_combine rotates, adds and rounds.
+// Decompression: k_unpack_extract turns coefficient j of a stored GLWE into an LWE ciphertext of
+// dimension k_c N_c (scaled back to 2^64); a bootstrap under the decompression key does the rest.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pack_combine(const int* __restrict__ C, const u64* __restrict__ in,
+                                                      uint16_t* __restrict__ out, int count, int big, int kc, int nc,
+                                                      int N, int cols_pad, int storage_log, u64 scale, BlockMap imap) {
+    // one workgroup per (GLWE, polynomial p); thread = coefficient c
+    const int g = blockIdx.x, p = blockIdx.y, c = threadIdx.x;
+    if (c >= nc) return;
+    const int first = g * nc;
+    const int cnt = min(nc, count - first);
+    u64 acc = 0;
+    for (int j = 0; j < cnt; ++j) {
+        // coefficient c of X^j * P is P[c - j], negated when it wrapped
+        const int src = c - j;
+        const bool wrap = src < 0;
+        const int* row = C + (size_t)(first + j) * N + p * nc + (wrap ? src + nc : src);
+        u64 v = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) v += (u64)(i64)row[(size_t)b * cols_pad] << (8 * b);
+        acc += wrap ? v : (u64)0 - v;      // the key switch subtracts
+    }
+    if (p == kc && c < cnt) acc += in[imap.block(first + c) * (size_t)(big + 1) + big] * scale;
+    const u64 r = ((acc >> (64 - storage_log - 1)) + 1) >> 1;
+    out[((size_t)g * (kc + 1) + p) * nc + c] = (uint16_t)(r & ((1u << storage_log) - 1));
+}
+
+// small[ct][kc nc + 1]: sample extraction of coefficient ct % nc of GLWE ct / nc, words scaled to 2^64
+__global__ void __launch_bounds__(256) k_unpack_extract(const uint16_t* __restrict__ glwe, u64* __restrict__ small, int count,
+                                                        int kc, int nc, int storage_log) {
+    const int ct = blockIdx.x;
+    const int g = ct / nc, j = ct % nc;
+    const uint16_t* G = glwe + (size_t)g * (kc + 1) * nc;
+    u64* o = small + (size_t)ct * ((size_t)kc * nc + 1);
+    const int sh = 64 - storage_log;
+    for (int w = threadIdx.x; w < kc * nc; w += blockDim.x) {
+        const int p = w / nc, i = w % nc;
+        const int src = j - i;
+        const u64 v = (u64)G[p * nc + (src < 0 ? src + nc : src)] << sh;
+        o[w] = src < 0 ? (u64)0 - v : v;
+    }
+    if (threadIdx.x == 0) o[(size_t)kc * nc] = (u64)G[kc * nc + j] << sh;
+}
+
+void launch_pack(const int8_t* limbs, const u64* in, int8_t* dig, int* prod, uint16_t* out, size_t count, int big, int kc,
+                 int nc, int base_log, int levels, int storage_log, u64 scale, const BlockMap& imap, hipStream_t st) {
+    const int cols = (kc + 1) * nc;                    // a multiple of 16 for every supported shape
+    const int K = big * levels, N = 8 * cols, M = (int)ksm_rows_pad(count);
+    size_t dthreads = (size_t)M * big;
+    unsigned dblocks = (unsigned)((dthreads + 255) / 256);
+    if (dblocks > 16384) dblocks = 16384;
+    hipLaunchKernelGGL(k_ksm_digits, dim3(dblocks), dim3(256), 0, st, in, dig, (int)count, M, big, base_log, levels, imap,
+                       scale);
+    hipLaunchKernelGGL(k_ksm_gemm, dim3(N / KSM_TILE, M / KSM_TILE), dim3(256), 0, st, dig, limbs, prod, K, N);
+    const unsigned groups = (unsigned)((count + nc - 1) / nc);
+    hipLaunchKernelGGL(k_pack_combine, dim3(groups, kc + 1), dim3(256), 0, st, prod, in, out, (int)count, big, kc, nc, N,
+                       cols, storage_log, scale, imap);
+}
+
+void launch_pack_key_limbs(const u64* pksk, int8_t* limbs, int big, int levels, int kc, int nc, hipStream_t st) {
+    const int K = big * levels, cols = (kc + 1) * nc;
+    const size_t threads = (size_t)cols * (K / 16);
+    hipLaunchKernelGGL(k_ksm_key_limbs, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, pksk, limbs, K, cols, cols);
+}
+
+void launch_unpack_extract(const uint16_t* glwe, u64* small, size_t count, int kc, int nc, int storage_log, hipStream_t st) {
+    if (!count) return;
+    hipLaunchKernelGGL(k_unpack_extract, dim3((unsigned)count), dim3(256), 0, st, glwe, small, (int)count, kc, nc, storage_log);
 }
 
 }  // namespace lfhe

@@ -615,6 +615,207 @@ int32_t lfhe_cast_from_pke(lfhe_ctx* ctx, const uint8_t* ct, uint64_t ct_len, ui
     });
 }
 
+// ---- compression for storage ----------------------------------------------------------------------
+namespace {
+constexpr uint32_t CZ_MAGIC = 0x5a43464cu;  // "LFCZ"
+struct CzHeader {
+    uint32_t magic;
+    uint16_t version, storage_log;
+    uint32_t n_cts, total_blocks;
+    uint32_t kc, nc;
+};
+struct CzEntry { uint16_t bit_width, nblocks; };
+static_assert(sizeof(CzHeader) == 24 && sizeof(CzEntry) == 4, "blob layout");
+
+// stored words of GLWE g: the kc mask polynomials and the first `cnt` body coefficients
+size_t cz_group_bytes(const CompShape& c, size_t cnt) { return (((size_t)c.small_dim() + cnt) * c.storage_log + 7) / 8; }
+
+void pack_bits(const uint16_t* v, size_t n, int bits, uint8_t* out) {
+    uint64_t acc = 0;
+    int have = 0;
+    for (size_t i = 0; i < n; ++i) {
+        acc |= (uint64_t)v[i] << have;
+        have += bits;
+        while (have >= 8) { *out++ = (uint8_t)acc; acc >>= 8; have -= 8; }
+    }
+    if (have) *out = (uint8_t)acc;
+}
+void unpack_bits(const uint8_t* in, size_t n, int bits, uint16_t* v) {
+    uint64_t acc = 0;
+    int have = 0;
+    for (size_t i = 0; i < n; ++i) {
+        while (have < bits) { acc |= (uint64_t)*in++ << have; have += 8; }
+        v[i] = (uint16_t)(acc & ((1u << bits) - 1));
+        acc >>= bits;
+        have -= bits;
+    }
+}
+}  // namespace
+
+int32_t lfhe_compression_keygen(lfhe_ctx* ctx) {
+    return guarded(ctx, [&]() -> int32_t {
+        if (!ctx->have_client) throw std::logic_error("no client keys: the compression keys are made from them");
+        if (!ctx->eng->has_keys()) throw std::logic_error("server keys not loaded");
+        const CompShape c;
+        unsigned hc = std::thread::hardware_concurrency();
+        const int threads = (int)(hc ? (hc > 16 ? 16 : hc) : 4);
+        std::vector<uint64_t> comp_sk((size_t)c.small_dim());
+        ChaCha r(ctx->seed, 7);
+        gen_binary_key(r, comp_sk.data(), comp_sk.size());
+        std::vector<uint64_t> pksk(c.pksk_words());
+        gen_packing_ksk(c, ctx->glwe_sk.data(), comp_sk.data(), ctx->seed, pksk.data(), threads);
+        // bootstrapping key for the compression secret, of the context's own flavour, from its own
+        // generator streams (a seed of its own: the masks must not repeat the main key's)
+        EngineParams p = ctx->prm;
+        p.lwe_dim = (uint32_t)c.small_dim();
+        uint8_t seed2[32];
+        std::memcpy(seed2, ctx->seed, 32);
+        seed2[0] ^= 0xC5; seed2[31] ^= 0x5C;
+        std::vector<uint64_t> bsk(ctx->eng->ggsw_count_for(p.lwe_dim) * 4 * (size_t)N);
+        if (p.bsk_modulus) gen_bsk_qp(p, comp_sk.data(), ctx->glwe_sk.data(), seed2, bsk.data(), threads);
+        else gen_bsk(p, comp_sk.data(), ctx->glwe_sk.data(), seed2, bsk.data(), threads);
+        ctx->eng->load_compression_keys(c, pksk.data(), bsk.data());
+        return LFHE_OK;
+    });
+}
+
+int32_t lfhe_compression_keys_import_raw(lfhe_ctx* ctx, const uint64_t* packing_key, uint64_t packing_words,
+                                         const uint64_t* decompression_bsk, uint64_t bsk_words) {
+    return guarded(ctx, [&]() -> int32_t {
+        if (!packing_key || !decompression_bsk) throw std::invalid_argument("null key pointer");
+        const CompShape c;
+        if (packing_words != c.pksk_words() ||
+            bsk_words != ctx->eng->ggsw_count_for((uint32_t)c.small_dim()) * 4 * (uint64_t)N)
+            throw std::invalid_argument("compression key size does not match the parameter set");
+        if (ctx->prm.bsk_modulus)
+            for (uint64_t i = 0; i < bsk_words; ++i)
+                if (decompression_bsk[i] >= ctx->prm.bsk_modulus) throw std::invalid_argument("bootstrapping key word not reduced");
+        ctx->eng->load_compression_keys(c, packing_key, decompression_bsk);
+        return LFHE_OK;
+    });
+}
+
+int32_t lfhe_compress(lfhe_ctx* ctx, const uint8_t* cts, uint64_t cts_len, uint8_t* out, uint64_t* out_len) {
+    return guarded(ctx, [&]() -> int32_t {
+        if (!cts || !out_len) throw std::invalid_argument("null pointer");
+        Engine& E = *ctx->eng;
+        if (!E.has_compression_keys()) throw std::logic_error("no compression keys: call lfhe_compression_keygen");
+        const CompShape& c = E.comp_shape();
+        // walk the ciphertexts
+        std::vector<CzEntry> dir;
+        std::vector<const uint8_t*> starts;
+        size_t total = 0;
+        for (uint64_t off = 0; off < cts_len;) {
+            if (cts_len - off < sizeof(CtHeader)) throw std::invalid_argument("truncated ciphertext");
+            CtHeader h;
+            std::memcpy(&h, cts + off, sizeof h);
+            if (h.magic != CT_MAGIC || h.version != 1 || !width_ok(h.bit_width) || h.nblocks != blocks_of(h.bit_width) ||
+                cts_len - off < ct_bytes(h.bit_width))
+                throw std::invalid_argument("malformed ciphertext");
+            if (h.degree > 3 || h.noise_level < 1 || h.noise_level > 2) throw std::invalid_argument("ciphertext metadata out of range");
+            dir.push_back(CzEntry{h.bit_width, (uint16_t)h.nblocks});
+            starts.push_back(cts + off);
+            total += h.nblocks;
+            off += ct_bytes(h.bit_width);
+        }
+        if (dir.empty()) throw std::invalid_argument("nothing to compress");
+        const size_t groups = (total + c.nc - 1) / c.nc;
+        size_t need = sizeof(CzHeader) + dir.size() * sizeof(CzEntry);
+        for (size_t g = 0; g < groups; ++g) need += cz_group_bytes(c, std::min<size_t>(c.nc, total - g * c.nc));
+        if (!out) { *out_len = need; return LFHE_OK; }
+        if (*out_len < need) { *out_len = need; return LFHE_ERR_SIZE; }
+        HC(hipSetDevice(E.device()));
+        hipStream_t st = E.stream();
+        DevBuf<u64> din(total * BLK_WORDS);
+        size_t b0 = 0;
+        for (size_t i = 0; i < dir.size(); ++i) {
+            HC(hipMemcpyAsync(din.p + b0 * BLK_WORDS, starts[i] + sizeof(CtHeader), (size_t)dir[i].nblocks * BLK_BYTES,
+                              hipMemcpyHostToDevice, st));
+            b0 += dir[i].nblocks;
+        }
+        DevBuf<uint16_t> dg(groups * (size_t)c.glwe_words());
+        // the message moves up by the message modulus into the (clear) carry bits: the stored modulus keeps it
+        E.compress(din.p, total, dg.p, ctx->prm.message_modulus);
+        std::vector<uint16_t> hg(groups * (size_t)c.glwe_words());
+        HC(hipMemcpy(hg.data(), dg.p, hg.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
+        CzHeader zh{CZ_MAGIC, 1, (uint16_t)c.storage_log, (uint32_t)dir.size(), (uint32_t)total, (uint32_t)c.kc, (uint32_t)c.nc};
+        uint8_t* w = out;
+        std::memcpy(w, &zh, sizeof zh); w += sizeof zh;
+        std::memcpy(w, dir.data(), dir.size() * sizeof(CzEntry)); w += dir.size() * sizeof(CzEntry);
+        for (size_t g = 0; g < groups; ++g) {
+            const size_t cnt = std::min<size_t>(c.nc, total - g * c.nc);
+            pack_bits(hg.data() + g * c.glwe_words(), (size_t)c.small_dim() + cnt, c.storage_log, w);
+            w += cz_group_bytes(c, cnt);
+        }
+        *out_len = need;
+        return LFHE_OK;
+    });
+}
+
+int32_t lfhe_decompress(lfhe_ctx* ctx, const uint8_t* blob, uint64_t blob_len, uint8_t* out, uint64_t* out_len) {
+    return guarded(ctx, [&]() -> int32_t {
+        if (!blob || !out_len) throw std::invalid_argument("null pointer");
+        Engine& E = *ctx->eng;
+        if (!E.has_compression_keys()) throw std::logic_error("no compression keys: call lfhe_compression_keygen");
+        const CompShape& c = E.comp_shape();
+        CzHeader zh;
+        if (blob_len < sizeof zh) throw std::invalid_argument("blob too short");
+        std::memcpy(&zh, blob, sizeof zh);
+        if (zh.magic != CZ_MAGIC || zh.version != 1 || zh.storage_log != (uint32_t)c.storage_log || zh.kc != (uint32_t)c.kc ||
+            zh.nc != (uint32_t)c.nc || zh.n_cts == 0 || zh.n_cts > (1u << 24) ||
+            blob_len < sizeof zh + (uint64_t)zh.n_cts * sizeof(CzEntry))
+            throw std::invalid_argument("malformed compressed list");
+        std::vector<CzEntry> dir(zh.n_cts);
+        std::memcpy(dir.data(), blob + sizeof zh, dir.size() * sizeof(CzEntry));
+        size_t total = 0;
+        uint64_t need = 0;
+        for (const CzEntry& e : dir) {
+            if (!width_ok(e.bit_width) || e.nblocks != blocks_of(e.bit_width)) throw std::invalid_argument("malformed compressed list");
+            total += e.nblocks;
+            need += ct_bytes(e.bit_width);
+        }
+        if (total != zh.total_blocks) throw std::invalid_argument("malformed compressed list");
+        const size_t groups = (total + c.nc - 1) / c.nc;
+        uint64_t packed = 0;
+        for (size_t g = 0; g < groups; ++g) packed += cz_group_bytes(c, std::min<size_t>(c.nc, total - g * c.nc));
+        if (blob_len != sizeof zh + dir.size() * sizeof(CzEntry) + packed) throw std::invalid_argument("malformed compressed list");
+        if (!out) { *out_len = need; return LFHE_OK; }
+        if (*out_len < need) { *out_len = need; return LFHE_ERR_SIZE; }
+        std::vector<uint16_t> hg(groups * (size_t)c.glwe_words(), 0);
+        const uint8_t* r = blob + sizeof zh + dir.size() * sizeof(CzEntry);
+        for (size_t g = 0; g < groups; ++g) {
+            const size_t cnt = std::min<size_t>(c.nc, total - g * c.nc);
+            unpack_bits(r, (size_t)c.small_dim() + cnt, c.storage_log, hg.data() + g * c.glwe_words());
+            r += cz_group_bytes(c, cnt);
+        }
+        HC(hipSetDevice(E.device()));
+        hipStream_t st = E.stream();
+        DevBuf<uint16_t> dg(hg.size());
+        HC(hipMemcpyAsync(dg.p, hg.data(), hg.size() * sizeof(uint16_t), hipMemcpyHostToDevice, st));
+        // the table undoes the shift: value 4 m (+ up to two boxes of noise either way) -> m
+        std::vector<u64> lut(N);
+        uint64_t tab[16];
+        const uint32_t mm = ctx->prm.message_modulus;
+        for (uint32_t x = 0; x < 16; ++x) tab[x] = ((x + mm / 2) / mm) % mm;
+        make_lut_body(ctx->space(), ctx->delta(), tab, lut.data());
+        DevBuf<u64> dl(N), dout(total * BLK_WORDS);
+        HC(hipMemcpyAsync(dl.p, lut.data(), (size_t)N * 8, hipMemcpyHostToDevice, st));
+        E.decompress(dg.p, total, dl.p, dout.p);
+        ctx->pbs_count += total;
+        uint8_t* w = out;
+        size_t b0 = 0;
+        for (const CzEntry& e : dir) {
+            CtHeader h{CT_MAGIC, 1, e.bit_width, e.nblocks, 1, (uint8_t)(e.bit_width == 1 ? 1 : 3), 0};
+            std::memcpy(w, &h, sizeof h);
+            HC(hipMemcpy(w + sizeof h, dout.p + b0 * BLK_WORDS, (size_t)e.nblocks * BLK_BYTES, hipMemcpyDeviceToHost));
+            w += ct_bytes(e.bit_width);
+            b0 += e.nblocks;
+        }
+        *out_len = need;
+        return LFHE_OK;
+    });
+}
+
 int32_t lfhe_op_from_name(const char* name) {
     if (!name) return -1;
     static const struct { const char* n; int op; } tab[] = {

@@ -97,6 +97,10 @@ def load():
         "lfhe_server_keys_import_raw": (i32, [vp, vp, u64, vp, u64, vp, u64]),
         "lfhe_client_keys_import_raw": (i32, [vp, vp, vp]),
         "lfhe_public_key": (i32, [vp, vp, pu64]),
+        "lfhe_compression_keygen": (i32, [vp]),
+        "lfhe_compression_keys_import_raw": (i32, [vp, vp, u64, vp, u64]),
+        "lfhe_compress": (i32, [vp, vp, u64, vp, pu64]),
+        "lfhe_decompress": (i32, [vp, vp, u64, vp, pu64]),
         "lfhe_device_keys_size": (i32, [vp, pu64, pu64]),
         "lfhe_device_keys_ptr": (i32, [vp, C.POINTER(vp), C.POINTER(vp)]),
         "lfhe_device_keys_attach": (i32, [vp, vp, vp]),
@@ -400,6 +404,38 @@ class Context:
         for a, sz in zip(outs, sizes):
             view = memoryview(a)
             res.append([bytes(view[i * sz:(i + 1) * sz]) for i in range(n)])
+        return res
+
+    # ---- compression for storage
+    def compression_keygen(self):
+        self._ck(self._L.lfhe_compression_keygen(self._h))
+
+    def import_compression_keys_raw(self, packing_key: np.ndarray, decompression_bsk: np.ndarray):
+        a, b = _u64(packing_key).reshape(-1), _u64(decompression_bsk).reshape(-1)
+        self._ck(self._L.lfhe_compression_keys_import_raw(self._h, _ptr(a), a.size, _ptr(b), b.size))
+
+    def compress(self, cts: list) -> bytes:
+        """Ciphertexts (any widths) -> one compressed list."""
+        src = np.frombuffer(b"".join(cts), dtype=np.uint8)
+        n = C.c_uint64(0)
+        self._ck(self._L.lfhe_compress(self._h, _ptr(src), src.size, None, C.byref(n)))
+        out = np.empty(n.value, dtype=np.uint8)
+        self._ck(self._L.lfhe_compress(self._h, _ptr(src), src.size, _ptr(out), C.byref(n)))
+        return out[:n.value].tobytes()
+
+    def decompress(self, blob: bytes) -> list:
+        """A compressed list -> its ciphertexts, one bootstrap per block."""
+        src = np.frombuffer(blob, dtype=np.uint8)
+        n = C.c_uint64(0)
+        self._ck(self._L.lfhe_decompress(self._h, _ptr(src), src.size, None, C.byref(n)))
+        out = np.empty(n.value, dtype=np.uint8)
+        self._ck(self._L.lfhe_decompress(self._h, _ptr(src), src.size, _ptr(out), C.byref(n)))
+        raw, res, off = memoryview(out), [], 0
+        while off < n.value:
+            width = int.from_bytes(raw[off + 6:off + 8], "little")
+            size = self.ciphertext_size(width)
+            res.append(bytes(raw[off:off + size]))
+            off += size
         return res
 
     def pbs_count(self) -> int:

@@ -150,6 +150,30 @@ int32_t lfhe_pke_key_set(lfhe_ctx* ctx, const uint64_t* pke_sk);
 int32_t lfhe_cast_from_pke(lfhe_ctx* ctx, const uint8_t* ct, uint64_t ct_len, uint8_t* out, uint64_t* out_len);
 int32_t lfhe_ciphertext_size(const lfhe_ctx* ctx, uint32_t bit_width, uint64_t* out_len);
 
+/* ---- compression for storage --------------------------------------------------------------------
+ * Replaces: CompressionKey / cpu_compress_ciphertexts_into_list / cuda_compress_ciphertexts_into_
+ * single_glwe and CompressedModulusSwitched...::extract of the reference's extension
+ * (ml/extensions/rust/src/compression.rs:132-291), in the form tfhe-rs gives it for radix
+ * ciphertexts (CompressedCiphertextList): up to 256 blocks are packed by a key switch into one GLWE
+ * ciphertext of dimension 4 x 256 and stored modulo 2^12 (1.5 bytes per coefficient instead of
+ * 16 392 bytes per block); decompression extracts each block and bootstraps it under a key for the
+ * compression secret.  Shape and noise: tfhe-rs COMP_PARAM_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128
+ * (packing base 2^4 x 3 levels, TUniform(43)).
+ * lfhe_compression_keygen: makes the compression secret, the packing key and the decompression
+ * bootstrapping key from the context's client keys and loads them (server keys must be loaded).
+ * lfhe_compress: `cts` = n ciphertexts back to back (any widths; carries must be clear, which every
+ * ciphertext this library returns satisfies); writes the blob, or its size when out is NULL.
+ * lfhe_decompress: the blob -> the same ciphertexts back to back, one bootstrap per block.
+ * lfhe_compression_keys_import_raw: the same two keys made elsewhere -- packing key
+ * [2048][3][5 * 256] words (mask polynomials, then body, of the GLWE encryption of
+ * s_i 2^(64 - 4 (lv + 1))), bootstrapping key for the 1024 bits of the compression secret in the
+ * layout and modulus of the context's bootstrapping key. */
+int32_t lfhe_compression_keygen(lfhe_ctx* ctx);
+int32_t lfhe_compression_keys_import_raw(lfhe_ctx* ctx, const uint64_t* packing_key, uint64_t packing_words,
+                                         const uint64_t* decompression_bsk, uint64_t bsk_words);
+int32_t lfhe_compress(lfhe_ctx* ctx, const uint8_t* cts, uint64_t cts_len, uint8_t* out, uint64_t* out_len);
+int32_t lfhe_decompress(lfhe_ctx* ctx, const uint8_t* blob, uint64_t blob_len, uint8_t* out, uint64_t* out_len);
+
 /* ---- operators ----------------------------------------------------------------------------------
  * Replaces: POST /evaluate {op,left,right,bitWidth} (e2e/test/fhe.test.ts:105-175,
  * local-dev/demo.ts:57-81) and the executor events FheAdd ... FheIfThenElse
