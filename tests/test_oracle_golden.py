@@ -273,3 +273,29 @@ def test_grouped_key_blind_rotation_over_prime_modulus(n):
     # all-zero mask: no step runs, the accumulator is the table itself, rotated by the body
     small = np.zeros(n + 1, dtype=np.uint64)
     assert np.array_equal(orc.blind_rotate_qp(pb, small, lut), orc.blind_rotate_qp(pb1, small, lut))
+
+
+def test_compression_oracle_round_trip():
+    """Packing key switch + storage modulus + extraction keep the (shifted) message: the phase of
+    every extracted block under the compression secret is 4 m delta up to a fraction of a box, and
+    the decompression bootstrap returns m under the compute key."""
+    from oracle import compress as OC
+    orc = Oracle()
+    lwe_sk, glwe_sk, _, _ = orc.gen_keys(seed_bytes(50))
+    comp_sk = OC.gen_comp_sk(Rng(seed_bytes(51), 1))
+    pksk = OC.gen_packing_ksk(glwe_sk, comp_sk, Rng(seed_bytes(51), 2))
+    r = Rng(seed_bytes(52))
+    msgs = [i % 4 for i in range(9)]
+    blocks = np.stack([orc.encrypt_block(glwe_sk, m, r) for m in msgs])
+    glwe = OC.pack(blocks, pksk, 4)
+    assert glwe.shape == (1, 5 * 256) and int(glwe.max()) < 1 << 12
+    small = OC.extract(glwe, len(msgs))
+    for m, s in zip(msgs, small):
+        phase = (int(s[-1]) - int((s[:-1] * comp_sk).sum(dtype=np.uint64))) % (1 << 64)
+        err = (phase - 4 * m * orc.p.delta) % (1 << 64)
+        assert min(err, (1 << 64) - err) < 1 << 57              # a quarter of a box; the table tolerates two boxes
+    packed = OC.pack_bits(glwe[0][:1024 + len(msgs)], 12)
+    assert len(packed) == ((1024 + len(msgs)) * 12 + 7) // 8
+    dec = OC.Decompressor("prime", comp_sk, glwe_sk, seed_bytes(53))
+    out = dec.bootstrap(small[3], dec.table())
+    assert orc.decrypt_block(glwe_sk, out) == msgs[3]
