@@ -29,6 +29,25 @@ namespace lfhe {
 extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
 static constexpr size_t LDS_BYTES = (size_t)LDS_WORDS * sizeof(double);
 
+// The separation a hand-over between two phases needs (pbs_phases.h: sync_after).  Inside one
+// wavefront LDS operations execute in program order, so a hand-over private to a wave only has to
+// keep the compiler from moving the loads above the stores.
+#ifdef LFHE_ABLATE_NO_BARRIER   // timing experiment only: results are wrong
+template <Sync K> __device__ __forceinline__ void phase_sync() {}
+#else
+template <Sync K>
+__device__ __forceinline__ void phase_sync() {
+    if constexpr (K == Sync::Block) {
+        __syncthreads();
+    } else if constexpr (K == Sync::Wave) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+#endif
+__device__ __forceinline__ void wave_sync() { phase_sync<Sync::Wave>(); }
+
 template <int... PH>
 __device__ __forceinline__ void ep_run_seq(EpState& s, double* lds, unsigned t, const Tables& T,
                                            const double* __restrict__ bsk_i,
@@ -152,12 +171,8 @@ template <int... PH>
 __device__ __forceinline__ void ep_run_assign(EpState& s, double* lds, unsigned t, const Tables& T,
                                               const double* __restrict__ bsk_i,
                                               std::integer_sequence<int, PH...>) {
-    // barrier between phases, none after the last: the caller publishes its result first
-#ifdef LFHE_ABLATE_NO_BARRIER   // timing experiment only: results are wrong
-    ((ep_phase<PH, false>(s, lds, t, T, bsk_i)), ...);
-#else
-    ((ep_phase<PH, false>(s, lds, t, T, bsk_i), (PH + 1 < EP_PHASES ? __syncthreads() : (void)0)), ...);
-#endif
+    // nothing after the last phase: the caller publishes its result first
+    ((ep_phase<PH, false>(s, lds, t, T, bsk_i), phase_sync<(PH + 1 < EP_PHASES ? sync_after(PH) : Sync::None)>()), ...);
 }
 
 __global__ void __launch_bounds__(NT, LFHE_BR_WAVES) k_blind_rotate(Tables T, const double* __restrict__ bsk,
@@ -186,8 +201,8 @@ __global__ void __launch_bounds__(NT, LFHE_BR_WAVES) k_blind_rotate(Tables T, co
             const u64 v = lut[rot_index(e, a, neg)];
             acc[0][j] = 0;
             acc[1][j] = neg ? (u64)0 - v : v;
-            acc_lds[0][e] = acc[0][j];
-            acc_lds[1][e] = acc[1][j];
+            acc_lds[0][pad12(e)] = acc[0][j];
+            acc_lds[1][pad12(e)] = acc[1][j];
         }
     }
     __syncthreads();
@@ -203,7 +218,7 @@ __global__ void __launch_bounds__(NT, LFHE_BR_WAVES) k_blind_rotate(Tables T, co
 #pragma unroll
             for (int j = 0; j < E; ++j) {
                 bool neg;
-                const u64 r = acc_lds[q][rot_index(own1(tt, j), a, neg)];
+                const u64 r = acc_lds[q][pad12(rot_index(own1(tt, j), a, neg))];
                 s.dig[q][j] = decomp23((neg ? (u64)0 - r : r) - acc[q][j]);
             }
         __syncthreads();  // every rotated read is done before the first phase overwrites the buffer
@@ -214,7 +229,7 @@ __global__ void __launch_bounds__(NT, LFHE_BR_WAVES) k_blind_rotate(Tables T, co
 #pragma unroll
             for (int j = 0; j < E; ++j) {
                 acc[q][j] += s.out[q][j];
-                acc_lds[q][own1(tt, j)] = acc[q][j];
+                acc_lds[q][pad12(own1(tt, j))] = acc[q][j];
             }
         __syncthreads();  // the new accumulator is visible to the whole workgroup before the next step
     }
@@ -273,18 +288,15 @@ __global__ void __launch_bounds__(NT) k_bskq_prepare(Tables T, const u64* __rest
 template <int... PH>
 __device__ __forceinline__ void epq_run(EpState& s, double* lds, unsigned t, const Tables& T,
                                         const double* __restrict__ bsk_i, std::integer_sequence<int, PH...>) {
-#ifdef LFHE_ABLATE_NO_BARRIER   // timing experiment only: results are wrong
-    ((ep_phase<PH, false, true>(s, lds, t, T, bsk_i)), ...);
-#else
-    ((ep_phase<PH, false, true>(s, lds, t, T, bsk_i), (PH + 1 < EPQ_PHASES ? __syncthreads() : (void)0)), ...);
-#endif
+    ((ep_phase<PH, false, true>(s, lds, t, T, bsk_i), phase_sync<(PH + 1 < EPQ_PHASES ? sync_after(PH) : Sync::None)>()), ...);
 }
 
 // phases 1..11 (the kernel runs phase 0 itself)
 template <int... PH>
 __device__ __forceinline__ void epq_run_from1(EpState& s, double* lds, unsigned t, const Tables& T,
                                               const double* __restrict__ bsk_i, std::integer_sequence<int, PH...>) {
-    ((ep_phase<PH + 1, false, true>(s, lds, t, T, bsk_i), (PH + 2 < EPQ_PHASES ? __syncthreads() : (void)0)), ...);
+    // workgroup barriers throughout: measured faster than wave-level fences at full occupancy (see LFHE_G2_BLOCK_MASK)
+    ((ep_phase<PH + 1, false, true>(s, lds, t, T, bsk_i), phase_sync<(PH + 2 < EPQ_PHASES ? Sync::Block : Sync::None)>()), ...);
 }
 
 // centred residue of an exact integer |x| < 3 q' (the quotient estimate is exact in this range)
@@ -345,8 +357,8 @@ __global__ void __launch_bounds__(NT, LFHE_BRQ_WAVES) k_blind_rotate_q(Tables T,
             const double v = torus_to_qp(lut[rot_index(e, a, neg)]);
             acc[0][j] = 0.0;
             acc[1][j] = neg ? -v : v;
-            acc_lds[0][e] = acc[0][j];
-            acc_lds[1][e] = acc[1][j];
+            acc_lds[0][pad12(e)] = acc[0][j];
+            acc_lds[1][pad12(e)] = acc[1][j];
         }
     }
     __syncthreads();
@@ -362,7 +374,7 @@ __global__ void __launch_bounds__(NT, LFHE_BRQ_WAVES) k_blind_rotate_q(Tables T,
 #pragma unroll
             for (int j = 0; j < E; ++j) {
                 bool neg;
-                const double r = acc_lds[q][rot_index(own1(tt, j), a, neg)];
+                const double r = acc_lds[q][pad12(rot_index(own1(tt, j), a, neg))];
                 const double d = (neg ? -r : r) - acc[q][j];
                 s.x[q][j] = __builtin_rint(qp_canon(d, P) * inv_g);
             }
@@ -381,7 +393,7 @@ __global__ void __launch_bounds__(NT, LFHE_BRQ_WAVES) k_blind_rotate_q(Tables T,
 #pragma unroll
             for (int j = 0; j < E; ++j) {
                 acc[q][j] = qp_canon(acc[q][j] + s.x[q][j], P);
-                acc_lds[q][own1(tt, j)] = acc[q][j];
+                acc_lds[q][pad12(own1(tt, j))] = acc[q][j];
             }
         __syncthreads();  // the new accumulator is visible to the whole workgroup before the next step
     }
@@ -403,6 +415,42 @@ __global__ void __launch_bounds__(NT, LFHE_BRQ_WAVES) k_blind_rotate_q(Tables T,
             else o[N - e] = qp_to_torus(-acc[0][j]);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS image of the 512-thread kernels.  One such workgroup owns a CU, so besides the two exchange
+// buffers it keeps the twiddle tables of passes 2-4 (and the monomial table of the grouped key) in
+// LDS.  Vector memory loads return in order: with the tables in LDS the key words are the only
+// vector loads of a step, so the NEXT step's key words can be requested as soon as the point-wise
+// stage has consumed this step's (a whole step of latency cover, in the same registers) without
+// any twiddle load queueing behind them.
+// ------------------------------------------------------------------------------------------------
+constexpr int WIDE_TWF = LDS_WORDS;                 // word offsets
+constexpr int WIDE_TWI = WIDE_TWF + N;
+constexpr int WIDE_MONO = WIDE_TWI + N;
+static constexpr size_t WIDE_LDS_BYTES = (size_t)(WIDE_MONO) * sizeof(double);
+static constexpr size_t WIDE2_LDS_BYTES = (size_t)(WIDE_MONO + MONO_WORDS + 8) * sizeof(double);
+
+__device__ __forceinline__ void wide_fill_tables(const Tables& T, bool mono) {
+    for (unsigned i = threadIdx.x; i < (unsigned)N; i += 2 * NT) {
+        lds_dyn[WIDE_TWF + i] = T.tw_fwd[0][i];
+        lds_dyn[WIDE_TWI + i] = T.tw_inv[0][i];
+    }
+    if (mono)
+        for (unsigned i = threadIdx.x; i < (unsigned)MONO_WORDS + 8; i += 2 * NT) lds_dyn[WIDE_MONO + i] = T.mono[i];
+}
+
+// The seven twiddles of pass 1 are the same for every thread and every step: held in scalar
+// registers for the whole kernel instead of being loaded (and waited for) in every step.
+__device__ __forceinline__ double uniform_f64(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void load_tw8_uniform(const double* __restrict__ tw, double (&w)[7]) {
+    load_tw8(tw, 1, w);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) w[k] = uniform_f64(w[k]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -428,10 +476,13 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q_wide(Tables T, con
     const u64* __restrict__ lut = luts + (size_t)(lut_index ? lut_index[omap.ops ? ct % omap.ops : ct] : 0) * N;
     double* mine = lds_dyn + h * POLY_STRIDE;
     double* theirs = lds_dyn + (1 - h) * POLY_STRIDE;
-    const double* __restrict__ twf = T.tw_fwd[0];
-    const double* __restrict__ twi = T.tw_inv[0];
+    const double* __restrict__ twf = lds_dyn + WIDE_TWF;   // passes 2-4; pass 1's live in scalar registers
+    const double* __restrict__ twi = lds_dyn + WIDE_TWI;
+    wide_fill_tables(T, false);
 
-    double acc[E], x[E], w[7];
+    double acc[E], x[E], w[7], w1f[7], w1i[7];
+    load_tw8_uniform(T.tw_fwd[0], w1f);
+    load_tw8_uniform(T.tw_inv[0], w1i);
     {
         const unsigned bt = modswitch_2n(lwe[n]);
         const unsigned a = (2 * N - bt) & (2 * N - 1);  // multiply by X^-b~
@@ -441,46 +492,53 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q_wide(Tables T, con
             bool neg;
             const double v = torus_to_qp(lut[rot_index(e, a, neg)]);
             acc[j] = h ? (neg ? -v : v) : 0.0;
-            mine[e] = acc[j];
+            mine[pad12(e)] = acc[j];
         }
     }
     __syncthreads();
 
-    for (int i = 0; i < n; ++i) {
+    // Key row of a step: kx multiplies this half's own digits, ky the other half's.  The row of step
+    // i + 1 is requested right after the point-wise stage of step i has used up the registers.
+    double kx[E], ky[E];
+    auto load_key = [&](int i, unsigned t) {
+        const double* __restrict__ row = bsk + (size_t)i * BSKQ_ROW;
+#pragma unroll
+        for (unsigned c4 = 0; c4 < 4; ++c4) {
+            const unsigned o0 = bsk_off(0, 3 * h, c4, t), o1 = bsk_off(0, 2 - h, c4, t);
+#pragma unroll
+            for (unsigned k = 0; k < 2; ++k) { kx[2 * c4 + k] = ldt(row, o0 + k); ky[2 * c4 + k] = ldt(row, o1 + k); }
+        }
+    };
+    // first step at or after i that is not the identity (X^0 - 1 = 0: such a CMux adds exactly zero)
+    auto next_step = [&](int i) {
+        while (i < n && modswitch_2n(lwe[i]) == 0) ++i;
+        return i;
+    };
+    int i = next_step(0);
+    if (i < n) load_key(i, t0);
+
+    while (i < n) {
         const unsigned a = modswitch_2n(lwe[i]);
-        if (a == 0) continue;
         unsigned t = t0;
         asm volatile("" : "+v"(t));  // addresses are recomputed per step instead of living in registers
-        // this step's key row goes into registers now: with few workgroups in flight nobody else has
-        // pulled it into L2 yet, and the point-wise stage is half a step away
-        double kx[E], ky[E];
-        {
-            const double* __restrict__ row = bsk + (size_t)i * BSKQ_ROW;
-#pragma unroll
-            for (unsigned c4 = 0; c4 < 4; ++c4) {
-                const unsigned o0 = bsk_off(0, 3 * h, c4, t), o1 = bsk_off(0, 2 - h, c4, t);
-#pragma unroll
-                for (unsigned k = 0; k < 2; ++k) { kx[2 * c4 + k] = ldt(row, o0 + k); ky[2 * c4 + k] = ldt(row, o1 + k); }
-            }
-        }
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             bool neg;
-            const double r = mine[rot_index(own1(t, j), a, neg)];
+            const double r = mine[pad12(rot_index(own1(t, j), a, neg))];
             x[j] = __builtin_rint(qp_canon((neg ? -r : r) - acc[j], P) * inv_g);
         }
-        ct_radix8(x, twf, 1, P);
+        ct_radix8(x, w1f, P);
         __syncthreads();                      // rotated reads done before the buffer is reused
         st_o1p12(mine, t, x); load_tw8(twf, base2(t), w);
         __syncthreads();
         ld_o2p12(mine, t, x); ct_radix8(x, w, P);
-        __syncthreads();
+        wave_sync();
         st_o2p23(mine, t, x); load_tw8(twf, base3(t), w);
-        __syncthreads();
+        wave_sync();
         ld_o3p23(mine, t, x); ct_radix8(x, w, P);
-        __syncthreads();
+        wave_sync();
         st_o3p34(mine, t, x); load_tw4x2(twf, t, w);
-        __syncthreads();
+        wave_sync();
         ld_o4p34(mine, t, x); ct_radix4x2(x, w, P);
         // publish the transformed digits (a thread rewrites the words it has just read) and fetch
         // the other polynomial's
@@ -496,25 +554,32 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q_wide(Tables T, con
 #pragma unroll
             for (int j = 0; j < E; ++j) x[j] = o[j];
         }
+        // the next step's loads must stay below the last use of this step's words (same registers):
+        // their addresses are made to depend on the point-wise results
+        unsigned tk = t;
+        asm volatile("" : "+v"(tk) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
+        const int inext = next_step(i + 1);
+        if (inext < n) load_key(inext, tk);
         gs_radix4x2<GS_NORM_PASS4[0], GS_NORM_PASS4[1]>(x, w, P);
         __syncthreads();                      // the other half has read this buffer
         st_o4p34(mine, t, x); load_tw8(twi, base3(t), w);
-        __syncthreads();
+        wave_sync();
         ld_o3p34(mine, t, x); gs_radix8<GS_NORM_PASS3[0], GS_NORM_PASS3[1], GS_NORM_PASS3[2]>(x, w, P);
-        __syncthreads();
+        wave_sync();
         st_o3p23(mine, t, x); load_tw8(twi, base2(t), w);
-        __syncthreads();
+        wave_sync();
         ld_o2p23(mine, t, x); gs_radix8<GS_NORM_PASS2[0], GS_NORM_PASS2[1], GS_NORM_PASS2[2]>(x, w, P);
-        __syncthreads();
+        wave_sync();
         st_o2p12(mine, t, x);
         __syncthreads();
-        ld_o1p12(mine, t, x); gs_radix8<GS_NORM_PASS1[0], GS_NORM_PASS1[1], GS_NORM_PASS1[2]>(x, twi, 1, P);
+        ld_o1p12(mine, t, x); gs_radix8<GS_NORM_PASS1[0], GS_NORM_PASS1[1], GS_NORM_PASS1[2]>(x, w1i, P);
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             acc[j] = qp_canon(acc[j] + x[j], P);
-            mine[own1(t, j)] = acc[j];
+            mine[pad12(own1(t, j))] = acc[j];
         }
         __syncthreads();
+        i = inext;
     }
 
     if (glwe_out) {
@@ -541,15 +606,20 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q_wide(Tables T, con
 // step's GGSW point by point from three key rows and the monomial factors, multiplies, transforms
 // back and REPLACES the accumulator -- no rotated reads, hence no accumulator copy in LDS.  (n + 1) / 2 steps of one external product each.
 // ------------------------------------------------------------------------------------------------
-#ifdef LFHE_ABLATE_NO_BARRIER   // timing experiment only: results are wrong
-#define LFHE_G2_SYNC() ((void)0)
-#else
-#define LFHE_G2_SYNC() __syncthreads()
+#define LFHE_G2_SYNC() phase_sync<Sync::Block>()
+#ifndef LFHE_G2_BLOCK_MASK
+// bit PH: workgroup barrier after phase PH even where the data flow does not need one.  With four
+// workgroups per CU the kernel is FASTER with all of them (4096 ciphertexts: 48.0 ms against 49.8 ms
+// with wave-level fences, 49.3 ms with only the barrier before the point-wise stage kept): waves
+// that stay in lock step walk the key rows together.  The 512-thread kernels, one workgroup per
+// CU, gain from dropping them.
+#define LFHE_G2_BLOCK_MASK 0x3FEu
 #endif
+constexpr Sync g2_sync_after(int PH) { return ((LFHE_G2_BLOCK_MASK >> PH) & 1u) ? Sync::Block : sync_after(PH); }
 template <int... PH>
 __device__ __forceinline__ void epq_run_range(EpState& s, double* lds, unsigned t, const Tables& T,
                                               std::integer_sequence<int, PH...>) {
-    ((ep_phase<PH, false, true>(s, lds, t, T, nullptr), LFHE_G2_SYNC()), ...);
+    ((ep_phase<PH, false, true>(s, lds, t, T, nullptr), phase_sync<g2_sync_after(PH)>()), ...);
 }
 template <int FIRST, int... K>
 constexpr auto phase_range(std::integer_sequence<int, K...>) { return std::integer_sequence<int, (FIRST + K)...>{}; }
@@ -600,7 +670,7 @@ __global__ void __launch_bounds__(NT, 4) k_blind_rotate_q2(Tables T, const doubl
         LFHE_G2_SYNC();
         epq_run_range(s, lds_dyn, t, T, phase_range<1>(std::make_integer_sequence<int, 4>{}));
         ep_group2_phase5(s, lds_dyn, t, T, bsk + (size_t)4 * g * BSKQ_ROW, a0, a1);
-        LFHE_G2_SYNC();
+        phase_sync<g2_sync_after(5)>();   // the next phase rewrites the words this thread has just read
         epq_run_range(s, lds_dyn, t, T, phase_range<6>(std::make_integer_sequence<int, 5>{}));
         ep_phase<11, false, true>(s, lds_dyn, t, T, nullptr);
 #pragma unroll
@@ -647,10 +717,14 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q2_wide(Tables T, co
     const u64* __restrict__ lut = luts + (size_t)(lut_index ? lut_index[omap.ops ? ct % omap.ops : ct] : 0) * N;
     double* mine = lds_dyn + h * POLY_STRIDE;
     double* theirs = lds_dyn + (1 - h) * POLY_STRIDE;
-    const double* __restrict__ twf = T.tw_fwd[0];
-    const double* __restrict__ twi = T.tw_inv[0];
+    const double* __restrict__ twf = lds_dyn + WIDE_TWF;   // passes 2-4; pass 1's live in scalar registers
+    const double* __restrict__ twi = lds_dyn + WIDE_TWI;
+    const double* __restrict__ mono = lds_dyn + WIDE_MONO;
+    wide_fill_tables(T, true);
 
-    double acc[E], x[E], w[7];
+    double acc[E], x[E], w[7], w1f[7], w1i[7];
+    load_tw8_uniform(T.tw_fwd[0], w1f);
+    load_tw8_uniform(T.tw_inv[0], w1i);
     {
         const unsigned bt = modswitch_2n(lwe[n]);
         const unsigned a = (2 * N - bt) & (2 * N - 1);  // multiply by X^-b~
@@ -664,40 +738,48 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q2_wide(Tables T, co
     __syncthreads();
 
     const int groups = (n + 1) / 2;
-    for (int g = 0; g < groups; ++g) {
+    // Key words of a step (four rows): kx multiplies this half's own digits, ky the other half's;
+    // polynomial index q = j_in * 2 + c_out.  The rows of step g + 1 are requested right after the
+    // point-wise stage of step g has used up the registers.
+    double kx[4][E], ky[4][E];
+    auto load_key = [&](int g, unsigned t) {
+        const double* __restrict__ rows = bsk + (size_t)4 * g * BSKQ_ROW;
+#pragma unroll
+        for (unsigned m = 0; m < 4; ++m)
+#pragma unroll
+            for (unsigned c4 = 0; c4 < 4; ++c4) {
+                const unsigned o0 = m * (unsigned)BSKQ_ROW + bsk_off(0, 3 * h, c4, t);
+                const unsigned o1 = m * (unsigned)BSKQ_ROW + bsk_off(0, 2 - h, c4, t);
+#pragma unroll
+                for (unsigned k = 0; k < 2; ++k) { kx[m][2 * c4 + k] = ldt(rows, o0 + k); ky[m][2 * c4 + k] = ldt(rows, o1 + k); }
+            }
+    };
+    // first step at or after g whose GGSW is not the identity (both exponents zero: skipped)
+    auto next_step = [&](int g) {
+        while (g < groups && (modswitch_2n(lwe[2 * g]) | (2 * g + 1 < n ? modswitch_2n(lwe[2 * g + 1]) : 0u)) == 0) ++g;
+        return g;
+    };
+    int g = next_step(0);
+    if (g < groups) load_key(g, t0);
+
+    while (g < groups) {
         const unsigned a0 = modswitch_2n(lwe[2 * g]);
         const unsigned a1 = 2 * g + 1 < n ? modswitch_2n(lwe[2 * g + 1]) : 0u;
-        if ((a0 | a1) == 0) continue;
         unsigned t = t0;
         asm volatile("" : "+v"(t));  // addresses are recomputed per step instead of living in registers
-        // this step's key words go into registers now (the point-wise stage is half a step away):
-        // kx multiplies this half's own digits, ky the other half's; polynomial index q = j_in * 2 + c_out
-        double kx[4][E], ky[4][E];
-        {
-            const double* __restrict__ rows = bsk + (size_t)4 * g * BSKQ_ROW;
-#pragma unroll
-            for (unsigned m = 0; m < 4; ++m)
-#pragma unroll
-                for (unsigned c4 = 0; c4 < 4; ++c4) {
-                    const unsigned o0 = m * (unsigned)BSKQ_ROW + bsk_off(0, 3 * h, c4, t);
-                    const unsigned o1 = m * (unsigned)BSKQ_ROW + bsk_off(0, 2 - h, c4, t);
-#pragma unroll
-                    for (unsigned k = 0; k < 2; ++k) { kx[m][2 * c4 + k] = ldt(rows, o0 + k); ky[m][2 * c4 + k] = ldt(rows, o1 + k); }
-                }
-        }
 #pragma unroll
         for (int j = 0; j < E; ++j) x[j] = __builtin_rint(acc[j] * inv_g);
-        ct_radix8(x, twf, 1, P);
+        ct_radix8(x, w1f, P);
         st_o1p12(mine, t, x); load_tw8(twf, base2(t), w);
         __syncthreads();
         ld_o2p12(mine, t, x); ct_radix8(x, w, P);
-        __syncthreads();
+        wave_sync();
         st_o2p23(mine, t, x); load_tw8(twf, base3(t), w);
-        __syncthreads();
+        wave_sync();
         ld_o3p23(mine, t, x); ct_radix8(x, w, P);
-        __syncthreads();
+        wave_sync();
         st_o3p34(mine, t, x); load_tw4x2(twf, t, w);
-        __syncthreads();
+        wave_sync();
         ld_o4p34(mine, t, x); ct_radix4x2(x, w, P);
 #pragma unroll
         for (int j = 0; j < E; ++j) x[j] = mnorm(x[j], P);
@@ -710,10 +792,10 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q2_wide(Tables T, co
             ld_o4p34(theirs, t, y);
             const unsigned ut = 2 * rev8(t) + 1;
             const unsigned am[3] = {a0, a1, (a0 + a1) & (2 * N - 1)};
-            const double* __restrict__ w8 = T.mono + MONO_WORDS;
+            const double* __restrict__ w8 = mono + MONO_WORDS;
             double base[3];
 #pragma unroll
-            for (int m = 0; m < 3; ++m) base[m] = ldt(T.mono, (am[m] * ut) & (2 * N - 1));
+            for (int m = 0; m < 3; ++m) base[m] = ldt(mono, (am[m] * ut) & (2 * N - 1));
             double o[E];
             auto chunk = [&](auto c4_tag) {
                 constexpr int c4 = decltype(c4_tag)::value;
@@ -739,22 +821,29 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q2_wide(Tables T, co
 #pragma unroll
             for (int j = 0; j < E; ++j) x[j] = o[j];
         }
+        // the next step's loads must stay below the last use of this step's words (same registers):
+        // their addresses are made to depend on the point-wise results
+        unsigned tk = t;
+        asm volatile("" : "+v"(tk) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
+        const int gnext = next_step(g + 1);
+        if (gnext < groups) load_key(gnext, tk);
         gs_radix4x2<GS_NORM_PASS4[0], GS_NORM_PASS4[1]>(x, w, P);
         __syncthreads();                      // the other half has read this buffer
         st_o4p34(mine, t, x); load_tw8(twi, base3(t), w);
-        __syncthreads();
+        wave_sync();
         ld_o3p34(mine, t, x); gs_radix8<GS_NORM_PASS3[0], GS_NORM_PASS3[1], GS_NORM_PASS3[2]>(x, w, P);
-        __syncthreads();
+        wave_sync();
         st_o3p23(mine, t, x); load_tw8(twi, base2(t), w);
-        __syncthreads();
+        wave_sync();
         ld_o2p23(mine, t, x); gs_radix8<GS_NORM_PASS2[0], GS_NORM_PASS2[1], GS_NORM_PASS2[2]>(x, w, P);
-        __syncthreads();
+        wave_sync();
         st_o2p12(mine, t, x);
         __syncthreads();
-        ld_o1p12(mine, t, x); gs_radix8<GS_NORM_PASS1[0], GS_NORM_PASS1[1], GS_NORM_PASS1[2]>(x, twi, 1, P);
+        ld_o1p12(mine, t, x); gs_radix8<GS_NORM_PASS1[0], GS_NORM_PASS1[1], GS_NORM_PASS1[2]>(x, w1i, P);
 #pragma unroll
         for (int j = 0; j < E; ++j) acc[j] = qp_canon(x[j], P);
         __syncthreads();                      // the last pass's reads are done before the buffer is reused
+        g = gnext;
     }
 
     if (glwe_out) {
@@ -786,8 +875,15 @@ void launch_external_product_q(const Tables& T, const double* bsk, const u32* id
 void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
                            const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
                            const BlockMap& omap, double inv_g, int wide_below, int grouping, hipStream_t st) {
+    static const bool big_lds = [] {   // more than 64 KiB of dynamic LDS has to be asked for once
+        bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_blind_rotate_q2_wide),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE2_LDS_BYTES) == hipSuccess;
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(k_blind_rotate_q_wide),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_BYTES) == hipSuccess && ok;
+    }();
+    (void)big_lds;
     if (grouping == 2 && count <= (size_t)wide_below) {
-        hipLaunchKernelGGL(k_blind_rotate_q2_wide, dim3((unsigned)count), dim3(2 * NT), LDS_BYTES, st, T, bsk,
+        hipLaunchKernelGGL(k_blind_rotate_q2_wide, dim3((unsigned)count), dim3(2 * NT), WIDE2_LDS_BYTES, st, T, bsk,
                            lwe_small, n, luts, lut_index, glwe_out, lwe_out, omap, inv_g);
         return;
     }
@@ -798,7 +894,7 @@ void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_sm
     }
     // up to two ciphertexts per CU: latency matters more than throughput, use 512 threads each
     if (count <= (size_t)wide_below)
-        hipLaunchKernelGGL(k_blind_rotate_q_wide, dim3((unsigned)count), dim3(2 * NT), LDS_BYTES, st, T, bsk, lwe_small,
+        hipLaunchKernelGGL(k_blind_rotate_q_wide, dim3((unsigned)count), dim3(2 * NT), WIDE_LDS_BYTES, st, T, bsk, lwe_small,
                            n, luts, lut_index, glwe_out, lwe_out, omap, inv_g);
     else
         hipLaunchKernelGGL(k_blind_rotate_q, dim3((unsigned)count), dim3(NT), LDS_BYTES, st, T, bsk, lwe_small, n, luts,

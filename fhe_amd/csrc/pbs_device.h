@@ -20,6 +20,13 @@
 // The forward transform is Cooley-Tukey with the twist merged (natural in, bit-reversed out);
 // the inverse is Gentleman-Sande through the same passes backwards.  Each exchange has its own
 // padding so that both its write and its read are bank-conflict free for 8-byte LDS accesses.
+//
+// Which exchanges cross wavefronts.  With t = 64 wave + lane, passes 2, 3 and 4 all own
+// coefficients whose two top index bits equal the wave number: wave w works on e in
+// [512 w, 512 w + 512), and every padding maps that range into the wave's own LDS region
+// [576 w, 576 w + 576).  Only the exchange between passes 1 and 2 moves data between waves and
+// needs a workgroup barrier on either side; the other two are private to a wave, whose LDS
+// operations execute in program order, so a compiler-level fence is all they need (sync_after).
 #pragma once
 #include <stdint.h>
 
@@ -119,7 +126,7 @@ LFHE_HD unsigned own2(unsigned t, unsigned j) { return ((t >> 5) << 8) + (t & 31
 LFHE_HD unsigned own3(unsigned t, unsigned j) { return ((t >> 2) << 5) + (t & 3) + 4 * j; }
 LFHE_HD unsigned own4(unsigned t, unsigned j) { return 8 * t + j; }
 // ---- paddings per exchange
-LFHE_HD unsigned pad12(unsigned e) { return e; }
+LFHE_HD unsigned pad12(unsigned e) { return e + 64 * (e >> 9); }
 LFHE_HD unsigned pad23(unsigned e) { return e + 4 * (e >> 5); }
 LFHE_HD unsigned pad34(unsigned e) { return e + (e >> 3); }
 

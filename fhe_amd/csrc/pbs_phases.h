@@ -38,6 +38,16 @@ struct EpState {
 constexpr int EP_PHASES = 24;  // 12 per prime
 constexpr int EPQ_PHASES = 12; // single ring modulus
 
+// What has to separate phase PH from the next one.  Phases 0 and 10 publish the exchange between
+// passes 1 and 2, which crosses wavefronts, and phase 11 reads it: workgroup barriers.  Phase 5 reads
+// exactly the words phase 6 rewrites, thread by thread: nothing.  Every other hand-over stays inside
+// one wavefront's LDS region (pbs_device.h): program order within the wave is enough.
+enum class Sync { None, Wave, Block };
+constexpr Sync sync_after(int PH) {
+    const int ph = PH % 12;
+    return (ph == 0 || ph >= 10) ? Sync::Block : ph == 5 ? Sync::None : Sync::Wave;
+}
+
 // The same product over the single ring modulus q' = p0 (bootstrapping key and accumulator in
 // Z_q'): phases 0-11 only, digits handed over as doubles in s.x, result (|y| <= p0, any
 // representative) left in s.x; key row layout [q = j_in*2 + c_out][c4][t][2].

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 #include "../../fhe_amd/csrc/pbs_phases.h"
@@ -20,12 +21,36 @@ static u64 rnd() {
     return rng_state * 0x2545F4914F6CDD1Dull;
 }
 
+// The emulated schedule is the most hostile one the synchronisation table (sync_after) allows: a
+// workgroup barrier joins all wavefronts, anything weaker does not, so between two barriers one
+// wavefront runs all its phases before the next one starts, in a scrambled wave order.  A hand-over
+// marked wave-private that in truth crossed wavefronts would read stale words here.
+constexpr int WAVE_ORDER[NT / 64] = {2, 0, 3, 1};
+
+template <int PH, int END, typename F>
+static void run_wave(int wave, F&& phase) {   // phases PH.. of one wavefront up to its next barrier
+    if constexpr (PH < END) {
+        for (int l = 0; l < 64; ++l) phase(std::integral_constant<int, PH>{}, wave * 64 + l);
+        if constexpr (sync_after(PH) != Sync::Block) run_wave<PH + 1, END>(wave, phase);
+    }
+}
+template <int PH, int END>
+constexpr int segment_end() {   // first phase after PH's barrier-free run
+    if constexpr (PH >= END) return END;
+    else if constexpr (sync_after(PH) == Sync::Block) return PH + 1;
+    else return segment_end<PH + 1, END>();
+}
+template <int PH, int END, typename F>
+static void run_schedule(F&& phase) {
+    if constexpr (PH < END) {
+        for (int w : WAVE_ORDER) run_wave<PH, END>(w, phase);
+        run_schedule<segment_end<PH, END>(), END>(phase);
+    }
+}
+
 template <int PH>
 static void run_phases(std::vector<EpState>& st, double* lds, const Tables& T, const double* bsk_i) {
-    if constexpr (PH < EP_PHASES) {
-        for (int t = 0; t < NT; ++t) ep_phase<PH>(st[t], lds, t, T, bsk_i);
-        run_phases<PH + 1>(st, lds, T, bsk_i);
-    }
+    run_schedule<PH, EP_PHASES>([&](auto ph, int t) { ep_phase<decltype(ph)::value>(st[t], lds, t, T, bsk_i); });
 }
 
 static void make_bsk_row(const HostTables& H, const u64* ggsw, std::vector<double>& row) {
@@ -75,12 +100,14 @@ static int run_case(const orc_ctx* oc, const HostTables& H, const Tables& T, con
 
 // ---- one step of the grouped blind rotation (single ring modulus): phases 0-4, the grouped
 // point-wise stage, phases 6-11, against orc_group_step_qp
-template <int PH, int END>
-static void run_phases_q(std::vector<EpState>& st, double* lds, const Tables& T) {
-    if constexpr (PH < END) {
-        for (int t = 0; t < NT; ++t) ep_phase<PH, false, true>(st[t], lds, t, T, nullptr);
-        run_phases_q<PH + 1, END>(st, lds, T);
-    }
+// phases 0-11 of the grouped step, phase 5 being the grouped point-wise stage
+static void run_group_phases(std::vector<EpState>& st, double* lds, const Tables& T, const double* rows,
+                             unsigned a0, unsigned a1) {
+    run_schedule<0, EPQ_PHASES>([&](auto ph, int t) {
+        constexpr int PH = decltype(ph)::value;
+        if constexpr (PH == 5) ep_group2_phase5(st[t], lds, t, T, rows, a0, a1);
+        else ep_phase<PH, false, true>(st[t], lds, t, T, nullptr);
+    });
 }
 
 static void make_bskq_rows(const HostTables& H, const u64* ggsw4, std::vector<double>& rows) {
@@ -111,9 +138,7 @@ static int run_group_case(const orc_ctx* oc, const HostTables& H, const Tables& 
         for (int q = 0; q < 2; ++q)
             for (int j = 0; j < E; ++j)
                 st[t].x[q][j] = __builtin_rint(h_centred(acc_in[q * N + own1(t, j)], p) * inv_g);
-    run_phases_q<0, 5>(st, lds.data(), T);
-    for (int t = 0; t < NT; ++t) ep_group2_phase5(st[t], lds.data(), t, T, rows.data(), a0, a1);
-    run_phases_q<6, 12>(st, lds.data(), T);
+    run_group_phases(st, lds.data(), T, rows.data(), a0, a1);
     std::vector<u64> want(acc_in, acc_in + 2 * N);
     orc_group_step_qp(oc, ggsw4, a0, a1, want.data());
     int bad = 0;
