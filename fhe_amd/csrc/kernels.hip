@@ -429,7 +429,8 @@ constexpr int WIDE_TWF = LDS_WORDS;                 // word offsets
 constexpr int WIDE_TWI = WIDE_TWF + N;
 constexpr int WIDE_MONO = WIDE_TWI + N;
 static constexpr size_t WIDE_LDS_BYTES = (size_t)(WIDE_MONO) * sizeof(double);
-static constexpr size_t WIDE2_LDS_BYTES = (size_t)(WIDE_MONO + MONO_WORDS + 8) * sizeof(double);
+constexpr int WIDE2_BACK = WIDE_MONO + MONO_WORDS + 8;   // grouped kernel: exchange buffers of the inverse transform
+static constexpr size_t WIDE2_LDS_BYTES = (size_t)(WIDE2_BACK + LDS_WORDS) * sizeof(double);
 
 __device__ __forceinline__ void wide_fill_tables(const Tables& T, bool mono) {
     for (unsigned i = threadIdx.x; i < (unsigned)N; i += 2 * NT) {
@@ -702,6 +703,10 @@ __global__ void __launch_bounds__(NT, 4) k_blind_rotate_q2(Tables T, const doubl
 // The grouped blind rotation for launches too small to fill the GPU: 512 threads per ciphertext, one
 // half per polynomial as in k_blind_rotate_q_wide.  Each half forms the two entries of the step's
 // GGSW that feed its own output polynomial.  Results are bit-identical to k_blind_rotate_q2.
+// The inverse transform has exchange buffers of its own, which leaves three workgroup barriers per
+// step: after pass 1 of the forward transform has been published, after the transformed digits
+// have been published for the other half, and before pass 1 of the inverse transform reads.  Every
+// later write into a buffer is separated from the last cross-wave read of it by one of the three.
 __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q2_wide(Tables T, const double* __restrict__ bsk,
                                                                     const u64* __restrict__ lwe_small, int n,
                                                                     const u64* __restrict__ luts,
@@ -717,6 +722,7 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q2_wide(Tables T, co
     const u64* __restrict__ lut = luts + (size_t)(lut_index ? lut_index[omap.ops ? ct % omap.ops : ct] : 0) * N;
     double* mine = lds_dyn + h * POLY_STRIDE;
     double* theirs = lds_dyn + (1 - h) * POLY_STRIDE;
+    double* back = lds_dyn + WIDE2_BACK + h * POLY_STRIDE;
     const double* __restrict__ twf = lds_dyn + WIDE_TWF;   // passes 2-4; pass 1's live in scalar registers
     const double* __restrict__ twi = lds_dyn + WIDE_TWI;
     const double* __restrict__ mono = lds_dyn + WIDE_MONO;
@@ -754,17 +760,17 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q2_wide(Tables T, co
                 for (unsigned k = 0; k < 2; ++k) { kx[m][2 * c4 + k] = ldt(rows, o0 + k); ky[m][2 * c4 + k] = ldt(rows, o1 + k); }
             }
     };
-    // first step at or after g whose GGSW is not the identity (both exponents zero: skipped)
-    auto next_step = [&](int g) {
-        while (g < groups && (modswitch_2n(lwe[2 * g]) | (2 * g + 1 < n ? modswitch_2n(lwe[2 * g + 1]) : 0u)) == 0) ++g;
-        return g;
-    };
-    int g = next_step(0);
+    // the two exponents of step g; a step with both zero has the identity as its GGSW and is skipped
+    auto exponent0 = [&](int g) { return g < groups ? modswitch_2n(lwe[2 * g]) : 0u; };
+    auto exponent1 = [&](int g) { return 2 * g + 1 < n ? modswitch_2n(lwe[2 * g + 1]) : 0u; };
+    int g = 0;
+    unsigned a0 = exponent0(0), a1 = exponent1(0);
+    while (g < groups && (a0 | a1) == 0) { ++g; a0 = exponent0(g); a1 = exponent1(g); }
     if (g < groups) load_key(g, t0);
 
     while (g < groups) {
-        const unsigned a0 = modswitch_2n(lwe[2 * g]);
-        const unsigned a1 = 2 * g + 1 < n ? modswitch_2n(lwe[2 * g + 1]) : 0u;
+        // exponents of the following step: requested now, looked at after the point-wise stage
+        unsigned na0 = exponent0(g + 1), na1 = exponent1(g + 1);
         unsigned t = t0;
         asm volatile("" : "+v"(t));  // addresses are recomputed per step instead of living in registers
 #pragma unroll
@@ -825,25 +831,24 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q2_wide(Tables T, co
         // their addresses are made to depend on the point-wise results
         unsigned tk = t;
         asm volatile("" : "+v"(tk) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
-        const int gnext = next_step(g + 1);
+        int gnext = g + 1;
+        while (gnext < groups && (na0 | na1) == 0) { ++gnext; na0 = exponent0(gnext); na1 = exponent1(gnext); }
         if (gnext < groups) load_key(gnext, tk);
         gs_radix4x2<GS_NORM_PASS4[0], GS_NORM_PASS4[1]>(x, w, P);
-        __syncthreads();                      // the other half has read this buffer
-        st_o4p34(mine, t, x); load_tw8(twi, base3(t), w);
+        st_o4p34(back, t, x); load_tw8(twi, base3(t), w);
         wave_sync();
-        ld_o3p34(mine, t, x); gs_radix8<GS_NORM_PASS3[0], GS_NORM_PASS3[1], GS_NORM_PASS3[2]>(x, w, P);
+        ld_o3p34(back, t, x); gs_radix8<GS_NORM_PASS3[0], GS_NORM_PASS3[1], GS_NORM_PASS3[2]>(x, w, P);
         wave_sync();
-        st_o3p23(mine, t, x); load_tw8(twi, base2(t), w);
+        st_o3p23(back, t, x); load_tw8(twi, base2(t), w);
         wave_sync();
-        ld_o2p23(mine, t, x); gs_radix8<GS_NORM_PASS2[0], GS_NORM_PASS2[1], GS_NORM_PASS2[2]>(x, w, P);
+        ld_o2p23(back, t, x); gs_radix8<GS_NORM_PASS2[0], GS_NORM_PASS2[1], GS_NORM_PASS2[2]>(x, w, P);
         wave_sync();
-        st_o2p12(mine, t, x);
+        st_o2p12(back, t, x);
         __syncthreads();
-        ld_o1p12(mine, t, x); gs_radix8<GS_NORM_PASS1[0], GS_NORM_PASS1[1], GS_NORM_PASS1[2]>(x, w1i, P);
+        ld_o1p12(back, t, x); gs_radix8<GS_NORM_PASS1[0], GS_NORM_PASS1[1], GS_NORM_PASS1[2]>(x, w1i, P);
 #pragma unroll
         for (int j = 0; j < E; ++j) acc[j] = qp_canon(x[j], P);
-        __syncthreads();                      // the last pass's reads are done before the buffer is reused
-        g = gnext;
+        g = gnext; a0 = na0; a1 = na1;
     }
 
     if (glwe_out) {
