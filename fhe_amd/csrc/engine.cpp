@@ -381,7 +381,7 @@ void Engine::blind_rotate_with(const double* bsk, uint32_t n, const u64* lwe_sma
         }
         if (single_modulus())
             launch_blind_rotate_q(T_, bsk, in, (int)n, luts, li, gout, lout, cnt, omap,
-                                  1.0 / (double)qp_gadget(), wide_below_, (int)prm_.bsk_grouping, stream_);
+                                  1.0 / (double)qp_gadget(), wide_below_, 4 * cu_count_, (int)prm_.bsk_grouping, stream_);
         else
             launch_blind_rotate(T_, bsk, in, (int)n, luts, li, gout, lout, cnt, omap, stream_);
         HC(hipGetLastError());

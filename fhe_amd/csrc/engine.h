@@ -57,7 +57,8 @@ void launch_external_product_q(const Tables& T, const double* bsk, const u32* id
                                size_t count, double inv_g, hipStream_t st);
 void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
                            const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
-                           const BlockMap& omap, double inv_g, int wide_below, int grouping, hipStream_t st);
+                           const BlockMap& omap, double inv_g, int wide_below, int lockstep_above, int grouping,
+                           hipStream_t st);
 void launch_lin_batch(u64* arena, const LinOp* ops, int nops, size_t instances, size_t inst_stride_blocks, u64 delta,
                       hipStream_t st);
 void launch_blocks_move(u64* arena, size_t instances, size_t inst_stride_blocks, const u32* idx, u32 first, u32 nblocks,

@@ -606,25 +606,26 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q_wide(Tables T, con
 // The accumulator lives in registers only: a step decomposes it, transforms the digits, forms the
 // step's GGSW point by point from three key rows and the monomial factors, multiplies, transforms
 // back and REPLACES the accumulator -- no rotated reads, hence no accumulator copy in LDS.  (n + 1) / 2 steps of one external product each.
+//
+// LOCKSTEP: workgroup barriers after every phase, also where the data flow needs a wave-level fence
+// only.  A launch that keeps more than one round of workgroups busy is FASTER with them (4096
+// ciphertexts: 48.0 ms against 49.8 ms with fences, 49.3 ms with only the barrier before the
+// point-wise stage kept; 2048: 24.3 against 24.6 ms): waves that stay in lock step walk the key rows
+// together.  Up to one round of workgroups the fences win (384: 6.5 against 6.9 ms, 768: 10.1
+// against 10.5 ms).
 // ------------------------------------------------------------------------------------------------
 #define LFHE_G2_SYNC() phase_sync<Sync::Block>()
-#ifndef LFHE_G2_BLOCK_MASK
-// bit PH: workgroup barrier after phase PH even where the data flow does not need one.  With four
-// workgroups per CU the kernel is FASTER with all of them (4096 ciphertexts: 48.0 ms against 49.8 ms
-// with wave-level fences, 49.3 ms with only the barrier before the point-wise stage kept): waves
-// that stay in lock step walk the key rows together.  The 512-thread kernels, one workgroup per
-// CU, gain from dropping them.
-#define LFHE_G2_BLOCK_MASK 0x3FEu
-#endif
-constexpr Sync g2_sync_after(int PH) { return ((LFHE_G2_BLOCK_MASK >> PH) & 1u) ? Sync::Block : sync_after(PH); }
-template <int... PH>
+template <bool LOCKSTEP>
+constexpr Sync g2_sync_after(int PH) { return LOCKSTEP ? Sync::Block : sync_after(PH); }
+template <bool LOCKSTEP, int... PH>
 __device__ __forceinline__ void epq_run_range(EpState& s, double* lds, unsigned t, const Tables& T,
                                               std::integer_sequence<int, PH...>) {
-    ((ep_phase<PH, false, true>(s, lds, t, T, nullptr), phase_sync<g2_sync_after(PH)>()), ...);
+    ((ep_phase<PH, false, true>(s, lds, t, T, nullptr), phase_sync<g2_sync_after<LOCKSTEP>(PH)>()), ...);
 }
 template <int FIRST, int... K>
 constexpr auto phase_range(std::integer_sequence<int, K...>) { return std::integer_sequence<int, (FIRST + K)...>{}; }
 
+template <bool LOCKSTEP>
 __global__ void __launch_bounds__(NT, 4) k_blind_rotate_q2(Tables T, const double* __restrict__ bsk,
                                                                         const u64* __restrict__ lwe_small, int n,
                                                                         const u64* __restrict__ luts,
@@ -669,10 +670,10 @@ __global__ void __launch_bounds__(NT, 4) k_blind_rotate_q2(Tables T, const doubl
         st_o1p12(lds_dyn, tt, s.x[0]); st_o1p12(lds_dyn + POLY_STRIDE, tt, s.x[1]);
         load_tw8(T.tw_fwd[0], base2(tt), s.tw);   // twiddles of the next pass, one phase ahead
         LFHE_G2_SYNC();
-        epq_run_range(s, lds_dyn, t, T, phase_range<1>(std::make_integer_sequence<int, 4>{}));
+        epq_run_range<LOCKSTEP>(s, lds_dyn, t, T, phase_range<1>(std::make_integer_sequence<int, 4>{}));
         ep_group2_phase5(s, lds_dyn, t, T, bsk + (size_t)4 * g * BSKQ_ROW, a0, a1);
-        phase_sync<g2_sync_after(5)>();   // the next phase rewrites the words this thread has just read
-        epq_run_range(s, lds_dyn, t, T, phase_range<6>(std::make_integer_sequence<int, 5>{}));
+        phase_sync<g2_sync_after<LOCKSTEP>(5)>();   // the next phase rewrites the words this thread has just read
+        epq_run_range<LOCKSTEP>(s, lds_dyn, t, T, phase_range<6>(std::make_integer_sequence<int, 5>{}));
         ep_phase<11, false, true>(s, lds_dyn, t, T, nullptr);
 #pragma unroll
         for (int q = 0; q < 2; ++q)
@@ -879,7 +880,8 @@ void launch_external_product_q(const Tables& T, const double* bsk, const u32* id
 }
 void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
                            const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
-                           const BlockMap& omap, double inv_g, int wide_below, int grouping, hipStream_t st) {
+                           const BlockMap& omap, double inv_g, int wide_below, int lockstep_above, int grouping,
+                           hipStream_t st) {
     static const bool big_lds = [] {   // more than 64 KiB of dynamic LDS has to be asked for once
         bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_blind_rotate_q2_wide),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE2_LDS_BYTES) == hipSuccess;
@@ -893,8 +895,12 @@ void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_sm
         return;
     }
     if (grouping == 2) {
-        hipLaunchKernelGGL(k_blind_rotate_q2, dim3((unsigned)count), dim3(NT), LDS_BYTES, st, T, bsk, lwe_small, n,
-                           luts, lut_index, glwe_out, lwe_out, omap, inv_g);
+        if (count > (size_t)lockstep_above)
+            hipLaunchKernelGGL(k_blind_rotate_q2<true>, dim3((unsigned)count), dim3(NT), LDS_BYTES, st, T, bsk, lwe_small,
+                               n, luts, lut_index, glwe_out, lwe_out, omap, inv_g);
+        else
+            hipLaunchKernelGGL(k_blind_rotate_q2<false>, dim3((unsigned)count), dim3(NT), LDS_BYTES, st, T, bsk, lwe_small,
+                               n, luts, lut_index, glwe_out, lwe_out, omap, inv_g);
         return;
     }
     // up to two ciphertexts per CU: latency matters more than throughput, use 512 threads each
