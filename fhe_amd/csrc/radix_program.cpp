@@ -1,6 +1,7 @@
 #include "radix_program.h"
 
 #include <algorithm>
+#include <functional>
 #include <sstream>
 
 #include "../../include/lfhe.h"
@@ -154,36 +155,92 @@ Blocks clean(Builder& B, const Blocks& v) {
 
 Expr pack(Builder& B, uint32_t hi_blk, uint32_t lo_blk) { return Builder::add(Builder::scale(B.E(hi_blk), 4), B.E(lo_blk)); }
 
+// Three-valued states (0 kill, 1 pass, 2 set) and their composition "the most significant state
+// that is not `pass` decides" -- carry states of an addition (none / propagate / generate), signs of a
+// comparison (less / equal / greater).  Up to THREE states compose in one bootstrap: with the state
+// at position k (0 = least significant) held as state * 2^k, the plain sum of the blocks is the
+// addition the states describe -- `pass` is a one bit that hands a carry on, `set` a carry into the
+// next position -- so the composed state is set when the sum reaches 2^g, pass when it is 2^g - 1
+// (all pass), kill otherwise; the largest sum, 2 + 4 + 8, still fits a block.  A state is a
+// function of one bootstrap input, so the table that produces it can hand it out at whatever
+// position its consumer needs; a second consumer at another position costs a second bootstrap of
+// the same input in the same layer, never an extra layer.
+class States {
+public:
+    explicit States(Builder& b) : B(b) {}
+    int leaf(const Expr& in, std::function<int(int)> fn) {
+        nodes.push_back({in, std::move(fn), {-1, -1, -1}});
+        return (int)nodes.size() - 1;
+    }
+    // states[0] is the most significant
+    int combine(const std::vector<int>& states) {
+        const int g = (int)states.size();
+        Expr in;
+        for (int j = 0; j < g; ++j) in = Builder::add(in, B.E(at(states[j], g - 1 - j)));
+        return leaf(in, [g](int x) { return x >= (1 << g) ? 2 : (x == (1 << g) - 1 ? 1 : 0); });
+    }
+    // the block holding state * 2^k
+    uint32_t at(int node, int k) {
+        if (nodes[node].blk[k] < 0) {
+            const auto fn = nodes[node].fn;
+            nodes[node].blk[k] = (int)B.pbs(nodes[node].in, [fn, k](int x) { return fn(x) << k; });
+        }
+        return (uint32_t)nodes[node].blk[k];
+    }
+    // state * 4 as an expression, from a block that exists already if there is one
+    Expr times4(int node) {
+        for (int k = 2; k >= 0; --k)
+            if (nodes[node].blk[k] >= 0) return Builder::scale(B.E((uint32_t)nodes[node].blk[k]), 4 >> k);
+        return B.E(at(node, 2));
+    }
+    // a bootstrap of the state's own input through g(state)
+    uint32_t map(int node, std::function<int(int)> g) {
+        const auto fn = nodes[node].fn;
+        return B.pbs(nodes[node].in, [fn, g](int x) { return g(fn(x)); });
+    }
+
+private:
+    struct Node {
+        Expr in;
+        std::function<int(int)> fn;
+        int blk[3];
+    };
+    Builder& B;
+    std::vector<Node> nodes;
+};
+
 // Carry propagation over per-block sums v[i] in [0,7]: digit i = (v[i] + carry_in[i]) mod 4,
-// carry_out[i] = (v[i] + carry_in[i]) >= 4.  One layer extracts digit and carry state (0 none,
-// 1 propagate, 2 generate), a prefix network resolves the states in ceil(log2 m) layers, a
-// last layer adds the incoming carry.
+// carry_out[i] = (v[i] + carry_in[i]) >= 4.  One layer extracts digit and carry state (none,
+// propagate, generate), a prefix network over the states resolves them in ceil(log3 (m - 1))
+// layers, a last layer adds the incoming carry.
 Blocks propagate(Builder& B, const std::vector<Expr>& v) {
-    const size_t m = v.size();
-    Blocks msg(m), st(m ? m - 1 : 0);
+    const size_t m = v.size(), n = m ? m - 1 : 0;
+    Blocks msg(m);
+    States S(B);
+    std::vector<int> st(n);
     for (size_t i = 0; i < m; ++i) {
         msg[i] = B.pbs(v[i], lo2);
-        if (i + 1 < m) {
-            if (i == 0) st[i] = B.pbs(v[i], [](int x) { return x >= 4 ? 2 : 0; });
-            else st[i] = B.pbs(v[i], [](int x) { return x >= 4 ? 2 : (x == 3 ? 1 : 0); });
+        if (i < n) {
+            if (i == 0) st[i] = S.leaf(v[i], [](int x) { return x >= 4 ? 2 : 0; });
+            else st[i] = S.leaf(v[i], [](int x) { return x >= 4 ? 2 : (x == 3 ? 1 : 0); });
         }
     }
-    // Sklansky prefix network: at level d every position whose bit d is set absorbs the last
-    // position of the preceding group of 2^d.  Same depth as a Hillis-Steele scan (ceil(log2 m)
-    // layers) with (m/2) log2 m bootstraps instead of m log2 m.
-    for (size_t d = 0; ((size_t)1 << d) < st.size(); ++d) {
-        Blocks nx = st;
-        for (size_t i = 0; i < st.size(); ++i) {
-            if (!((i >> d) & 1)) continue;
-            const size_t j = ((i >> d) << d) - 1;
-            nx[i] = B.pbs(pack(B, st[i], st[j]), [](int x) { return hi2(x) == 1 ? lo2(x) : std::min(hi2(x), 2); });
+    // Sklansky network in base three: at the level of width w every group of 3 w positions is cut
+    // into thirds A, B, C; a position of B absorbs the last position of A, a position of C the last
+    // positions of B and of A.  Afterwards st[i] composes everything from the start of the group.
+    for (size_t w = 1; w < n; w *= 3) {
+        std::vector<int> nx = st;
+        for (size_t i = 0; i < n; ++i) {
+            const size_t third = (i / w) % 3, start = (i / w) * w;
+            if (third == 1) nx[i] = S.combine({st[i], st[start - 1]});
+            else if (third == 2) nx[i] = S.combine({st[i], st[start - 1], st[start - 1 - w]});
         }
         st = nx;
     }
     Blocks res(m);
     for (size_t i = 0; i < m; ++i) {
         if (i == 0) res[i] = msg[i];
-        else res[i] = B.pbs(Builder::add(B.E(msg[i]), Builder::scale(B.E(st[i - 1]), 4)),
+        else res[i] = B.pbs(Builder::add(B.E(msg[i]), S.times4(st[i - 1])),
                             [](int x) { return (lo2(x) + (hi2(x) == 2 ? 1 : 0)) & 3; });
     }
     return res;
@@ -296,35 +353,33 @@ uint32_t op_eq(Builder& B, const Blocks& a0, const Blocks& b0, bool negate) {
     return cur[0];
 }
 
-// order: per-block sign (0 equal, 1 less, 2 greater), most significant non-equal block wins
+// order: per-block sign (0 less, 1 equal, 2 greater), most significant non-equal block wins; the
+// signs compose three at a time (States)
 uint32_t op_cmp(Builder& B, const Blocks& a0, const Blocks& b0, uint32_t op) {
     const Blocks a = clean(B, a0), b = clean(B, b0);
     const size_t m = a.size();
     auto verdict = [op](int s) {
         switch (op) {
             case LFHE_OP_GT: return s == 2 ? 1 : 0;
-            case LFHE_OP_GE: return s != 1 ? 1 : 0;
-            case LFHE_OP_LT: return s == 1 ? 1 : 0;
+            case LFHE_OP_GE: return s != 0 ? 1 : 0;
+            case LFHE_OP_LT: return s == 0 ? 1 : 0;
             default: return s != 2 ? 1 : 0;  // LE
         }
     };
-    auto sign = [](int x) { return hi2(x) > lo2(x) ? 2 : (hi2(x) < lo2(x) ? 1 : 0); };
-    Blocks cur;  // most significant first
+    States S(B);
+    std::vector<int> cur;  // most significant first
     for (size_t i = m; i-- > 0;)
-        cur.push_back(B.pbs(pack(B, a[i], b[i]), [=](int x) { return m == 1 ? verdict(sign(x)) : sign(x); }));
+        cur.push_back(S.leaf(pack(B, a[i], b[i]), [](int x) { return hi2(x) > lo2(x) ? 2 : (hi2(x) < lo2(x) ? 0 : 1); }));
     while (cur.size() > 1) {
-        Blocks nx;
-        const bool last = cur.size() == 2;
-        for (size_t k = 0; k < cur.size(); k += 2) {
-            if (k + 1 == cur.size()) { nx.push_back(cur[k]); continue; }
-            nx.push_back(B.pbs(pack(B, cur[k], cur[k + 1]), [=](int x) {
-                const int s = hi2(x) != 0 ? std::min(hi2(x), 2) : std::min(lo2(x), 2);
-                return last ? verdict(s) : s;
-            }));
+        std::vector<int> nx;
+        for (size_t k = 0; k < cur.size(); k += 3) {
+            const size_t g = std::min<size_t>(3, cur.size() - k);
+            if (g == 1) nx.push_back(cur[k]);
+            else nx.push_back(S.combine(std::vector<int>(cur.begin() + k, cur.begin() + k + g)));
         }
         cur.swap(nx);
     }
-    return cur[0];
+    return S.map(cur[0], verdict);
 }
 
 // cond ? a : b per block in ONE bootstrap: x = 2 (a - b + 3) + cond fits the block (at most 13) and
