@@ -123,6 +123,12 @@ class NativeEngine {
   setPkeKey(pkeSk) { native.setPkeKey(this.handle, Buffer.from(pkeSk.buffer, pkeSk.byteOffset, pkeSk.byteLength)); }
   castFromPke(ciphertext) { return native.castFromPke(this.handle, Buffer.from(ciphertext)); }
 
+  /** Compression for storage: keys once, then any list of ciphertexts <-> one blob (one bootstrap per block on the way back). */
+  compressionKeygen() { native.compressionKeygen(this.handle); }
+  compress(ciphertexts) { return native.compress(this.handle, Buffer.concat(ciphertexts.map((c) => Buffer.from(c)))); }
+  /** @returns {Buffer} the ciphertexts back to back, in the order they were given to compress */
+  decompress(blob) { return native.decompress(this.handle, Buffer.from(blob)); }
+
   pbsCount() { return native.pbsCount(this.handle); }
   close() { if (this.handle) { native.destroy(this.handle); this.handle = null; } }
 }

@@ -50,6 +50,9 @@ FN(int32_t, lfhe_keygen_server, (lfhe_ctx*))
 FN(int32_t, lfhe_client_keys_import_raw, (lfhe_ctx*, const uint64_t*, const uint64_t*))
 FN(int32_t, lfhe_pke_key_set, (lfhe_ctx*, const uint64_t*))
 FN(int32_t, lfhe_cast_from_pke, (lfhe_ctx*, const uint8_t*, uint64_t, uint8_t*, uint64_t*))
+FN(int32_t, lfhe_compression_keygen, (lfhe_ctx*))
+FN(int32_t, lfhe_compress, (lfhe_ctx*, const uint8_t*, uint64_t, uint8_t*, uint64_t*))
+FN(int32_t, lfhe_decompress, (lfhe_ctx*, const uint8_t*, uint64_t, uint8_t*, uint64_t*))
 #undef FN
 
 static napi_value throw_msg(napi_env env, const char* msg) {
@@ -78,6 +81,7 @@ static int resolve_all(napi_env env, const char* path) {
     GET(lfhe_trivial_encrypt) GET(lfhe_encrypt_public) GET(lfhe_decrypt) GET(lfhe_ciphertext_size)
     GET(lfhe_op_from_name) GET(lfhe_evaluate) GET(lfhe_evaluate_batch) GET(lfhe_pbs_count)
     GET(lfhe_rand) GET(lfhe_keygen_server) GET(lfhe_client_keys_import_raw) GET(lfhe_pke_key_set) GET(lfhe_cast_from_pke)
+    GET(lfhe_compression_keygen) GET(lfhe_compress) GET(lfhe_decompress)
 #undef GET
     return 1;
 }
@@ -483,6 +487,44 @@ static napi_value js_cast_from_pke(napi_env env, napi_callback_info info) {
     return out;
 }
 
+static napi_value js_compression_keygen(napi_env env, napi_callback_info info) {
+    NEED_LIB();
+    napi_value argv[1];
+    if (!get_args(env, info, 1, argv)) return NULL;
+    lfhe_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return NULL;
+    const int32_t rc = p_lfhe_compression_keygen(c);
+    if (rc != LFHE_OK) return fail(env, c, rc, "lfhe_compression_keygen");
+    return NULL;
+}
+
+/* compress / decompress: size query first (out = NULL), then the call proper */
+typedef int32_t (*recode_fn)(lfhe_ctx*, const uint8_t*, uint64_t, uint8_t*, uint64_t*);
+static napi_value blob_call(napi_env env, napi_callback_info info, recode_fn fn, const char* what) {
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return NULL;
+    lfhe_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return NULL;
+    const uint8_t* in; size_t n;
+    if (!get_bytes(env, argv[1], &in, &n)) return NULL;
+    uint64_t on = 0;
+    int32_t rc = fn(c, in, n, NULL, &on);
+    if (rc != LFHE_OK) return fail(env, c, rc, what);
+    uint8_t* tmp = (uint8_t*)malloc(on ? on : 1);
+    rc = fn(c, in, n, tmp, &on);
+    napi_value out = rc == LFHE_OK ? make_buffer(env, tmp, on) : fail(env, c, rc, what);
+    free(tmp);
+    return out;
+}
+static napi_value js_compress(napi_env env, napi_callback_info info) {
+    NEED_LIB();
+    return blob_call(env, info, p_lfhe_compress, "lfhe_compress");
+}
+static napi_value js_decompress(napi_env env, napi_callback_info info) {
+    NEED_LIB();
+    return blob_call(env, info, p_lfhe_decompress, "lfhe_decompress");
+}
+
 static napi_value js_pbs_count(napi_env env, napi_callback_info info) {
     NEED_LIB();
     napi_value argv[1];
@@ -504,7 +546,8 @@ static napi_value init(napi_env env, napi_value exports) {
         {"decrypt", js_decrypt}, {"opFromName", js_op_from_name}, {"evaluate", js_evaluate},
         {"evaluateBatch", js_evaluate_batch}, {"pbsCount", js_pbs_count}, {"rand", js_rand},
         {"importClientKeys", js_import_client}, {"keygenServer", js_keygen_server}, {"setPkeKey", js_set_pke_key},
-        {"castFromPke", js_cast_from_pke}};
+        {"castFromPke", js_cast_from_pke}, {"compressionKeygen", js_compression_keygen}, {"compress", js_compress},
+        {"decompress", js_decompress}};
     for (size_t i = 0; i < sizeof tab / sizeof tab[0]; ++i) {
         napi_value f;
         napi_create_function(env, tab[i].name, NAPI_AUTO_LENGTH, tab[i].fn, NULL, &f);

@@ -24,10 +24,17 @@ const { LuxFHEClient, NativeEngine } = require('./index.js');
     rand: String(engine.decrypt(engine.rand(16, Buffer.alloc(16, 7), 10))),
     pbs: engine.pbsCount(),
   };
+  // compression for storage: both operands into one blob and back
+  engine.compressionKeygen();
+  const blob = engine.compress([a, b]);
+  const back = engine.decompress(blob);
+  res.blobBytes = blob.length;
+  res.restored = [String(engine.decrypt(back.slice(0, a.length))), String(engine.decrypt(back.slice(a.length)))];
   console.log(JSON.stringify(res));
   const ok = res.health === 'ok' && res.add === '59' && res.sub === '25' && res.lt === '0' && res.eq === '1' &&
     res.addScalar === '242' && res.shl === String((42 << 3) & 255) && res.mul64 === '18434227713315959936' &&
-    res.batch[0] === '1' && res.batch[1] === '0' && Number(res.rand) < 1024;
+    res.batch[0] === '1' && res.batch[1] === '0' && Number(res.rand) < 1024 &&
+    res.restored[0] === '42' && res.restored[1] === '17' && back.length === a.length + b.length && blob.length < a.length / 8;
   engine.close();
   process.exit(ok ? 0 : 1);
 })().catch((e) => { console.error(e.message); process.exit(2); });

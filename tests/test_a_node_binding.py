@@ -25,7 +25,8 @@ def test_addon_loads_and_exports_the_engine_calls():
     out = subprocess.run(["node", "-e", js], cwd=NODE_DIR, capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, out.stderr
     d = json.loads(out.stdout)
-    for fn in ("open", "createContext", "keygen", "publicKey", "encrypt", "decrypt", "evaluate", "evaluateBatch"):
+    for fn in ("open", "createContext", "keygen", "publicKey", "encrypt", "decrypt", "evaluate", "evaluateBatch",
+               "compressionKeygen", "compress", "decompress"):
         assert fn in d["fns"]
     # the reference SDK's method names (packages/luxfhejs/src/index.ts:56-122)
     for m in ("initialize", "getPublicKey", "encrypt_uint8", "encrypt_uint16", "encrypt_uint32", "encrypt_uint64",
@@ -54,3 +55,4 @@ def test_plumbing_case_through_node():
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["add"] == "59" and d["sub"] == "25" and d["lt"] == "0" and d["eq"] == "1"
     assert d["mul64"] == "18434227713315959936" and d["batch"] == ["1", "0"]
+    assert d["restored"] == ["42", "17"] and d["blobBytes"] < 8192      # compressed for storage and back
