@@ -10,6 +10,9 @@
 // rest.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <stdexcept>
+
 #include <cstdlib>
 #include <utility>
 
@@ -882,13 +885,18 @@ void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_sm
                            const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
                            const BlockMap& omap, double inv_g, int wide_below, int lockstep_above, int grouping,
                            hipStream_t st) {
-    static const bool big_lds = [] {   // more than 64 KiB of dynamic LDS has to be asked for once
-        bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_blind_rotate_q2_wide),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE2_LDS_BYTES) == hipSuccess;
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(k_blind_rotate_q_wide),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_BYTES) == hipSuccess && ok;
-    }();
-    (void)big_lds;
+    // more than 64 KiB of dynamic LDS has to be asked for, once per device the kernels run on
+    static std::atomic<uint64_t> lds_asked{0};
+    int dev = 0;
+    if (count <= (size_t)wide_below && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 &&
+        !(lds_asked.load(std::memory_order_acquire) >> dev & 1)) {
+        const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_blind_rotate_q2_wide),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE2_LDS_BYTES) == hipSuccess &&
+                        hipFuncSetAttribute(reinterpret_cast<const void*>(k_blind_rotate_q_wide),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_BYTES) == hipSuccess;
+        if (!ok) throw std::runtime_error("the 512-thread blind rotation needs 136 KiB of LDS per workgroup");
+        lds_asked.fetch_or(1ull << dev, std::memory_order_release);
+    }
     if (grouping == 2 && count <= (size_t)wide_below) {
         hipLaunchKernelGGL(k_blind_rotate_q2_wide, dim3((unsigned)count), dim3(2 * NT), WIDE2_LDS_BYTES, st, T, bsk,
                            lwe_small, n, luts, lut_index, glwe_out, lwe_out, omap, inv_g);

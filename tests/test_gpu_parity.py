@@ -390,6 +390,9 @@ def test_grouped_key_pbs_full_parameters():
             assert np.array_equal(out[i], orc.pbs_qp(ksk, pb, cts[i], luts_o[idx[i]])), i
         # a small launch takes the 512-thread kernel: same bits
         assert np.array_equal(ctx.pbs_batch(cts[:8], luts_g, idx[:8]), out[:8])
+        # more than four workgroups per CU: the instantiation with a barrier after every phase, same bits
+        big = ctx.pbs_batch(np.concatenate([cts, cts[:500]]), luts_g, np.concatenate([idx, idx[:500]]))
+        assert np.array_equal(big[:B], out) and np.array_equal(big[B:], out[:500])
     finally:
         ctx.close()
 
