@@ -21,6 +21,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+def column(cts):
+    """Ciphertexts of one width as an (n, size) byte array."""
+    import numpy as np
+    rows = [np.frombuffer(c, dtype=np.uint8) for c in cts]
+    return np.stack(rows) if rows else np.zeros((0, 0), dtype=np.uint8)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -99,11 +106,12 @@ def main():
     ys = [p[1] for p in kat] + [rnd.randrange(1 << 64) for _ in range(nb)]
     nb = len(xs)
     lo, hi = shard_bounds(nb, world, rank)
-    A, B = [ctx.encrypt(x, 64) for x in xs[lo:hi]], [ctx.encrypt(y, 64) for y in ys[lo:hi]]
+    # operand columns as (n, size) byte arrays: the C ABI's own layout, no copies in the binding
+    A, B = column(ctx.encrypt(x, 64) for x in xs[lo:hi]), column(ctx.encrypt(y, 64) for y in ys[lo:hi])
     outs, t_mulb = timed(lambda: ctx.evaluate_batch("mul", 64, A, B))
-    assert [ctx.decrypt(o) for o in outs] == [(x * y) & M64 for x, y in zip(xs[lo:hi], ys[lo:hi])]
+    assert [ctx.decrypt(bytes(o)) for o in outs] == [(x * y) & M64 for x, y in zip(xs[lo:hi], ys[lo:hi])]
     outs, t_gtb = timed(lambda: ctx.evaluate_batch("gt", 64, A, B))
-    assert [ctx.decrypt(o) for o in outs] == [int(x > y) for x, y in zip(xs[lo:hi], ys[lo:hi])]
+    assert [ctx.decrypt(bytes(o)) for o in outs] == [int(x > y) for x, y in zip(xs[lo:hi], ys[lo:hi])]
     res["euint64"] = {"mul_latency_ms": t_mul * 1e3, "mul_pbs": pbs_mul, "gt_latency_ms": t_gt * 1e3,
                       "add_latency_ms": t_add * 1e3, "mul_batch": nb, "mul_per_s": nb / t_mulb,
                       "mul_batch_pbs_per_s": nb * pbs_mul / t_mulb, "gt_per_s": nb / t_gtb}
@@ -114,7 +122,7 @@ def main():
     bal_to = [rnd.randrange(1 << 40) for _ in range(n)]
     amount = [rnd.randrange(1 << 41) for _ in range(n)]   # about half exceed the balance
     lo, hi = shard_bounds(n, world, rank)
-    F, T, AM = ([ctx.encrypt(v, 64) for v in vs[lo:hi]] for vs in (bal_from, bal_to, amount))
+    F, T, AM = (column(ctx.encrypt(v, 64) for v in vs[lo:hi]) for vs in (bal_from, bal_to, amount))
     zero = ctx.encrypt(0, 64, trivial=True)
     n0 = ctx.pbs_count()
     (nf, nt), t_erc = timed(lambda: workloads.transfers(ctx, F, T, AM, zero))
@@ -122,7 +130,7 @@ def main():
     for i in range(0, hi - lo, max(1, (hi - lo) // 64)):
         g = lo + i
         v = amount[g] if amount[g] <= bal_from[g] else 0
-        assert (ctx.decrypt(nf[i]), ctx.decrypt(nt[i])) == (bal_from[g] - v, (bal_to[g] + v) & M64), g
+        assert (ctx.decrypt(bytes(nf[i])), ctx.decrypt(bytes(nt[i]))) == (bal_from[g] - v, (bal_to[g] + v) & M64), g
     res["erc20"] = {"transfers": n, "seconds": t_erc, "transfers_per_s": n / t_erc, "pbs": pbs_erc,
                     "pbs_per_transfer": pbs_erc / n, "pbs_per_s": pbs_erc / t_erc}
 
@@ -130,13 +138,13 @@ def main():
     nbid = args.bids
     bids = rnd.sample(range(1 << 32), nbid)
     lo, hi = shard_bounds(nbid, world, rank)
-    vals = [ctx.encrypt(v, 32) if lo <= i < hi else None for i, v in enumerate(bids)]
-    idxs = [ctx.encrypt(i, 16, trivial=True) if lo <= i < hi else None for i in range(nbid)]
+    vals = column(ctx.encrypt(bids[i], 32) for i in range(lo, hi))
+    idxs = column(ctx.encrypt(i, 16, trivial=True) for i in range(lo, hi))
     n0 = ctx.pbs_count()
-    win, t_arg = timed(lambda: workloads.sharded_argmax(dist, ctx, vals, idxs, rank, world))
+    win, t_arg = timed(lambda: workloads.sharded_argmax(dist, ctx, vals, idxs, rank, world, local=True))
     pbs_arg = total(ctx.pbs_count() - n0)
     if rank == 0:
-        assert ctx.decrypt(win[0]) == max(bids) and ctx.decrypt(win[1]) == bids.index(max(bids))
+        assert ctx.decrypt(bytes(win[0])) == max(bids) and ctx.decrypt(bytes(win[1])) == bids.index(max(bids))
     res["argmax"] = {"bids": nbid, "seconds": t_arg, "pbs": pbs_arg, "pbs_per_s": pbs_arg / t_arg}
     if rank == 0:
         print(json.dumps(res), flush=True)

@@ -354,25 +354,41 @@ class Context:
                                        C.byref(n)))
         return out[: n.value].tobytes()
 
-    def evaluate_batch(self, op: str, bit_width: int, lhs: list, rhs: list | None = None,
-                       cond: list | None = None) -> list:
+    @staticmethod
+    def _column(col) -> np.ndarray:
+        """n ciphertexts as the C ABI wants them, back to back: a list of byte strings is joined, an
+        (n, size) byte array is used where it lies."""
+        if isinstance(col, np.ndarray):
+            return np.ascontiguousarray(col, dtype=np.uint8).reshape(-1)
+        return np.frombuffer(b"".join(col), dtype=np.uint8)
+
+    @staticmethod
+    def _rows(flat: np.ndarray, n: int, sz: int, as_array: bool):
+        if as_array:
+            return flat.reshape(n, sz)
+        view = memoryview(flat)
+        return [bytes(view[i * sz:(i + 1) * sz]) for i in range(n)]
+
+    def evaluate_batch(self, op: str, bit_width: int, lhs, rhs=None, cond=None):
+        """n independent instances of one operator.  Operands: lists of ciphertext byte strings, or
+        (n, size) byte arrays (no copy on the way in, an array comes back); rhs may be a list of ints."""
         n = len(lhs)
+        as_array = isinstance(lhs, np.ndarray)
         scalar = rhs is not None and len(rhs) > 0 and isinstance(rhs[0], int)
-        A = np.frombuffer(b"".join(lhs), dtype=np.uint8)
+        A = self._column(lhs)
         if rhs is None:
             B = None
         elif scalar:
             B = np.frombuffer(b"".join(le32(v % (1 << 256)) for v in rhs), dtype=np.uint8)
         else:
-            B = np.frombuffer(b"".join(rhs), dtype=np.uint8)
-        Cn = None if cond is None else np.frombuffer(b"".join(cond), dtype=np.uint8)
+            B = self._column(rhs)
+        Cn = None if cond is None else self._column(cond)
         out_w = 1 if op in COMPARISONS else bit_width
         sz = self.ciphertext_size(out_w)
         out = np.empty(n * sz, dtype=np.uint8)   # every byte is written by the library
         self._ck(self._L.lfhe_evaluate_batch(self._h, OPS[op], bit_width, n, _ptr(A), _ptr(B), 1 if scalar else 0,
                                              _ptr(Cn), _ptr(out)))
-        view = memoryview(out)
-        return [bytes(view[i * sz:(i + 1) * sz]) for i in range(n)]
+        return self._rows(out, n, sz, as_array)
 
     def rand(self, bit_width: int, seed: bytes, random_bits: int | None = None) -> bytes:
         """Oblivious pseudo-random ciphertext: uniform below 2^random_bits (default: the full width)."""
@@ -384,27 +400,24 @@ class Context:
         return buf.tobytes()
 
     def evaluate_fused(self, steps: list, in_widths: list, inputs: list, outputs: list, out_widths: list) -> list:
-        """Several operations as one schedule.  inputs: one list of n ciphertexts per input;
-        outputs: value references; out_widths: the width of each (1 for comparisons).  Returns one
-        list of n ciphertexts per output."""
+        """Several operations as one schedule.  inputs: per input, a list of n ciphertexts or an
+        (n, size) byte array; outputs: value references; out_widths: the width of each (1 for
+        comparisons).  Returns per output a list of n ciphertexts (an array when the inputs were arrays)."""
         n = len(inputs[0])
+        as_array = isinstance(inputs[0], np.ndarray)
         if n == 0:
             return [[] for _ in outputs]
         arr = make_steps(steps)
         w = (C.c_uint32 * len(in_widths))(*in_widths)
         o = (C.c_int32 * len(outputs))(*outputs)
-        ins = [np.frombuffer(b"".join(col), dtype=np.uint8) for col in inputs]
+        ins = [self._column(col) for col in inputs]
         in_ptrs = (C.c_void_p * len(ins))(*[a.ctypes.data for a in ins])
         sizes = [self.ciphertext_size(x) for x in out_widths]
         outs = [np.empty(n * sz, dtype=np.uint8) for sz in sizes]   # every byte is written by the library
         out_ptrs = (C.c_void_p * len(outs))(*[a.ctypes.data for a in outs])
         self._ck(self._L.lfhe_evaluate_fused(self._h, arr, len(steps), len(in_widths), w, n, in_ptrs, o, len(outputs),
                                              out_ptrs))
-        res = []
-        for a, sz in zip(outs, sizes):
-            view = memoryview(a)
-            res.append([bytes(view[i * sz:(i + 1) * sz]) for i in range(n)])
-        return res
+        return [self._rows(a, n, sz, as_array) for a, sz in zip(outs, sizes)]
 
     # ---- compression for storage
     def compression_keygen(self):
