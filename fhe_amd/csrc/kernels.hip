@@ -628,6 +628,27 @@ __device__ __forceinline__ void epq_run_range(EpState& s, double* lds, unsigned 
 template <int FIRST, int... K>
 constexpr auto phase_range(std::integer_sequence<int, K...>) { return std::integer_sequence<int, (FIRST + K)...>{}; }
 
+// The twiddles of passes 1 and 2 -- table entries 1..63 of either direction, 1 KiB together -- sit
+// in LDS behind the exchange buffers (four workgroups still fit a CU): they are what every thread
+// asks for with few distinct addresses, and taking them off the vector memory path leaves it to the
+// key rows and the pass-3/4 twiddles.
+#ifndef LFHE_G2_TW_SMALL
+#define LFHE_G2_TW_SMALL 64
+#endif
+constexpr int G2_TW_SMALL = LFHE_G2_TW_SMALL;
+static constexpr size_t G2_LDS_BYTES = LDS_BYTES + 2 * G2_TW_SMALL * sizeof(double);
+// twiddles of pass 3 (first-stage index b in [64, 128)): entries below G2_TW_SMALL from LDS
+__device__ __forceinline__ void load_tw8_pass3(const double* __restrict__ small, const double* __restrict__ tw,
+                                               unsigned b, double (&w)[7]) {
+    if constexpr (G2_TW_SMALL >= 256) {
+        w[0] = small[b]; w[1] = small[2 * b]; w[2] = small[2 * b + 1];
+#pragma unroll
+        for (unsigned k = 0; k < 4; ++k) w[3 + k] = ldtw(tw, 4 * b + k);
+    } else {
+        load_tw8(tw, b, w);
+    }
+}
+
 template <bool LOCKSTEP>
 __global__ void __launch_bounds__(NT, 4) k_blind_rotate_q2(Tables T, const double* __restrict__ bsk,
                                                                         const u64* __restrict__ lwe_small, int n,
@@ -654,9 +675,17 @@ __global__ void __launch_bounds__(NT, 4) k_blind_rotate_q2(Tables T, const doubl
             acc[1][j] = neg ? -v : v;
         }
     }
+    const double* __restrict__ twf_small = lds_dyn + LDS_WORDS;   // entries 0..63 of the forward table
+    const double* __restrict__ twi_small = twf_small + G2_TW_SMALL;
+    for (unsigned i = t; i < (unsigned)G2_TW_SMALL; i += NT) {
+        lds_dyn[LDS_WORDS + i] = T.tw_fwd[0][i];
+        lds_dyn[LDS_WORDS + G2_TW_SMALL + i] = T.tw_inv[0][i];
+    }
     LFHE_G2_SYNC();
 
     EpState s;
+    double* b0 = lds_dyn;
+    double* b1 = lds_dyn + POLY_STRIDE;
     const int groups = (n + 1) / 2;
     for (int g = 0; g < groups; ++g) {
         const unsigned a0 = modswitch_2n(lwe[2 * g]);
@@ -668,16 +697,35 @@ __global__ void __launch_bounds__(NT, 4) k_blind_rotate_q2(Tables T, const doubl
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int j = 0; j < E; ++j) s.x[q][j] = __builtin_rint(acc[q][j] * inv_g);
-        ct_radix8(s.x[0], T.tw_fwd[0], 1, P);
-        ct_radix8(s.x[1], T.tw_fwd[0], 1, P);
-        st_o1p12(lds_dyn, tt, s.x[0]); st_o1p12(lds_dyn + POLY_STRIDE, tt, s.x[1]);
-        load_tw8(T.tw_fwd[0], base2(tt), s.tw);   // twiddles of the next pass, one phase ahead
+        // phase 0
+        ct_radix8(s.x[0], twf_small, 1, P);
+        ct_radix8(s.x[1], twf_small, 1, P);
+        st_o1p12(b0, tt, s.x[0]); st_o1p12(b1, tt, s.x[1]);
+        load_tw8(twf_small, base2(tt), s.tw);   // twiddles of the next pass, one phase ahead
         LFHE_G2_SYNC();
-        epq_run_range<LOCKSTEP>(s, lds_dyn, t, T, phase_range<1>(std::make_integer_sequence<int, 4>{}));
+        epq_run_range<LOCKSTEP>(s, lds_dyn, t, T, phase_range<1>(std::make_integer_sequence<int, 1>{}));
+        // phases 2, 6, 8 and 11 as in ep_phase, with twiddles from LDS
+        asm volatile("" : "+v"(tt));
+        st_o2p23(b0, tt, s.x[0]); st_o2p23(b1, tt, s.x[1]);
+        load_tw8_pass3(twf_small, T.tw_fwd[0], base3(tt), s.tw);
+        phase_sync<g2_sync_after<LOCKSTEP>(2)>();
+        epq_run_range<LOCKSTEP>(s, lds_dyn, t, T, phase_range<3>(std::make_integer_sequence<int, 2>{}));
         ep_group2_phase5(s, lds_dyn, t, T, bsk + (size_t)4 * g * BSKQ_ROW, a0, a1);
         phase_sync<g2_sync_after<LOCKSTEP>(5)>();   // the next phase rewrites the words this thread has just read
-        epq_run_range<LOCKSTEP>(s, lds_dyn, t, T, phase_range<6>(std::make_integer_sequence<int, 5>{}));
-        ep_phase<11, false, true>(s, lds_dyn, t, T, nullptr);
+        asm volatile("" : "+v"(tt));
+        st_o4p34(b0, tt, s.x[0]); st_o4p34(b1, tt, s.x[1]);
+        load_tw8_pass3(twi_small, T.tw_inv[0], base3(tt), s.tw);
+        phase_sync<g2_sync_after<LOCKSTEP>(6)>();
+        epq_run_range<LOCKSTEP>(s, lds_dyn, t, T, phase_range<7>(std::make_integer_sequence<int, 1>{}));
+        asm volatile("" : "+v"(tt));
+        st_o3p23(b0, tt, s.x[0]); st_o3p23(b1, tt, s.x[1]);
+        load_tw8(twi_small, base2(tt), s.tw);
+        phase_sync<g2_sync_after<LOCKSTEP>(8)>();
+        epq_run_range<LOCKSTEP>(s, lds_dyn, t, T, phase_range<9>(std::make_integer_sequence<int, 2>{}));
+        asm volatile("" : "+v"(tt));
+        ld_o1p12(b0, tt, s.x[0]); ld_o1p12(b1, tt, s.x[1]);
+        gs_radix8<GS_NORM_PASS1[0], GS_NORM_PASS1[1], GS_NORM_PASS1[2]>(s.x[0], twi_small, 1, P);
+        gs_radix8<GS_NORM_PASS1[0], GS_NORM_PASS1[1], GS_NORM_PASS1[2]>(s.x[1], twi_small, 1, P);
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -904,10 +952,10 @@ void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_sm
     }
     if (grouping == 2) {
         if (count > (size_t)lockstep_above)
-            hipLaunchKernelGGL(k_blind_rotate_q2<true>, dim3((unsigned)count), dim3(NT), LDS_BYTES, st, T, bsk, lwe_small,
+            hipLaunchKernelGGL(k_blind_rotate_q2<true>, dim3((unsigned)count), dim3(NT), G2_LDS_BYTES, st, T, bsk, lwe_small,
                                n, luts, lut_index, glwe_out, lwe_out, omap, inv_g);
         else
-            hipLaunchKernelGGL(k_blind_rotate_q2<false>, dim3((unsigned)count), dim3(NT), LDS_BYTES, st, T, bsk, lwe_small,
+            hipLaunchKernelGGL(k_blind_rotate_q2<false>, dim3((unsigned)count), dim3(NT), G2_LDS_BYTES, st, T, bsk, lwe_small,
                                n, luts, lut_index, glwe_out, lwe_out, omap, inv_g);
         return;
     }
