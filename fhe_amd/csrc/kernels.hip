@@ -1211,7 +1211,10 @@ void launch_lin_batch(u64* arena, const LinOp* ops, int nops, size_t instances, 
 
 // ------------------------------------------------------------------------------------------------
 // modulus-switch noise reduction (ms_noise.h): one workgroup per small ciphertext, one wavefront
-// per candidate, four candidates per round in index order (-1 = the ciphertext as it is)
+// per candidate, WAVES candidates per round in index order (-1 = the ciphertext as it is).  The
+// choice is the first candidate in index order within the bound, whatever WAVES is: four per round
+// waste the least work in a long batch, sixteen per round need a quarter of the rounds when a
+// bootstrap layer is a few dozen ciphertexts and the slowest search sets the launch time.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ i64 wave_sum_i64(i64 v) {
 #pragma unroll
@@ -1219,18 +1222,19 @@ __device__ __forceinline__ i64 wave_sum_i64(i64 v) {
     return v;
 }
 
-__global__ void __launch_bounds__(256) k_ms_noise_reduce(u64* __restrict__ lwe_small, int n,
-                                                         const u64* __restrict__ zeros, MsParams m,
-                                                         int* __restrict__ chosen_out) {
+template <int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) k_ms_noise_reduce(u64* __restrict__ lwe_small, int n,
+                                                                const u64* __restrict__ zeros, MsParams m,
+                                                                int* __restrict__ chosen_out) {
     extern __shared__ u64 ms_ct[];  // n + 1 words
-    __shared__ u64 est[4];
+    __shared__ u64 est[WAVES];
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     u64* ct = lwe_small + (size_t)blockIdx.x * (n + 1);
-    for (int j = t; j <= n; j += 256) ms_ct[j] = ct[j];
+    for (int j = t; j <= n; j += 64 * WAVES) ms_ct[j] = ct[j];
     __syncthreads();
     u64 best = ~0ull;
     int best_idx = -1, chosen = -2;
-    for (int base = -1; base < (int)m.zcount && chosen == -2; base += 4) {
+    for (int base = -1; base < (int)m.zcount && chosen == -2; base += WAVES) {
         const int cand = base + wave;
         if (cand < (int)m.zcount) {
             const u64* z = zeros + (size_t)(cand < 0 ? 0 : cand) * (n + 1);
@@ -1246,7 +1250,7 @@ __global__ void __launch_bounds__(256) k_ms_noise_reduce(u64* __restrict__ lwe_s
             if (lane == 0) est[wave] = ms_estimate(s1, (u64)s2, m);
         }
         __syncthreads();
-        for (int w = 0; w < 4 && base + w < (int)m.zcount; ++w) {
+        for (int w = 0; w < WAVES && base + w < (int)m.zcount; ++w) {
             const u64 e = est[w];
             if (e <= m.bound_fx) { chosen = base + w; break; }
             if (e < best) { best = e; best_idx = base + w; }
@@ -1256,15 +1260,19 @@ __global__ void __launch_bounds__(256) k_ms_noise_reduce(u64* __restrict__ lwe_s
     if (chosen == -2) chosen = best_idx;
     if (chosen >= 0) {
         const u64* z = zeros + (size_t)chosen * (n + 1);
-        for (int j = t; j <= n; j += 256) ct[j] = ms_ct[j] + z[j];
+        for (int j = t; j <= n; j += 64 * WAVES) ct[j] = ms_ct[j] + z[j];
     }
     if (chosen_out && t == 0) chosen_out[blockIdx.x] = chosen;
 }
 
 void launch_ms_noise_reduce(u64* lwe_small, int n, const u64* zeros, const MsParams& m, int* chosen, size_t count,
                             hipStream_t st) {
-    hipLaunchKernelGGL(k_ms_noise_reduce, dim3((unsigned)count), dim3(256), (size_t)(n + 1) * sizeof(u64), st,
-                       lwe_small, n, zeros, m, chosen);
+    if (count <= 512)
+        hipLaunchKernelGGL(k_ms_noise_reduce<16>, dim3((unsigned)count), dim3(1024), (size_t)(n + 1) * sizeof(u64), st,
+                           lwe_small, n, zeros, m, chosen);
+    else
+        hipLaunchKernelGGL(k_ms_noise_reduce<4>, dim3((unsigned)count), dim3(256), (size_t)(n + 1) * sizeof(u64), st,
+                           lwe_small, n, zeros, m, chosen);
 }
 
 void launch_lwe_linear(const u64* a, const u64* b, u64* out, size_t count, int dim1, u64 ca, u64 cb, u64 add_body,
