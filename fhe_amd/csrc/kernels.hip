@@ -431,7 +431,10 @@ __global__ void __launch_bounds__(NT, LFHE_BRQ_WAVES) k_blind_rotate_q(Tables T,
 constexpr int WIDE_TWF = LDS_WORDS;                 // word offsets
 constexpr int WIDE_TWI = WIDE_TWF + N;
 constexpr int WIDE_MONO = WIDE_TWI + N;
-static constexpr size_t WIDE_LDS_BYTES = (size_t)(WIDE_MONO) * sizeof(double);
+// one-bit kernel: exchange buffers of the inverse transform and the published accumulator behind the tables
+constexpr int WIDE_BACK = WIDE_MONO;
+constexpr int WIDE_ACC = WIDE_BACK + LDS_WORDS;
+static constexpr size_t WIDE_LDS_BYTES = (size_t)(WIDE_ACC + LDS_WORDS) * sizeof(double);
 constexpr int WIDE2_BACK = WIDE_MONO + MONO_WORDS + 8;   // grouped kernel: exchange buffers of the inverse transform
 static constexpr size_t WIDE2_LDS_BYTES = (size_t)(WIDE2_BACK + LDS_WORDS) * sizeof(double);
 
@@ -482,6 +485,12 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q_wide(Tables T, con
     double* theirs = lds_dyn + (1 - h) * POLY_STRIDE;
     const double* __restrict__ twf = lds_dyn + WIDE_TWF;   // passes 2-4; pass 1's live in scalar registers
     const double* __restrict__ twi = lds_dyn + WIDE_TWI;
+    // The inverse transform and the published accumulator (the next step's rotated reads) have
+    // buffers of their own, which leaves four workgroup barriers per step: after pass 1 of the
+    // forward transform is published, after the transformed digits are, before pass 1 of the
+    // inverse transform reads, and after the new accumulator is published.
+    double* back = lds_dyn + WIDE_BACK + h * POLY_STRIDE;
+    double* accb = lds_dyn + WIDE_ACC + h * POLY_STRIDE;
     wide_fill_tables(T, false);
 
     double acc[E], x[E], w[7], w1f[7], w1i[7];
@@ -496,7 +505,7 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q_wide(Tables T, con
             bool neg;
             const double v = torus_to_qp(lut[rot_index(e, a, neg)]);
             acc[j] = h ? (neg ? -v : v) : 0.0;
-            mine[pad12(e)] = acc[j];
+            accb[pad12(e)] = acc[j];
         }
     }
     __syncthreads();
@@ -528,11 +537,10 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q_wide(Tables T, con
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             bool neg;
-            const double r = mine[pad12(rot_index(own1(t, j), a, neg))];
+            const double r = accb[pad12(rot_index(own1(t, j), a, neg))];
             x[j] = __builtin_rint(qp_canon((neg ? -r : r) - acc[j], P) * inv_g);
         }
         ct_radix8(x, w1f, P);
-        __syncthreads();                      // rotated reads done before the buffer is reused
         st_o1p12(mine, t, x); load_tw8(twf, base2(t), w);
         __syncthreads();
         ld_o2p12(mine, t, x); ct_radix8(x, w, P);
@@ -565,24 +573,23 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q_wide(Tables T, con
         const int inext = next_step(i + 1);
         if (inext < n) load_key(inext, tk);
         gs_radix4x2<GS_NORM_PASS4[0], GS_NORM_PASS4[1]>(x, w, P);
-        __syncthreads();                      // the other half has read this buffer
-        st_o4p34(mine, t, x); load_tw8(twi, base3(t), w);
+        st_o4p34(back, t, x); load_tw8(twi, base3(t), w);
         wave_sync();
-        ld_o3p34(mine, t, x); gs_radix8<GS_NORM_PASS3[0], GS_NORM_PASS3[1], GS_NORM_PASS3[2]>(x, w, P);
+        ld_o3p34(back, t, x); gs_radix8<GS_NORM_PASS3[0], GS_NORM_PASS3[1], GS_NORM_PASS3[2]>(x, w, P);
         wave_sync();
-        st_o3p23(mine, t, x); load_tw8(twi, base2(t), w);
+        st_o3p23(back, t, x); load_tw8(twi, base2(t), w);
         wave_sync();
-        ld_o2p23(mine, t, x); gs_radix8<GS_NORM_PASS2[0], GS_NORM_PASS2[1], GS_NORM_PASS2[2]>(x, w, P);
+        ld_o2p23(back, t, x); gs_radix8<GS_NORM_PASS2[0], GS_NORM_PASS2[1], GS_NORM_PASS2[2]>(x, w, P);
         wave_sync();
-        st_o2p12(mine, t, x);
+        st_o2p12(back, t, x);
         __syncthreads();
-        ld_o1p12(mine, t, x); gs_radix8<GS_NORM_PASS1[0], GS_NORM_PASS1[1], GS_NORM_PASS1[2]>(x, w1i, P);
+        ld_o1p12(back, t, x); gs_radix8<GS_NORM_PASS1[0], GS_NORM_PASS1[1], GS_NORM_PASS1[2]>(x, w1i, P);
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             acc[j] = qp_canon(acc[j] + x[j], P);
-            mine[pad12(own1(t, j))] = acc[j];
+            accb[pad12(own1(t, j))] = acc[j];
         }
-        __syncthreads();
+        __syncthreads();                      // the new accumulator is visible before the next step's rotated reads
         i = inext;
     }
 
