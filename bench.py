@@ -37,7 +37,7 @@ PEAK_GBFLY_PER_PRIME = 4748.0
 # memory-side traffic of one 4096-ciphertext blind-rotation launch, from separate rocprofv3 --pmc passes
 # (profiles/r01/pmc_hbm_v5.txt): (2 * FETCH_SIZE + WRITE_SIZE) * 1024, Infinity-Cache hits included
 TRAFFIC_BYTES_4096 = {"prime": (2 * 3808307 + 196800) * 1024, "q64": (2 * 7909668 + 196739) * 1024,
-                      "grouped": (2 * 14541630 + 67674) * 1024}   # profiles/r01/pmc_grouped_v10.txt
+                      "grouped": (2 * 7534766 + 65813) * 1024}   # profiles/r01/pmc_grouped_v13.txt
 # algorithmic bytes of one batch launch: both keys once + one ciphertext in and out per bootstrap
 BSK_BYTES, KSK_BYTES, CT_BYTES = 60162048, 60227584, 16392
 # device image of the bootstrapping key (f64 residues in the transform domain)
