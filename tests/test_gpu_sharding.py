@@ -78,8 +78,10 @@ def _two_rank_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_ranks_replicate_keys_through_torch_distributed():
+def test_two_ranks_replicate_keys_through_torch_distributed(capsys):
+    import queue
     import socket
+    import time
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -90,10 +92,26 @@ def test_two_ranks_replicate_keys_through_torch_distributed():
     procs = [mpc.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = sorted(q.get(timeout=300) for _ in procs)
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    # the two ranks are the first processes of the run to import torch, which takes minutes on a box
+    # that has not paged the image in yet: wait with a sign of life every 20 s, give up after 10 min
+    got, t0 = [], time.time()
+    try:
+        while len(got) < len(procs):
+            try:
+                got.append(q.get(timeout=20))
+            except queue.Empty:
+                assert all(p.is_alive() or p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+                assert time.time() - t0 < 600, "ranks did not report"
+                with capsys.disabled():
+                    print(f"[two-rank test: waiting for the ranks, {time.time() - t0:.0f} s]", flush=True)
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+    got.sort()
     (r0, cut0, s0, w0, d0, t0, k0), (r1, cut1, s1, w1, d1, t1, k1) = got
     assert cut0 == (0, 16) and cut1 == (16, 32)
     assert d0 and d1                      # every bootstrapped block decrypts to table(message) on both ranks
