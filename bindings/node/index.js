@@ -10,6 +10,7 @@
  * Unlike the reference's encrypt_uint64/128/256, BigInt values are not squeezed through Number().
  */
 const path = require('path');
+const crypto = require('crypto');
 const native = require('./lfhe_napi.node');
 
 const PARAMS = { Q64: 1, PRIME_BSK: 2, PRIME_BSK_GROUPED: 3 };
@@ -43,13 +44,16 @@ function openLibrary(libPath) {
 class NativeEngine {
   /**
    * @param {{seed?: Uint8Array, device?: number, params?: number, libPath?: string, keygen?: boolean}} opts
+   * seed: 32 bytes the keys derive from -- as secret as the keys, so the default is fresh
+   * randomness; a fixed seed is for tests.  params: default PARAMS.PRIME_BSK_GROUPED, as the
+   * HTTP server and the Python binding's GpuBackend.
    */
   constructor(opts) {
     const o = opts || {};
     openLibrary(o.libPath);
-    const seed = o.seed ? Buffer.from(o.seed) : Buffer.alloc(32);
+    const seed = o.seed ? Buffer.from(o.seed) : crypto.randomBytes(32);
     if (seed.length !== 32) throw new RangeError('seed must be 32 bytes');
-    this.handle = native.createContext(seed, o.device || 0, o.params || PARAMS.PRIME_BSK);
+    this.handle = native.createContext(seed, o.device || 0, o.params || PARAMS.PRIME_BSK_GROUPED);
     if (o.keygen !== false) native.keygen(this.handle);
   }
 

@@ -1,5 +1,7 @@
 // C ABI (include/lfhe.h): context, keys, the bootstrap path and its stages.  The integer operators
 // (lfhe_encrypt ... lfhe_evaluate_batch) live in radix.cpp.
+#include <sys/random.h>
+
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
@@ -43,6 +45,16 @@ int host_threads() {
     return (int)(hc > 16 ? 16 : hc);
 }
 
+// 32 bytes from the operating system's generator
+void os_entropy(uint8_t out[32]) {
+    size_t got = 0;
+    while (got < 32) {
+        const ssize_t r = getrandom(out + got, 32 - got, 0);
+        if (r <= 0) throw std::runtime_error("getrandom failed: no entropy for keys and encryptions");
+        got += (size_t)r;
+    }
+}
+
 void require_server(lfhe_ctx* c) {
     if (!c->eng->has_keys()) throw std::logic_error("server keys not loaded: call lfhe_keygen or an import first");
 }
@@ -72,7 +84,7 @@ void lfhe_default_params(lfhe_params* p) {
 }
 
 int32_t lfhe_ctx_create_custom(lfhe_ctx** out, const lfhe_params* p, int32_t device, const uint8_t seed[32]) {
-    if (!out || !p || !seed) return LFHE_ERR_ARG;
+    if (!out || !p) return LFHE_ERR_ARG;
     *out = nullptr;
     lfhe_ctx* c = new (std::nothrow) lfhe_ctx();
     if (!c) return LFHE_ERR_DEVICE;
@@ -85,10 +97,17 @@ int32_t lfhe_ctx_create_custom(lfhe_ctx** out, const lfhe_params* p, int32_t dev
     c->prm.ms_r_sigma_factor = p->ms_r_sigma_factor; c->prm.ms_input_variance = p->ms_input_variance;
     c->prm.bsk_modulus = p->bsk_modulus;
     c->prm.bsk_grouping = p->bsk_grouping ? p->bsk_grouping : 1;
-    std::memcpy(c->seed, seed, 32);
-    c->enc_rng.init(seed, 16);
     int32_t rc = LFHE_OK;
     try {
+        // Keys come from `seed` (null: from the operating system).  Encryption randomness never
+        // does: a restarted server with the same key seed must not hand out the same masks and
+        // noise again, so its generator starts from fresh entropy unless lfhe_encryption_reseed
+        // asks for a reproducible stream.
+        if (seed) std::memcpy(c->seed, seed, 32);
+        else os_entropy(c->seed);
+        uint8_t fresh[32];
+        os_entropy(fresh);
+        c->enc_rng.init(fresh, 16);
         if (p->message_modulus != 4 || p->carry_modulus != 4)
             throw std::invalid_argument("unsupported parameters: message_modulus and carry_modulus must be 4");
         c->eng.reset(new Engine(device, c->prm));
@@ -120,6 +139,23 @@ int32_t lfhe_ctx_create(lfhe_ctx** out, uint32_t params_id, int32_t device, cons
 }
 
 void lfhe_ctx_destroy(lfhe_ctx* ctx) { delete ctx; }
+
+int32_t lfhe_encryption_reseed(lfhe_ctx* ctx, const uint8_t seed[32]) {
+    return guarded(ctx, [&]() -> int32_t {
+        uint8_t fresh[32];
+        if (!seed) os_entropy(fresh);
+        ctx->enc_rng.init(seed ? seed : fresh, 16);
+        return LFHE_OK;
+    });
+}
+
+uint64_t lfhe_arena_chunk(uint64_t budget_bytes, uint64_t instance_bytes) {
+    // the scatter / gather launches index instances with the grid's second dimension (65535 at most)
+    const uint64_t grid_limit = 65535;
+    uint64_t cap = budget_bytes / (instance_bytes ? instance_bytes : 1);
+    if (cap > grid_limit) cap = grid_limit;
+    return cap ? cap : 1;
+}
 
 const char* lfhe_last_error(const lfhe_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
@@ -268,22 +304,32 @@ int32_t lfhe_keys_import(lfhe_ctx* ctx, uint32_t which, const uint8_t* in, uint6
     std::memcpy(&h, in, sizeof h);
     lfhe_params mine;
     lfhe_get_params(ctx, &mine);
-    if (h.magic != KEY_MAGIC || h.which != which || std::memcmp(&h.prm, &mine, sizeof mine) != 0 ||
-        len != sizeof h + (h.words_a + h.words_b + h.words_c) * 8) {
+    // The word counts are caller data: each is compared with what this context's parameter set
+    // prescribes for `which` before anything is summed, multiplied or allocated.
+    uint64_t want_a, want_b, want_c;
+    if (which == LFHE_KEY_CLIENT) {
+        want_a = ctx->prm.lwe_dim; want_b = (uint64_t)N; want_c = 0;
+    } else if (which == LFHE_KEY_SERVER) {
+        want_a = ctx->eng->bsk_raw_words(); want_b = ctx->eng->ksk_words(); want_c = ctx->eng->ms_zeros_words();
+    } else {
+        ctx->err = "unknown key kind";
+        return LFHE_ERR_ARG;
+    }
+    const bool counts_ok = h.words_a == want_a && h.words_b == want_b && (h.words_c == want_c || h.words_c == 0);
+    if (h.magic != KEY_MAGIC || h.which != which || std::memcmp(&h.prm, &mine, sizeof mine) != 0 || !counts_ok ||
+        (len - sizeof h) % 8 != 0 || (len - sizeof h) / 8 != h.words_a + h.words_b + h.words_c) {
         ctx->err = "key blob does not match this context";
         return LFHE_ERR_FORMAT;
     }
-    const uint64_t* a = reinterpret_cast<const uint64_t*>(in + sizeof h);
-    std::vector<uint64_t> va(h.words_a), vb(h.words_b), vc(h.words_c);
-    std::memcpy(va.data(), a, h.words_a * 8);
-    std::memcpy(vb.data(), in + sizeof h + h.words_a * 8, h.words_b * 8);
-    if (h.words_c) std::memcpy(vc.data(), in + sizeof h + (h.words_a + h.words_b) * 8, h.words_c * 8);
-    if (which == LFHE_KEY_CLIENT) {
-        if (h.words_a != ctx->prm.lwe_dim || h.words_b != (uint64_t)N) { ctx->err = "bad client key size"; return LFHE_ERR_FORMAT; }
-        return lfhe_client_keys_import_raw(ctx, va.data(), vb.data());
-    }
-    return lfhe_server_keys_import_raw(ctx, va.data(), va.size(), vb.data(), vb.size(), vc.empty() ? nullptr : vc.data(),
-                                       vc.size());
+    return guarded(ctx, [&]() -> int32_t {
+        std::vector<uint64_t> va(h.words_a), vb(h.words_b), vc(h.words_c);
+        std::memcpy(va.data(), in + sizeof h, h.words_a * 8);
+        std::memcpy(vb.data(), in + sizeof h + h.words_a * 8, h.words_b * 8);
+        if (h.words_c) std::memcpy(vc.data(), in + sizeof h + (h.words_a + h.words_b) * 8, h.words_c * 8);
+        if (which == LFHE_KEY_CLIENT) return lfhe_client_keys_import_raw(ctx, va.data(), vb.data());
+        return lfhe_server_keys_import_raw(ctx, va.data(), va.size(), vb.data(), vb.size(),
+                                           vc.empty() ? nullptr : vc.data(), vc.size());
+    });
 }
 
 int32_t lfhe_device_keys_size(const lfhe_ctx* ctx, uint64_t* bsk_bytes, uint64_t* ksk_bytes) {

@@ -299,7 +299,13 @@ void Engine::keyswitch(const u64* lwe_in, u64* lwe_small_out, size_t count, cons
         }
         return;
     }
-    const size_t need = keyswitch_scratch_words(count, N);
+    // the grid's second dimension counts groups of sixteen ciphertexts and ends at 65535: longer
+    // batches go in several launches, a whole number of program instances each
+    if (imap.idx && !imap.ops) throw std::logic_error("block map without a period");
+    size_t chunk = ks_valu_max_count();
+    if (imap.idx) chunk = imap.ops >= chunk ? imap.ops : chunk / imap.ops * imap.ops;
+    if (chunk > count) chunk = count;
+    const size_t need = keyswitch_scratch_words(chunk, N);
     if (need > ksdig_cap_) {
         HC(hipStreamSynchronize(stream_));
         (void)hipFree(d_ksdig_);
@@ -307,9 +313,13 @@ void Engine::keyswitch(const u64* lwe_in, u64* lwe_small_out, size_t count, cons
         HC(hipMalloc(&d_ksdig_, need * sizeof(u32)));
         ksdig_cap_ = need;
     }
-    launch_keyswitch(key, key + ksk_words(), lwe_in, d_ksdig_, lwe_small_out, count, N, (int)prm_.lwe_dim,
-                     (int)prm_.ks_base_log, (int)prm_.ks_level, imap, stream_);
-    HC(hipGetLastError());
+    for (size_t c0 = 0; c0 < count; c0 += chunk) {
+        const size_t cnt = count - c0 < chunk ? count - c0 : chunk;
+        const u64* in = lwe_in + (imap.idx ? (c0 / imap.ops) * imap.inst_stride : c0) * (size_t)(N + 1);
+        launch_keyswitch(key, key + ksk_words(), in, d_ksdig_, lwe_small_out + c0 * (prm_.lwe_dim + 1), cnt, N,
+                         (int)prm_.lwe_dim, (int)prm_.ks_base_log, (int)prm_.ks_level, imap, stream_);
+        HC(hipGetLastError());
+    }
 }
 
 void Engine::pbs_layer(u64* arena, size_t instances, size_t inst_stride_blocks, const u32* in_idx, const u32* out_idx,

@@ -68,6 +68,7 @@ void launch_ksk_colsum(const u64* ksk, int rows, int cols, int half_base, u64* c
 void launch_keyswitch(const u64* ksk, const u64* colsum, const u64* in, u32* dig_scratch, u64* out, size_t count,
                       int big, int n, int base_log, int levels, const BlockMap& imap, hipStream_t st);
 size_t keyswitch_scratch_words(size_t count, int big);
+size_t ks_valu_max_count();   // ciphertexts one launch_keyswitch call can take (grid limit)
 // the same key switch as an int8 matrix product on the matrix cores (ks_mfma.hip), for large batches
 bool ksm_supported(int big, int levels, int n);
 size_t ksm_limb_bytes(int big, int levels, int n);            // key image: eight signed bytes per key word

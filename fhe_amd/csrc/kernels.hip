@@ -1154,6 +1154,7 @@ void launch_keyswitch(const u64* ksk, const u64* colsum, const u64* in, u32* dig
         default: hipLaunchKernelGGL(k_keyswitch<4>, grid, dim3(256), 0, st, ksk, colsum, in, dig_scratch, out, (int)count, big, n, imap); break;
     }
 }
+size_t ks_valu_max_count() { return (size_t)65535 * KS_CT; }
 size_t keyswitch_scratch_words(size_t count, int big) { return ((count + KS_CT - 1) / KS_CT) * KS_CT * (size_t)big; }
 
 // ------------------------------------------------------------------------------------------------

@@ -111,8 +111,7 @@ uint64_t arena_capacity(size_t inst_bytes) {
     HC(hipMemGetInfo(&free_b, &total_b));
     uint64_t budget = free_b / 2;
     if (const char* e = std::getenv("LFHE_ARENA_BYTES")) budget = std::strtoull(e, nullptr, 10);
-    const uint64_t cap = budget / (inst_bytes ? inst_bytes : 1);
-    return cap ? cap : 1;
+    return lfhe_arena_chunk(budget, inst_bytes);
 }
 
 // descriptors and tables of a program to the device
@@ -183,10 +182,14 @@ void cast_one(lfhe_ctx* ctx, const uint8_t* in, uint64_t in_len, uint32_t to_wid
     if (in_len < sizeof(CtHeader)) throw std::invalid_argument("ciphertext too short");
     CtHeader h;
     std::memcpy(&h, in, sizeof h);
-    if (h.magic != CT_MAGIC || !width_ok(h.bit_width) || in_len != ct_bytes(h.bit_width))
+    // the header is caller data: the block count that is copied comes from the width the length was
+    // checked against, never from the header's own field
+    if (h.magic != CT_MAGIC || h.version != 1 || !width_ok(h.bit_width) || h.nblocks != blocks_of(h.bit_width) ||
+        in_len != ct_bytes(h.bit_width))
         throw std::invalid_argument("malformed ciphertext");
+    if (h.noise_level < 1 || h.noise_level > 2 || h.degree > 3) throw std::invalid_argument("ciphertext metadata out of range");
     if (to_width == 1 && h.bit_width != 1) throw std::invalid_argument("cast to ebool: use ne(x, 0)");
-    const uint32_t nb = blocks_of(to_width), have = std::min(nb, (uint32_t)h.nblocks);
+    const uint32_t nb = blocks_of(to_width), have = std::min(nb, blocks_of(h.bit_width));
     CtHeader o{CT_MAGIC, 1, (uint16_t)to_width, nb, h.noise_level, h.degree, 0};
     std::memcpy(out, &o, sizeof o);
     std::memcpy(out + sizeof o, in + sizeof h, (size_t)have * BLK_BYTES);

@@ -87,6 +87,8 @@ def load():
         "lfhe_ctx_create": (i32, [C.POINTER(vp), u32, i32, C.c_char_p]),
         "lfhe_ctx_create_custom": (i32, [C.POINTER(vp), C.POINTER(Params), i32, C.c_char_p]),
         "lfhe_ctx_destroy": (None, [vp]),
+        "lfhe_encryption_reseed": (i32, [vp, C.c_char_p]),
+        "lfhe_arena_chunk": (u64, [u64, u64]),
         "lfhe_last_error": (C.c_char_p, [vp]),
         "lfhe_get_params": (i32, [vp, C.POINTER(Params)]),
         "lfhe_health": (i32, [vp, C.c_char_p, pu64]),
@@ -194,10 +196,17 @@ class Context:
 
     N = 2048
 
-    def __init__(self, seed: bytes = bytes(32), device: int = 0, params: Params | None = None,
+    def __init__(self, seed: bytes | None = None, device: int = 0, params: Params | None = None,
                  params_id: int = PARAMS_DEFAULT):
+        """seed: 32 bytes the keys are derived from (as secret as the keys; fixed seeds are for tests),
+        or None for operating-system entropy.  Encryption randomness is fresh in every context
+        whatever the seed; `reseed_encryption` makes it reproducible."""
         self._L = load()
         self._h = C.c_void_p()
+        if seed is None:
+            seed = os.urandom(32)
+        if len(seed) != 32:
+            raise ValueError("seed must be 32 bytes")
         if params is None:
             rc = self._L.lfhe_ctx_create(C.byref(self._h), params_id, device, seed)
         else:
@@ -227,6 +236,13 @@ class Context:
     def _ck(self, rc: int):
         if rc != LFHE_OK:
             raise LfheError(rc, self._L.lfhe_last_error(self._h).decode())
+
+    def reseed_encryption(self, seed: bytes | None = None):
+        """Restart the encryption generator from `seed` (reproducible ciphertexts: tests only) or,
+        with None, from operating-system entropy."""
+        if seed is not None and len(seed) != 32:
+            raise ValueError("seed must be 32 bytes")
+        self._ck(self._L.lfhe_encryption_reseed(self._h, seed))
 
     # ---- keys
     def keygen(self):
@@ -362,6 +378,15 @@ class Context:
             return np.ascontiguousarray(col, dtype=np.uint8).reshape(-1)
         return np.frombuffer(b"".join(col), dtype=np.uint8)
 
+    def _sized_column(self, col, n: int, bit_width: int, what: str) -> np.ndarray:
+        """A column of n ciphertexts of one width.  The C entry points take no lengths and read
+        n * ciphertext_size(width) bytes: the length is checked here."""
+        a = self._column(col)
+        want = n * self.ciphertext_size(bit_width)
+        if a.size != want:
+            raise ValueError(f"{what}: {a.size} bytes for {n} ciphertexts of width {bit_width}, expected {want}")
+        return a
+
     @staticmethod
     def _rows(flat: np.ndarray, n: int, sz: int, as_array: bool):
         if as_array:
@@ -375,14 +400,16 @@ class Context:
         n = len(lhs)
         as_array = isinstance(lhs, np.ndarray)
         scalar = rhs is not None and len(rhs) > 0 and isinstance(rhs[0], int)
-        A = self._column(lhs)
+        A = self._sized_column(lhs, n, bit_width, "lhs")
         if rhs is None:
             B = None
         elif scalar:
+            if len(rhs) != n:
+                raise ValueError(f"rhs: {len(rhs)} clear operands for {n} instances")
             B = np.frombuffer(b"".join(le32(v % (1 << 256)) for v in rhs), dtype=np.uint8)
-        else:
-            B = self._column(rhs)
-        Cn = None if cond is None else self._column(cond)
+        else:   # shift and rotation amounts are euint8
+            B = self._sized_column(rhs, n, 8 if op in ("shl", "shr", "rotl", "rotr") else bit_width, "rhs")
+        Cn = None if cond is None else self._sized_column(cond, n, 1, "cond")
         out_w = 1 if op in COMPARISONS else bit_width
         sz = self.ciphertext_size(out_w)
         out = np.empty(n * sz, dtype=np.uint8)   # every byte is written by the library
@@ -410,7 +437,9 @@ class Context:
         arr = make_steps(steps)
         w = (C.c_uint32 * len(in_widths))(*in_widths)
         o = (C.c_int32 * len(outputs))(*outputs)
-        ins = [self._column(col) for col in inputs]
+        if len(inputs) != len(in_widths):
+            raise ValueError("one width per input")
+        ins = [self._sized_column(col, n, wd, f"input {i}") for i, (col, wd) in enumerate(zip(inputs, in_widths))]
         in_ptrs = (C.c_void_p * len(ins))(*[a.ctypes.data for a in ins])
         sizes = [self.ciphertext_size(x) for x in out_widths]
         outs = [np.empty(n * sz, dtype=np.uint8) for sz in sizes]   # every byte is written by the library

@@ -29,7 +29,11 @@ WIDTHS = (1, 8, 16, 32, 64, 128, 160, 256)
 class GpuBackend:
     """liblfhe behind the HTTP surface: one context, requests serialised on it."""
 
-    def __init__(self, seed: bytes = bytes(32), device: int = 0, params_id: int = 1):
+    def __init__(self, seed: bytes | None = None, device: int = 0, params_id: int = 3):
+        """seed: 32 bytes the server's keys derive from, or None (the default) for
+        operating-system entropy -- a fixed seed means a secret key anyone with the seed can
+        compute, so it is for tests and reproducible set-ups only.  params_id 3 is the grouped
+        bootstrapping key, the default of every entry point (include/lfhe.h)."""
         from .native import Context
         self.ctx = Context(seed=seed, device=device, params_id=params_id)
         self.ctx.keygen()
@@ -199,11 +203,19 @@ def main(argv=None):
     ap.add_argument("--bootstrapping-key", choices=["q64", "prime", "grouped"], default="grouped",
                     help="server-side bootstrapping key (include/lfhe.h parameter set ids 1, 2, 3): over 2^64, over the "
                          "NTT prime, or over the prime with the key bits in pairs (fastest); clients see no difference")
+    ap.add_argument("--seed-hex", default=None,
+                    help="64 hex digits the keys are derived from (reproducible set-ups only: whoever knows the "
+                         "seed knows the secret key); default: operating-system entropy")
     args = ap.parse_args(argv)
+    seed = None
+    if args.seed_hex is not None:
+        seed = bytes.fromhex(args.seed_hex)
+        if len(seed) != 32:
+            raise SystemExit("--seed-hex needs 64 hex digits")
     if args.threshold:
         raise SystemExit("threshold decryption is outside this backend's scope: run without -threshold")
     params_id = {"q64": 1, "prime": 2, "grouped": 3}[args.bootstrapping_key]
-    srv = serve(GpuBackend(device=args.device, params_id=params_id), args.addr, False, args.parties)
+    srv = serve(GpuBackend(seed=seed, device=args.device, params_id=params_id), args.addr, False, args.parties)
     print(f"fhe-server (gfx950) listening on {args.addr}")
     srv.serve_forever()
 

@@ -85,12 +85,21 @@ void lfhe_default_params(lfhe_params* p);
 
 /* ---- context ------------------------------------------------------------------------------------
  * Replaces: engine process start-up (`fhe-server -addr :8448`, e2e/scripts/start-server.sh:17;
- * local-dev/docker-compose.yml:29).  `seed` drives every random draw of the context. */
+ * local-dev/docker-compose.yml:29).  `seed` drives key generation (lfhe_keygen and the keys derived
+ * from it): the same seed gives the same keys, so it is as secret as they are; NULL takes 32 bytes
+ * from the operating system.  Encryption masks and noise are NOT derived from it: their generator
+ * starts from operating-system entropy in every context (see lfhe_encryption_reseed). */
 int32_t lfhe_ctx_create(lfhe_ctx** out, uint32_t params_id, int32_t device, const uint8_t seed[32]);
 /* same with explicit numbers (the kernels need N = 2048, k = 1, one PBS level of base 2^23; the
  * LWE dimension and the key-switch decomposition are free) */
 int32_t lfhe_ctx_create_custom(lfhe_ctx** out, const lfhe_params* p, int32_t device, const uint8_t seed[32]);
 void lfhe_ctx_destroy(lfhe_ctx* ctx);
+/* Restart the generator behind lfhe_encrypt / lfhe_encrypt_public: from `seed` (reproducible
+ * ciphertexts, for tests and known-answer vectors only -- two ciphertexts made from one stream
+ * position reveal the difference of their plaintexts), or from fresh operating-system entropy when
+ * seed is NULL.  Replaces: the seeder a tfhe-rs client installs before encrypting
+ * (ml/extensions/rust/src/lib_wasm.rs:77-136 JsSeeder; ml/extensions/tests/test_random_seed.py). */
+int32_t lfhe_encryption_reseed(lfhe_ctx* ctx, const uint8_t seed[32]);
 const char* lfhe_last_error(const lfhe_ctx* ctx);
 int32_t lfhe_get_params(const lfhe_ctx* ctx, lfhe_params* out);
 /* Replaces: GET /health (e2e/test/fhe.test.ts:31-37).  Writes a NUL-terminated JSON object
@@ -206,6 +215,11 @@ int32_t lfhe_evaluate(lfhe_ctx* ctx, uint32_t op, uint32_t bit_width, const uint
  * is lfhe_ciphertext_size of its width (cond: width 1); scalars are 32 bytes each. */
 int32_t lfhe_evaluate_batch(lfhe_ctx* ctx, uint32_t op, uint32_t bit_width, uint64_t n, const uint8_t* lhs,
                             const uint8_t* rhs, int32_t rhs_is_scalar, const uint8_t* cond, uint8_t* out);
+/* Instances per pass of lfhe_evaluate_batch / lfhe_evaluate_fused: a batch larger than this runs in
+ * passes.  budget_bytes: device memory the arena may take; instance_bytes: arena bytes of one
+ * instance.  The result never exceeds the 65535 instances one scatter / gather launch can index.
+ * Host logic only (no context, no GPU). */
+uint64_t lfhe_arena_chunk(uint64_t budget_bytes, uint64_t instance_bytes);
 /* Several operations as ONE schedule.  Values are numbered: 0 .. n_inputs-1 are the inputs,
  * n_inputs + k is the result of step k; a step names its operands by number (-1: unused) or carries
  * a clear right operand.  Intermediate results never leave the GPU and independent steps share

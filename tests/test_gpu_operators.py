@@ -44,37 +44,54 @@ def _operands(ctx, k):
     return op, w, lhs, rhs, exp
 
 
-def _sample():
-    """Two vectors per (operator, type pair) among widths <= 64, every same-width euint64 case."""
-    seen, out = {}, []
+def _groups():
+    """Every reference vector, grouped into batches of one shape: (operator, working width, which
+    operands are encrypted).  A group is one `evaluate_batch` call."""
+    groups = {}
     for k in KATS:
         op, w, ins, exp = radix.kat_case(k)
-        if op not in GPU_OPS or w > 64:
-            continue
-        key = (op, tuple(k["types"]))
-        full = all(t == "euint64" for t in k["types"])
-        if seen.get(key, 0) < (4 if full else 1):
-            seen[key] = seen.get(key, 0) + 1
-            out.append(k)
-    return out
+        assert op in GPU_OPS, op
+        enc = tuple(t.startswith("e") for t in k["types"])
+        if op in SPECIALISED:
+            w = radix.type_width(k["types"][0])
+        groups.setdefault((op, w, enc), []).append((k, ins, exp))
+    return groups
 
 
-def test_reference_operator_vectors(ctx):
-    ks = _sample()
-    assert len(ks) > 300
+def test_every_reference_operator_vector(ctx):
+    """All 2394 decrypted-result vectors of tests/fhevm-suite/e2e/test/fhevmOperations/
+    fhevmOperations1..13.ts (every overload, euint8 ... euint256, encrypted, clear-right and
+    clear-left operands), end to end on the GPU: encrypt -> evaluate_batch -> decrypt."""
+    groups = _groups()
+    assert sum(len(v) for v in groups.values()) == len(KATS) == 2394
     t0 = time.time()
     n0 = ctx.pbs_count()
-    for k in ks:
-        op, w, lhs, rhs, exp = _operands(ctx, k)
-        got = ctx.decrypt(ctx.evaluate(op, w, lhs, rhs))
-        assert got == exp, k
-    print(f"{len(ks)} reference vectors, {ctx.pbs_count() - n0} bootstraps, {time.time() - t0:.1f} s")
+    for (op, w, enc), cases in sorted(groups.items()):
+        lhs = [ctx.encrypt(ins[0], w, trivial=not enc[0]) for _, ins, _ in cases]
+        rhs = None
+        if len(enc) > 1:
+            if not enc[1]:
+                rhs = [ins[1] for _, ins, _ in cases]                     # clear right operands
+            else:                                                         # shift amounts are euint8
+                rhs = [ctx.encrypt(ins[1], 8 if op in SPECIALISED else w) for _, ins, _ in cases]
+        out = ctx.evaluate_batch(op, w, lhs, rhs)
+        got = [ctx.decrypt(o) for o in out]
+        for (k, _, exp), g in zip(cases, got):
+            assert g == exp, (k, g)
+    print(f"{len(KATS)} reference vectors in {len(groups)} batches, {ctx.pbs_count() - n0} bootstraps, "
+          f"{time.time() - t0:.1f} s")
 
 
-def test_wide_types(ctx):
-    for k in [k for k in KATS if k["op"] in ("add", "eq", "and") and radix.kat_case(k)[1] in (128, 256)][:6]:
+def test_single_evaluate_on_one_vector_per_operator(ctx):
+    """The one-operation entry point (POST /evaluate's shape) on the first vector of every operator."""
+    seen = set()
+    for k in KATS:
+        if k["op"] in seen or radix.kat_case(k)[1] > 64:
+            continue
+        seen.add(k["op"])
         op, w, lhs, rhs, exp = _operands(ctx, k)
         assert ctx.decrypt(ctx.evaluate(op, w, lhs, rhs)) == exp, k
+    assert seen == GPU_OPS
 
 
 def test_select_vectors_and_noise_tracking(ctx):
@@ -219,6 +236,71 @@ def test_long_batches_cut_into_several_launches_give_the_same_bits(params_id):
     finally:
         ref.close()
         cut.close()
+
+
+def test_forged_headers_and_short_columns_are_refused(ctx):
+    """Ciphertext headers and column lengths are caller data."""
+    import struct
+    from fhe_amd.native import LfheError
+    a8 = ctx.encrypt(0x5A, 8)
+    # a header that claims 128 blocks in front of an 8-bit ciphertext's 4: the cast must not read past the input
+    magic, version, width, nblocks, noise, degree, rsv = struct.unpack("<IHHIBBH", a8[:16])
+    assert (width, nblocks) == (8, 4)
+    forged = struct.pack("<IHHIBBH", magic, version, width, 128, noise, degree, rsv) + a8[16:]
+    with pytest.raises(LfheError):
+        ctx.evaluate("cast", 256, forged)
+    with pytest.raises(LfheError):
+        ctx.evaluate("cast", 256, struct.pack("<IHHIBBH", magic, 7, width, nblocks, noise, degree, rsv) + a8[16:])
+    assert ctx.decrypt(ctx.evaluate("cast", 256, a8)) == 0x5A
+    # the batch entry points take no lengths: the binding checks every column against n and the width
+    a16 = ctx.encrypt(3, 16)
+    with pytest.raises(ValueError):
+        ctx.evaluate_batch("add", 16, [a16, a16], [a16, a8])
+    with pytest.raises(ValueError):
+        ctx.evaluate_batch("add", 16, [a16, a16], [1])
+    with pytest.raises(ValueError):
+        ctx.evaluate_batch("select", 16, [a16], [a16], [a8])
+    with pytest.raises(ValueError):
+        ctx.evaluate_fused([("add", 16, 0, 1, None)], [16, 16], [[a16], [a8]], [2], [16])
+    # key blobs: counts that overflow, or that do not match the parameter set, are a format error
+    from fhe_amd.native import KEY_CLIENT, KEY_SERVER
+    blob = bytearray(ctx.export_keys(KEY_CLIENT))
+    hdr = len(blob) - (918 + 2048) * 8
+    bad = bytes(blob[:hdr - 24]) + struct.pack("<QQQ", 1 << 61, 0, 0)
+    with pytest.raises(LfheError) as e:
+        ctx.import_keys(KEY_CLIENT, bad)
+    assert e.value.code == -6
+    with pytest.raises(LfheError) as e:
+        ctx.import_keys(KEY_SERVER, bytes(blob))
+    assert e.value.code == -6
+    ctx.import_keys(KEY_CLIENT, bytes(blob))
+
+
+def test_encryption_randomness_is_fresh_unless_reseeded():
+    """Two contexts made from one key seed hold the same keys but never hand out the same masks;
+    a reseeded generator is reproducible (tests and known-answer vectors only)."""
+    from fhe_amd.native import Context, KEY_CLIENT
+    seed = bytes(range(32))
+    a, b = Context(seed=seed, params_id=3), Context(seed=seed, params_id=3)
+    try:
+        a.keygen()
+        blob = a.export_keys(KEY_CLIENT)
+        b.import_keys(KEY_CLIENT, blob)
+        ca, cb = a.encrypt(77, 16), b.encrypt(77, 16)
+        assert ca != cb and ca[16:48] != cb[16:48]
+        assert b.decrypt(ca) == 77 and a.decrypt(cb) == 77
+        a.reseed_encryption(bytes(32))
+        b.reseed_encryption(bytes(32))
+        assert a.encrypt(77, 16) == b.encrypt(77, 16)
+        a.reseed_encryption()
+        b.reseed_encryption()
+        assert a.encrypt(77, 16) != b.encrypt(77, 16)
+        # no seed at all: keys from operating-system entropy
+        c = Context(params_id=3)
+        c.close()
+    finally:
+        a.close()
+        b.close()
 
 
 def test_error_paths(ctx):

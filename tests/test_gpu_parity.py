@@ -426,7 +426,7 @@ def test_library_keygen_round_trip(params_id):
         ctx.close()
 
 
-@pytest.mark.parametrize("params_id", [2, 3], ids=["bsk_prime", "bsk_prime_grouped"])
+@pytest.mark.parametrize("params_id", [1, 2, 3], ids=["bsk_q64", "bsk_prime", "bsk_prime_grouped"])
 def test_full_size_batch_properties(params_id):
     """The benchmark's configuration (4096 blocks, 16 distinct tables) through size-independent
     properties: every output decrypts to f(m); a second pass gives the same bits (no dependence on

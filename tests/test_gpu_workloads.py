@@ -1,0 +1,81 @@
+"""The operator workloads of the benchmark configurations on real ciphertexts, through the C ABI:
+the blind-auction argmax (a tournament of gt + select over encrypted euint32 bids with encrypted
+euint16 indices) and batched ERC20 transfers, checked against the clear computation."""
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=[1, 3], ids=["bsk_q64", "bsk_prime_grouped"])
+def ctx(request):
+    from fhe_amd.native import Context
+    c = Context(seed=bytes(range(32)), params_id=request.param)
+    c.keygen()
+    yield c
+    c.close()
+
+
+def _column(ctx, values, width):
+    return np.stack([np.frombuffer(ctx.encrypt(v, width), dtype=np.uint8) for v in values])
+
+
+@pytest.mark.parametrize("n", [64, 37, 1])
+def test_argmax_tournament(ctx, n):
+    """Power-of-two, ragged and single-entry tournaments; byte-array columns (the form the benchmark uses)."""
+    from fhe_amd import workloads
+    rnd = random.Random(100 + n)
+    bids = rnd.sample(range(1 << 32), n)
+    val, idx = workloads.argmax(ctx, _column(ctx, bids, 32), _column(ctx, range(n), 16))
+    assert (ctx.decrypt(bytes(val)), ctx.decrypt(bytes(idx))) == (max(bids), bids.index(max(bids)))
+
+
+def test_argmax_of_one_thousand_bids_and_its_two_shard_form():
+    """The blind-auction configuration at full size (1000 distinct euint32 bids, 10 levels), as one
+    tournament and as the sharded form (two slices reduced separately, winners reduced again)."""
+    from fhe_amd import workloads
+    from fhe_amd.native import Context
+    from fhe_amd.sharding import shard_bounds
+    ctx = Context(seed=bytes(range(32)), params_id=3)
+    try:
+        ctx.keygen()
+        rnd = random.Random(7)
+        n = 1000
+        bids = rnd.sample(range(1 << 32), n)
+        V, I = _column(ctx, bids, 32), _column(ctx, range(n), 16)
+        n0 = ctx.pbs_count()
+        val, idx = workloads.argmax(ctx, V, I)
+        want = (max(bids), bids.index(max(bids)))
+        assert (ctx.decrypt(bytes(val)), ctx.decrypt(bytes(idx))) == want
+        print(f"argmax of {n} bids: {ctx.pbs_count() - n0} bootstraps")
+        winners = []
+        for r in range(2):
+            lo, hi = shard_bounds(n, 2, r)
+            winners.append(workloads.sharded_argmax(None, ctx, V[lo:hi], I[lo:hi], 0, 1, local=True))
+        val2, idx2 = workloads.argmax(ctx, [bytes(w[0]) for w in winners], [bytes(w[1]) for w in winners])
+        assert (ctx.decrypt(val2), ctx.decrypt(idx2)) == want
+        # ties: equal bids keep a well-defined winner (the tournament's left entry needs a strictly greater value)
+        tied = [5, 9, 9, 3]
+        v, i = workloads.argmax(ctx, _column(ctx, tied, 32), _column(ctx, range(4), 16))
+        assert ctx.decrypt(bytes(v)) == 9 and ctx.decrypt(bytes(i)) in (1, 2)
+    finally:
+        ctx.close()
+
+
+def test_batched_transfers_against_the_clear_ledger(ctx):
+    """A batch of independent transfers, about half with an amount above the balance
+    (tests/fhevm-suite/e2e/contracts/EncryptedERC20.sol:87-93, 208-220)."""
+    from fhe_amd import workloads
+    rnd = random.Random(21)
+    n = 48
+    frm = [rnd.randrange(1 << 64) for _ in range(n)]
+    amt = [rnd.randrange(f + 1) if i % 2 else min((1 << 64) - 1, f + 1 + rnd.randrange(1 << 20)) for i, f in enumerate(frm)]
+    to = [rnd.randrange(1 << 64) for _ in range(n)]
+    nf, nt = workloads.transfers(ctx, _column(ctx, frm, 64), _column(ctx, to, 64), _column(ctx, amt, 64),
+                                 ctx.encrypt(0, 64, trivial=True))
+    moved = [a if a <= f else 0 for a, f in zip(amt, frm)]
+    assert [ctx.decrypt(bytes(c)) for c in nf] == [f - v for f, v in zip(frm, moved)]
+    assert [ctx.decrypt(bytes(c)) for c in nt] == [(t + v) & ((1 << 64) - 1) for t, v in zip(to, moved)]
+    assert any(moved) and not all(moved)

@@ -46,6 +46,22 @@ def test_context_free_entry_points():
     assert L.lfhe_last_error(None) == b"null context"
 
 
+def test_arena_chunk_respects_memory_and_the_grid_limit():
+    """Instances per pass of a batched operator: bounded by the arena budget AND by the 65535
+    instances one scatter / gather launch can index, so n > 65535 runs in passes instead of failing
+    at launch."""
+    from fhe_amd import native
+    L = native.load()
+    blk = 2049 * 8
+    assert L.lfhe_arena_chunk(100 * 40 * blk, 40 * blk) == 100
+    assert L.lfhe_arena_chunk(0, 40 * blk) == 1                      # always at least one instance
+    assert L.lfhe_arena_chunk(1 << 37, 4 * blk) == 65535             # 128 GiB would hold two million euint8
+    n = 200_000
+    cap = L.lfhe_arena_chunk(1 << 37, 4 * blk)
+    passes = [(off, min(cap, n - off)) for off in range(0, n, cap)]
+    assert len(passes) == 4 and sum(c for _, c in passes) == n and max(c for _, c in passes) <= 65535
+
+
 def test_shard_bounds_cover_everything():
     from fhe_amd.sharding import shard_bounds
     for total in (0, 1, 7, 4096, 10000):
