@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "liblfhe.so")
-SOURCES = ["kernels.hip", "ks_mfma.hip", "engine.cpp", "host_tfhe.cpp", "api.cpp", "radix.cpp", "radix_program.cpp"]
+SOURCES = ["kernels.hip", "ks_mfma.hip", "noalloc.hip", "engine.cpp", "host_tfhe.cpp", "api.cpp", "radix.cpp", "radix_program.cpp"]
 HEADERS = ["pbs_device.h", "pbs_phases.h", "ms_noise.h", "tables.h", "engine.h", "host_tfhe.h", "ctx.h", "radix_program.h",
            os.path.join("..", "..", "include", "lfhe.h")]
 

@@ -1,5 +1,6 @@
 #include "engine.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <stdexcept>
@@ -34,6 +35,9 @@ Engine::Engine(int device, const EngineParams& p) : device_(device), prm_(p) {
     HC(hipGetDeviceCount(&ndev));
     if (ndev <= 0) throw std::runtime_error("no HIP device: the HIP path is the only path");
     if (device < 0 || device >= ndev) throw std::runtime_error("device index out of range");
+    HC(hipSetDevice(device_));
+    noalloc_setup(device_);
+    blind_rotate_setup(device_);
     HC(hipSetDevice(device_));
     HC(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     hipDeviceProp_t prop;
@@ -270,53 +274,72 @@ void Engine::cast_batch(const u64* lwe_in, const u64* identity_lut, u64* lwe_out
     blind_rotate(small, identity_lut, nullptr, nullptr, lwe_out, count);
 }
 
-void Engine::keyswitch(const u64* lwe_in, u64* lwe_small_out, size_t count, const BlockMap& imap, bool with_cast_key) {
+void Engine::keyswitch(const u64* lwe_in, u64* lwe_small_out, size_t count, const BlockMap& imap, bool with_cast_key,
+                       const PbsScratch* ext) {
     const u64* key = with_cast_key ? d_cast_ksk_ : d_ksk_;
     if (!key) throw std::runtime_error("no key-switching key loaded");
     if (!count) return;
     HC(hipSetDevice(device_));
-    if (!with_cast_key && ksm_min_ > 0 && d_ksk_limbs_ && count >= (size_t)ksm_min_) {
-        // large batch: int8 matrix product on the matrix cores, in launches of about 4096
-        // ciphertexts (whole program instances each, so that the block map shifts by pointer arithmetic)
-        if (imap.idx && !imap.ops) throw std::logic_error("block map without a period");
-        size_t chunk = 4096;
+    if (imap.idx && !imap.ops) throw std::logic_error("block map without a period");
+    // a launch takes a whole number of program instances, so that the block map shifts by pointer arithmetic
+    auto whole_instances = [&](size_t chunk) {
         if (imap.idx) chunk = imap.ops >= chunk ? imap.ops : chunk / imap.ops * imap.ops;
-        if (chunk > count) chunk = count;
-        if (chunk > ksm_cap_) {
+        return chunk > count ? count : chunk;
+    };
+    if (!with_cast_key && ksm_min_ > 0 && d_ksk_limbs_ && count >= (size_t)ksm_min_) {
+        // large batch: int8 matrix product on the matrix cores, in launches of about 4096 ciphertexts
+        size_t chunk = whole_instances(4096);
+        int8_t* dig = d_ksm_dig_;
+        int* prod = d_ksm_prod_;
+        if (ext) {
+            // rows (multiples of the product tile) the caller's two regions hold
+            const size_t rows = std::min(ext->ksm_dig_bytes / ksm_digit_bytes(1, N, (int)prm_.ks_level),
+                                         ext->ksm_prod_bytes / ksm_product_bytes(1, (int)prm_.lwe_dim)) * ksm_rows_pad(1);
+            if (chunk > rows) chunk = whole_instances(rows);
+            if (!ext->ksm_dig || !ext->ksm_prod || !rows || ksm_rows_pad(chunk) > rows)
+                throw std::invalid_argument("scratch too small for one key-switch launch");
+            dig = ext->ksm_dig;
+            prod = ext->ksm_prod;
+        } else if (chunk > ksm_cap_) {
             HC(hipStreamSynchronize(stream_));
             (void)hipFree(d_ksm_dig_); (void)hipFree(d_ksm_prod_);
             d_ksm_dig_ = nullptr; d_ksm_prod_ = nullptr; ksm_cap_ = 0;
             HC(hipMalloc(&d_ksm_dig_, ksm_digit_bytes(chunk, N, (int)prm_.ks_level)));
             HC(hipMalloc(&d_ksm_prod_, ksm_product_bytes(chunk, (int)prm_.lwe_dim)));
             ksm_cap_ = chunk;
+            dig = d_ksm_dig_;
+            prod = d_ksm_prod_;
         }
         for (size_t c0 = 0; c0 < count; c0 += chunk) {
             const size_t cnt = count - c0 < chunk ? count - c0 : chunk;
             const u64* in = lwe_in + (imap.idx ? (c0 / imap.ops) * imap.inst_stride : c0) * (size_t)(N + 1);
-            launch_keyswitch_mfma(d_ksk_limbs_, in, d_ksm_dig_, d_ksm_prod_, lwe_small_out + c0 * (prm_.lwe_dim + 1), cnt, N,
+            launch_keyswitch_mfma(d_ksk_limbs_, in, dig, prod, lwe_small_out + c0 * (prm_.lwe_dim + 1), cnt, N,
                                   (int)prm_.lwe_dim, (int)prm_.ks_base_log, (int)prm_.ks_level, imap, stream_);
             HC(hipGetLastError());
         }
         return;
     }
     // the grid's second dimension counts groups of sixteen ciphertexts and ends at 65535: longer
-    // batches go in several launches, a whole number of program instances each
-    if (imap.idx && !imap.ops) throw std::logic_error("block map without a period");
-    size_t chunk = ks_valu_max_count();
-    if (imap.idx) chunk = imap.ops >= chunk ? imap.ops : chunk / imap.ops * imap.ops;
-    if (chunk > count) chunk = count;
-    const size_t need = keyswitch_scratch_words(chunk, N);
-    if (need > ksdig_cap_) {
+    // batches go in several launches
+    size_t chunk = whole_instances(ks_valu_max_count());
+    u32* digits = d_ksdig_;
+    if (ext) {
+        while (chunk > 1 && keyswitch_scratch_words(chunk, N) > ext->ks_dig_words) chunk = whole_instances(chunk / 2);
+        if (!ext->ks_dig || keyswitch_scratch_words(chunk, N) > ext->ks_dig_words)
+            throw std::invalid_argument("scratch too small for one key-switch launch");
+        digits = ext->ks_dig;
+    } else if (const size_t need = keyswitch_scratch_words(chunk, N); need > ksdig_cap_) {
         HC(hipStreamSynchronize(stream_));
         (void)hipFree(d_ksdig_);
         d_ksdig_ = nullptr;
         HC(hipMalloc(&d_ksdig_, need * sizeof(u32)));
         ksdig_cap_ = need;
+        digits = d_ksdig_;
     }
     for (size_t c0 = 0; c0 < count; c0 += chunk) {
         const size_t cnt = count - c0 < chunk ? count - c0 : chunk;
         const u64* in = lwe_in + (imap.idx ? (c0 / imap.ops) * imap.inst_stride : c0) * (size_t)(N + 1);
-        launch_keyswitch(key, key + ksk_words(), in, d_ksdig_, lwe_small_out + c0 * (prm_.lwe_dim + 1), cnt, N,
+        launch_keyswitch(key, key + ksk_words(), in, digits, lwe_small_out + c0 * (prm_.lwe_dim + 1), cnt, N,
                          (int)prm_.lwe_dim, (int)prm_.ks_base_log, (int)prm_.ks_level, imap, stream_);
         HC(hipGetLastError());
     }
@@ -404,6 +427,16 @@ void Engine::pbs_batch(const u64* lwe_in, const u64* luts, const u32* lut_index,
     keyswitch(lwe_in, small, count);
     ms_noise_reduce(small, count);
     blind_rotate(small, luts, lut_index, nullptr, lwe_out, count);
+}
+
+void Engine::pbs_batch_on(const PbsScratch& scratch, const u64* lwe_in, const u64* luts, const u32* lut_index,
+                          u64* lwe_out, size_t count) {
+    if (!count) return;
+    if (!scratch.small || scratch.small_words < count * ((size_t)prm_.lwe_dim + 1))
+        throw std::invalid_argument("scratch too small for the key-switched ciphertexts");
+    keyswitch(lwe_in, scratch.small, count, BlockMap(), false, &scratch);
+    ms_noise_reduce(scratch.small, count);
+    blind_rotate(scratch.small, luts, lut_index, nullptr, lwe_out, count);
 }
 
 void Engine::external_product(const u32* ggsw_index, const u64* glwe, u64* out, size_t count) {

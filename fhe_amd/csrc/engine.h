@@ -103,6 +103,17 @@ struct CompShape {
     size_t pksk_words() const { return (size_t)N * ks_level * glwe_words(); }
 };
 
+// Caller-provided scratch of one bootstrap batch (all device memory): the key-switched small
+// ciphertexts, the packed digits of the VALU key switch, the digits and partial products of the
+// matrix-core key switch.  A region that is too small for the whole batch makes the stage run in
+// several launches; one that cannot hold a single launch is an error.  Nothing is allocated.
+struct PbsScratch {
+    u64* small = nullptr;      size_t small_words = 0;
+    u32* ks_dig = nullptr;     size_t ks_dig_words = 0;
+    int8_t* ksm_dig = nullptr; size_t ksm_dig_bytes = 0;
+    int* ksm_prod = nullptr;   size_t ksm_prod_bytes = 0;
+};
+
 class Engine {
 public:
     // throws std::runtime_error on unsupported parameters or HIP failure
@@ -151,8 +162,12 @@ public:
     // ---- device-pointer operations, asynchronous on stream()
     // count bootstraps: lwe_in [count][N+1], luts [nluts][N] body polynomials, lut_index [count] or null
     void pbs_batch(const u64* lwe_in, const u64* luts, const u32* lut_index, u64* lwe_out, size_t count);
+    // the same pipeline (same kernels, same bits) on the caller's scratch; allocates nothing
+    void pbs_batch_on(const PbsScratch& scratch, const u64* lwe_in, const u64* luts, const u32* lut_index, u64* lwe_out,
+                      size_t count);
+    // ext: scratch to use instead of the engine's own grow-only buffers
     void keyswitch(const u64* lwe_in, u64* lwe_small_out, size_t count, const BlockMap& imap = BlockMap(),
-                   bool with_cast_key = false);
+                   bool with_cast_key = false, const PbsScratch* ext = nullptr);
     // in place on [count][n+1] small ciphertexts; a no-op without encryptions of zero;
     // chosen [count] (device, may be null) receives the candidate taken (-1: none added)
     void ms_noise_reduce(u64* lwe_small, size_t count, int* chosen = nullptr);
@@ -221,5 +236,10 @@ private:
 };
 
 void hip_check(hipError_t e, const char* what);
+// once per device, with any device current: resolves the device address of the scratch array behind
+// lfhe_pbs_batch_device_noalloc (noalloc.hip)
+void noalloc_setup(int device);
+// once per device: the 512-thread blind-rotation kernels ask for more than 64 KiB of dynamic LDS
+void blind_rotate_setup(int device);
 
 }  // namespace lfhe

@@ -936,21 +936,28 @@ void launch_external_product_q(const Tables& T, const double* bsk, const u32* id
     hipLaunchKernelGGL(k_external_product_q, dim3((unsigned)count), dim3(NT), LDS_BYTES, st, T, bsk, idx, glwe, out,
                        inv_g);
 }
+// more than 64 KiB of dynamic LDS has to be asked for, once per device the kernels run on
+void blind_rotate_setup(int dev) {
+    static std::atomic<uint64_t> lds_asked{0};
+    if (dev < 0 || dev >= 64) throw std::runtime_error("device index out of range");
+    if (lds_asked.load(std::memory_order_acquire) >> dev & 1) return;
+    const bool ok = hipSetDevice(dev) == hipSuccess &&
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(k_blind_rotate_q2_wide),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE2_LDS_BYTES) == hipSuccess &&
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(k_blind_rotate_q_wide),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_BYTES) == hipSuccess;
+    if (!ok) throw std::runtime_error("the 512-thread blind rotation needs 136 KiB of LDS per workgroup");
+    lds_asked.fetch_or(1ull << dev, std::memory_order_release);
+}
+
 void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
                            const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
                            const BlockMap& omap, double inv_g, int wide_below, int lockstep_above, int grouping,
                            hipStream_t st) {
-    // more than 64 KiB of dynamic LDS has to be asked for, once per device the kernels run on
-    static std::atomic<uint64_t> lds_asked{0};
-    int dev = 0;
-    if (count <= (size_t)wide_below && hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 &&
-        !(lds_asked.load(std::memory_order_acquire) >> dev & 1)) {
-        const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_blind_rotate_q2_wide),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE2_LDS_BYTES) == hipSuccess &&
-                        hipFuncSetAttribute(reinterpret_cast<const void*>(k_blind_rotate_q_wide),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_BYTES) == hipSuccess;
-        if (!ok) throw std::runtime_error("the 512-thread blind rotation needs 136 KiB of LDS per workgroup");
-        lds_asked.fetch_or(1ull << dev, std::memory_order_release);
+    if (count <= (size_t)wide_below) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) throw std::runtime_error("hipGetDevice failed");
+        blind_rotate_setup(dev);   // a no-op after the engine's own call at start-up
     }
     if (grouping == 2 && count <= (size_t)wide_below) {
         hipLaunchKernelGGL(k_blind_rotate_q2_wide, dim3((unsigned)count), dim3(2 * NT), WIDE2_LDS_BYTES, st, T, bsk,

@@ -125,6 +125,7 @@ def load():
         "lfhe_pbs_batch": (i32, [vp, u64, vp, vp, u32, vp, vp]),
         "lfhe_pbs_batch_device": (i32, [vp, u64, vp, vp, vp, vp]),
         "lfhe_sync": (i32, [vp]),
+        "lfhe_pbs_batch_device_noalloc": (i32, [vp, u64, vp, vp, vp, vp]),
         "lfhe_pbs_batch_device_timed": (i32, [vp, u64, vp, vp, vp, vp, u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "lfhe_ntt_info": (i32, [vp, pu64, pu64]),
         "lfhe_ntt_forward": (i32, [vp, u64, vp, vp]),
@@ -505,6 +506,11 @@ class Context:
     def pbs_batch_device(self, count: int, d_in: int, d_luts: int, d_idx: int | None, d_out: int):
         self._ck(self._L.lfhe_pbs_batch_device(self._h, count, C.c_void_p(d_in), C.c_void_p(d_luts),
                                                C.c_void_p(d_idx) if d_idx else None, C.c_void_p(d_out)))
+
+    def pbs_batch_device_noalloc(self, count: int, d_in: int, d_luts: int, d_idx: int | None, d_out: int):
+        """pbs_batch_device on the library's static scratch array: no device allocation in the call."""
+        self._ck(self._L.lfhe_pbs_batch_device_noalloc(self._h, count, C.c_void_p(d_in), C.c_void_p(d_luts),
+                                                       C.c_void_p(d_idx) if d_idx else None, C.c_void_p(d_out)))
 
     def pbs_batch_device_timed(self, count: int, d_in: int, d_luts: int, d_idx: int | None, d_out: int, iters: int):
         ks, br = C.c_double(), C.c_double()

@@ -270,6 +270,17 @@ int32_t lfhe_pbs_batch(lfhe_ctx* ctx, uint64_t count, const uint64_t* lwe_in, co
 int32_t lfhe_pbs_batch_device(lfhe_ctx* ctx, uint64_t count, const void* d_lwe_in, const void* d_lut_bodies,
                               const void* d_lut_index, void* d_lwe_out);
 int32_t lfhe_sync(lfhe_ctx* ctx);
+/* lfhe_pbs_batch_device for callers that cannot allocate device memory: a stream under HIP graph
+ * capture, a tight serving loop, a harness that forbids hipMalloc.  No counterpart in the
+ * reference.  Same kernels and bit-identical results; the intermediates of the batch live in a
+ * static device array of the library (about 25 MiB per GPU, held until the process ends) instead of
+ * the context's grow-only buffers, and the call makes no hipMalloc / hipFree.  At most
+ * LFHE_NOALLOC_MAX_COUNT ciphertexts per call (more is LFHE_ERR_ARG; so is a custom parameter set
+ * with an LWE dimension above 1024).  All calls on one GPU share that GPU's array: calls that
+ * overlap on one GPU -- from two contexts or two threads -- race; serialise them. */
+#define LFHE_NOALLOC_MAX_COUNT 1024u
+int32_t lfhe_pbs_batch_device_noalloc(lfhe_ctx* ctx, uint64_t count, const void* d_lwe_in, const void* d_lut_bodies,
+                                      const void* d_lut_index, void* d_lwe_out);
 /* the same pipeline timed with HIP events on the context's stream: `iters` back-to-back runs;
  * returns the average duration of the key-switch kernel and of the blind-rotation kernel (ms) */
 int32_t lfhe_pbs_batch_device_timed(lfhe_ctx* ctx, uint64_t count, const void* d_lwe_in, const void* d_lut_bodies,
