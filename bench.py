@@ -34,10 +34,28 @@ MODMUL_PER_PBS_GROUPED = 459 * (4 * 11264 + 16 * 2048)
 # f64 butterflies (modular multiply + add + sub) per prime.  Over q = 2^64 a logical modular product
 # costs one butterfly in each of two primes; over the prime ring modulus it costs one.
 PEAK_GBFLY_PER_PRIME = 4748.0
-# memory-side traffic of one 4096-ciphertext blind-rotation launch, from separate rocprofv3 --pmc passes
-# (profiles/r01/pmc_hbm_v5.txt): (2 * FETCH_SIZE + WRITE_SIZE) * 1024, Infinity-Cache hits included
-TRAFFIC_BYTES_4096 = {"prime": (2 * 3808307 + 196800) * 1024, "q64": (2 * 7909668 + 196739) * 1024,
-                      "grouped": (2 * 7534766 + 65813) * 1024}   # profiles/r01/pmc_grouped_v13.txt
+# memory-side traffic of one 4096-ciphertext blind-rotation launch: read from the tracked counter summary
+# (tools/pmc_passes.sh + tools/pmc_summary.py: separate rocprofv3 --pmc passes, (2 * FETCH_SIZE +
+# WRITE_SIZE) * 1024, Infinity-Cache hits included).  The summary is stamped with a hash of the kernel
+# sources; a build from other sources reports null instead of a stale number.
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02", "traffic.json")
+
+
+def measured_traffic(flavour: str, batch: int):
+    """(bytes per launch or None, where it comes from)."""
+    if batch != BATCH or not os.path.exists(TRAFFIC_FILE):
+        return None, None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from pmc_summary import kernel_source_hash
+        rec = json.load(open(TRAFFIC_FILE)).get(flavour)
+        if not rec or rec.get("kernel_sources") != kernel_source_hash():
+            return None, None
+        return rec["bytes_per_launch_4096"], rec.get("source")
+    except (OSError, ValueError, KeyError, ImportError):
+        return None, None
+
+
 # algorithmic bytes of one batch launch: both keys once + one ciphertext in and out per bootstrap
 BSK_BYTES, KSK_BYTES, CT_BYTES = 60162048, 60227584, 16392
 # device image of the bootstrapping key (f64 residues in the transform domain)
@@ -87,7 +105,52 @@ def cpu_baseline(seconds_budget: float = 20.0, flavour: str = "prime"):
                       "own CPU restatement (oracle C port with OpenMP): the reference engine is unavailable offline"}
 
 
-def main():
+class GpuBackend:
+    """What the benchmark needs from the machine: the device of a rank, a context with replicated
+    keys, a device-wide wait.  The HIP library is the only compute path of this default; the CPU
+    tests drive the same control flow (ranks, shards, collectives, verification, exit status) with a
+    plaintext stand-in from tests/ injected in its place."""
+    collective = "nccl"
+
+    def device(self, local: int):
+        import torch
+        if not torch.cuda.is_available():
+            raise SystemExit("no GPU: the HIP path is the only path")
+        torch.cuda.set_device(local)
+        return torch.device("cuda", local)
+
+    def context(self, dist, rank, world, dev, seed, params_id):
+        from fhe_amd.sharding import replicated_context
+        return replicated_context(dist, rank, world, dev, seed, params_id)
+
+    def synchronize(self):
+        import torch
+        torch.cuda.synchronize()
+
+
+# first reference vector of the euint64 multiplication (tests/fhevm-suite/e2e/test/fhevmOperations/
+# fhevmOperations6.ts:647-660)
+MUL_KAT = (4293652672, 4293367238, 18434227713315959936)
+
+
+def mul_latency(ctx, reps: int = 3):
+    """One euint64 multiplication, operands and result in host memory (the shape of POST /evaluate):
+    best of `reps` after a warm-up that builds and uploads the schedule.  Returns (ms, bootstraps, ok)."""
+    a, b = ctx.encrypt(MUL_KAT[0], 64), ctx.encrypt(MUL_KAT[1], 64)
+    ctx.evaluate("mul", 64, a, b)
+    best, ok = None, True
+    n0 = ctx.pbs_count()
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = ctx.evaluate("mul", 64, a, b)
+        dt = time.perf_counter() - t0
+        ok = ok and ctx.decrypt(out) == MUL_KAT[2]
+        best = dt if best is None else min(best, dt)
+    return best * 1e3, (ctx.pbs_count() - n0) // reps, ok
+
+
+def main(argv=None, backend=None):
+    backend = backend or GpuBackend()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -99,39 +162,40 @@ def main():
                          "prime (one transform per polynomial), or over the prime with the key bits taken two per "
                          "blind-rotation step")
     ap.add_argument("--no-alt", action="store_true", help="skip the legs with the other bootstrapping keys")
-    args = ap.parse_args()
+    ap.add_argument("--no-operators", action="store_true", help="skip the euint64 multiplication latency probe")
+    args = ap.parse_args(argv)
 
     import torch
-    from fhe_amd.sharding import max_over_ranks, replicated_context
+    from fhe_amd.sharding import max_over_ranks
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if not torch.cuda.is_available():
-        raise SystemExit("no GPU: the HIP path is the only path")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    dev = backend.device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend.collective == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend.collective, rank=rank, world_size=world)
 
     seed = bytes((7 * i + 3) & 0xFF for i in range(32))
 
     def make_context(flavour: str):
         """Context with keys on every rank: generated on rank 0, device images broadcast once."""
-        return replicated_context(dist, rank, world, dev, seed, FLAVOURS[flavour][0])
+        return backend.context(dist, rank, world, dev, seed, FLAVOURS[flavour][0])
 
     B = args.batch
     # 16 distinct tables, table j on block i when i % 16 == j (table 0 is the identity)
     f = [(lambda x, j=j: ((2 * j + 1) * x + j) % 16) for j in range(16)]
     idx = (np.arange(B) % 16).astype(np.uint32)
 
-    def run_leg(flavour: str, steps: int, warmup: int):
-        """K timed passes over this rank's B blocks; returns (elapsed s, ks ms, br ms, verified)."""
+    def run_leg(flavour: str, steps: int, warmup: int, operators: bool = False):
+        """K timed passes over this rank's B blocks; returns (elapsed s, ks ms, br ms, verified, mul probe)."""
         ctx, keep = make_context(flavour)
         # synthetic inputs: batch blocks = batch/4 euint8 values, fresh encryptions, distinct per rank
         rng = np.random.default_rng(1234 + rank)
@@ -144,7 +208,7 @@ def main():
         d_luts = torch.from_numpy(luts.view(np.int64)).to(dev)
         d_idx = torch.from_numpy(idx.view(np.int32)).to(dev)
         d_out = torch.zeros_like(d_in)
-        torch.cuda.synchronize()
+        backend.synchronize()
 
         def step(iters):
             return ctx.pbs_batch_device_timed(B, d_in.data_ptr(), d_luts.data_ptr(), d_idx.data_ptr(),
@@ -153,13 +217,13 @@ def main():
         if warmup > 0:
             step(warmup)
         ctx.sync()
-        torch.cuda.synchronize()
+        backend.synchronize()
         if dist is not None:
             dist.barrier()
         t0 = time.perf_counter()
         ks_ms, br_ms = step(steps)   # K back-to-back passes, each kernel bracketed by HIP events
         ctx.sync()
-        torch.cuda.synchronize()
+        backend.synchronize()
         if dist is not None:
             dist.barrier()
         elapsed = time.perf_counter() - t0
@@ -174,21 +238,26 @@ def main():
             flag = torch.tensor([1 if ok else 0], device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = bool(flag.item())
+        # outside the timed region: the latency of one euint64 multiplication on this rank's GPU
+        # (rank 0 reports; no collective involved)
+        probe = mul_latency(ctx) if operators and rank == 0 else None
+        if probe is not None:
+            ok = ok and probe[2]
         ctx.close()
         del keep
-        return elapsed, ks_ms, br_ms, ok
+        return elapsed, ks_ms, br_ms, ok, probe
 
     flavour = args.bsk_modulus
-    elapsed, ks_ms, br_ms, ok = run_leg(flavour, args.steps, args.warmup)
+    elapsed, ks_ms, br_ms, ok, probe = run_leg(flavour, args.steps, args.warmup, operators=not args.no_operators)
     alts = []
     if not args.no_alt:
         a_steps = max(1, min(args.steps, 3))
         for other in FLAVOURS:
             if other == flavour:
                 continue
-            a_el, a_ks, a_br, a_ok = run_leg(other, a_steps, 1)
+            a_el, a_ks, a_br, a_ok, _ = run_leg(other, a_steps, 1)
             ok = ok and a_ok
-            alts.append({"bsk_modulus": FLAVOURS[other][1], "kernel": FLAVOURS[other][2],
+            alts.append({"flavour": other, "bsk_modulus": FLAVOURS[other][1], "kernel": FLAVOURS[other][2],
                          "value": B * a_steps * world / a_el, "unit": "PBS/s", "steps": a_steps,
                          "kernel_ms": {"keyswitch_and_ms_noise_reduction": a_ks, "blind_rotate": a_br},
                          "verified": a_ok})
@@ -201,6 +270,7 @@ def main():
         achieved = B * modmul / br_s / 1e9
         peak = PEAK_GBFLY_PER_PRIME / 2 if flavour == "q64" else PEAK_GBFLY_PER_PRIME
         algo_bytes = BSK_BYTES + KSK_BYTES + 2 * CT_BYTES * B
+        traffic, traffic_source = measured_traffic(flavour, B)
         res = {
             "metric": "programmable bootstraps/sec (node)",
             "value": value,
@@ -222,7 +292,7 @@ def main():
             "kernel_ms": {"keyswitch_and_ms_noise_reduction": ks_ms, "blind_rotate": br_ms},
             "roofline": {"bound": "valu", "kernel": FLAVOURS[flavour][2], "achieved": achieved, "peak": peak,
                          "unit": "Gmodmul/s", "frac": achieved / peak, "modmul_per_pbs": modmul,
-                         "traffic": TRAFFIC_BYTES_4096.get(flavour) if B == BATCH else None,
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "hbm": {"achieved": algo_bytes / ((ks_ms + br_ms) * 1e-3) / 1e9, "peak": 8000.0,
                                  "unit": "GB/s", "algorithmic_bytes": algo_bytes},
                          # key words the workgroups request per launch (served by L2): every ciphertext
@@ -230,8 +300,18 @@ def main():
                          "key_stream": {"bytes": B * KEY_IMAGE_BYTES[flavour],
                                         "achieved": B * KEY_IMAGE_BYTES[flavour] / br_s / 1e9, "unit": "GB/s"}},
         }
+        if probe is not None:
+            # second half of the headline metric: one euint64 multiplication, host buffers in and out
+            res["euint64_mul_latency_ms"] = probe[0]
+            res["mul_pbs"] = probe[1]
         if alts:
             res["other_bootstrapping_keys"] = alts
+            # the parameter set exactly as the reference names it (bootstrapping key over 2^64)
+            q64 = [a for a in alts if a["flavour"] == "q64"]
+            if q64:
+                res["value_q64_key"] = q64[0]["value"]
+        elif flavour == "q64":
+            res["value_q64_key"] = value
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(flavour=flavour)
         print(json.dumps(res), flush=True)

@@ -48,6 +48,8 @@ Engine::Engine(int device, const EngineParams& p) : device_(device), prm_(p) {
     // 256, but 8.8 vs 7.4 ms at 512
     wide_below_ = (p.bsk_grouping == 2 ? 1 : 2) * cu_count_;
     if (const char* e = std::getenv("LFHE_WIDE_BELOW")) wide_below_ = std::atoi(e);   // tuning / A-B runs
+    pair_above_ = 2 * cu_count_;
+    if (const char* e = std::getenv("LFHE_PAIR_ABOVE")) pair_above_ = std::atoi(e);   // -1: never
     if (const char* e = std::getenv("LFHE_BR_CHUNK")) br_chunk_ = std::atoi(e);       // 0: automatic
     if (const char* e = std::getenv("LFHE_KS_MFMA_MIN")) ksm_min_ = std::atoi(e);     // 0: VALU key switch only
     if (!ksm_supported(N, (int)p.ks_level, (int)p.lwe_dim)) ksm_min_ = 0;
@@ -414,7 +416,8 @@ void Engine::blind_rotate_with(const double* bsk, uint32_t n, const u64* lwe_sma
         }
         if (single_modulus())
             launch_blind_rotate_q(T_, bsk, in, (int)n, luts, li, gout, lout, cnt, omap,
-                                  1.0 / (double)qp_gadget(), wide_below_, 4 * cu_count_, (int)prm_.bsk_grouping, stream_);
+                                  1.0 / (double)qp_gadget(), wide_below_, 4 * cu_count_, (int)prm_.bsk_grouping, pair_above_,
+                                  stream_);
         else
             launch_blind_rotate(T_, bsk, in, (int)n, luts, li, gout, lout, cnt, omap, stream_);
         HC(hipGetLastError());

@@ -58,7 +58,7 @@ void launch_external_product_q(const Tables& T, const double* bsk, const u32* id
 void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
                            const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
                            const BlockMap& omap, double inv_g, int wide_below, int lockstep_above, int grouping,
-                           hipStream_t st);
+                           int pair_above, hipStream_t st);
 void launch_lin_batch(u64* arena, const LinOp* ops, int nops, size_t instances, size_t inst_stride_blocks, u64 delta,
                       hipStream_t st);
 void launch_blocks_move(u64* arena, size_t instances, size_t inst_stride_blocks, const u32* idx, u32 first, u32 nblocks,
@@ -231,6 +231,7 @@ private:
     int cu_count_ = 256;
     int br_chunk_ = 0;      // ciphertexts per blind-rotation launch; 0: about four rounds of resident workgroups
     int wide_below_ = -1;   // launches of at most this many ciphertexts use 512 threads each
+    int pair_above_ = -1;   // grouped key: launches of more ciphertexts put two in a workgroup (-1: never)
     void set_ms_params(u32 zcount);
     u64* ms_zeros_dev() const { return d_ksk_ + ksk_words() + prm_.lwe_dim + 1 + 1; }
 };

@@ -697,7 +697,6 @@ __global__ void __launch_bounds__(NT, 4) k_blind_rotate_q2(Tables T, const doubl
     for (int g = 0; g < groups; ++g) {
         const unsigned a0 = modswitch_2n(lwe[2 * g]);
         const unsigned a1 = 2 * g + 1 < n ? modswitch_2n(lwe[2 * g + 1]) : 0u;
-        if ((a0 | a1) == 0) continue;  // the step's GGSW is the identity: skipped
         unsigned tt = t;
         asm volatile("" : "+v"(tt));  // recompute the addresses per step (see ep_phase)
 #pragma unroll
@@ -755,6 +754,283 @@ __global__ void __launch_bounds__(NT, 4) k_blind_rotate_q2(Tables T, const doubl
             const unsigned e = own1(t, j);
             if (e == 0) { o[0] = qp_to_torus(acc[0][j]); o[N] = qp_to_torus(acc[1][j]); }
             else o[N - e] = qp_to_torus(-acc[0][j]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The grouped blind rotation with TWO ciphertexts per workgroup.  Every thread owns the same
+// positions of both ciphertexts: the key words of a step are loaded once and multiplied into both
+// (half the L2 -> CU key traffic per ciphertext), the twiddles of a pass are loaded once for four
+// polynomials instead of two, LDS addresses are computed once, and a barrier separates twice the
+// work.  Two workgroups per CU (four ciphertexts per CU, as with one ciphertext per workgroup), so
+// the register budget is 256 per thread; each ciphertext keeps exchange buffers of its own.
+// Arithmetic, index maps and results are those of k_blind_rotate_q2, bit for bit.
+// An odd batch: the last workgroup computes its only ciphertext twice and stores it once.
+// ------------------------------------------------------------------------------------------------
+constexpr int G2P_NC = 2;
+static constexpr size_t G2P_LDS_BYTES = G2P_NC * LDS_BYTES + 2 * G2_TW_SMALL * sizeof(double);
+
+template <bool LOCKSTEP>
+__global__ void __launch_bounds__(NT, 2) k_blind_rotate_q2_pair(Tables T, const double* __restrict__ bsk,
+                                                               const u64* __restrict__ lwe_small, int n,
+                                                               const u64* __restrict__ luts,
+                                                               const u32* __restrict__ lut_index,
+                                                               u64* __restrict__ glwe_out,
+                                                               u64* __restrict__ lwe_out, BlockMap omap,
+                                                               double inv_g, unsigned count) {
+    constexpr int NC = G2P_NC;
+    const unsigned t = threadIdx.x;
+    const Prime P = T.pr[0];
+    size_t ct[NC];
+    const u64* __restrict__ lwe[NC];
+    double x[NC][2][E];   // accumulator between steps, working residues inside a step
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const size_t want = (size_t)blockIdx.x * NC + c;
+        ct[c] = want < count ? want : (size_t)count - 1;
+        lwe[c] = lwe_small + ct[c] * (size_t)(n + 1);
+        const u64* __restrict__ lut = luts + (size_t)(lut_index ? lut_index[omap.ops ? ct[c] % omap.ops : ct[c]] : 0) * N;
+        const unsigned bt = modswitch_2n(lwe[c][n]);
+        const unsigned a = (2 * N - bt) & (2 * N - 1);  // multiply by X^-b~
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            bool neg;
+            const double v = torus_to_qp(lut[rot_index(own1(t, j), a, neg)]);
+            x[c][0][j] = 0.0;
+            x[c][1][j] = neg ? -v : v;
+        }
+    }
+    const double* __restrict__ twf_small = lds_dyn + NC * LDS_WORDS;   // entries 0..63 of the forward table
+    const double* __restrict__ twi_small = twf_small + G2_TW_SMALL;
+    for (unsigned i = t; i < (unsigned)G2_TW_SMALL; i += NT) {
+        lds_dyn[NC * LDS_WORDS + i] = T.tw_fwd[0][i];
+        lds_dyn[NC * LDS_WORDS + G2_TW_SMALL + i] = T.tw_inv[0][i];
+    }
+    __syncthreads();
+
+    // polynomial q of ciphertext c
+    auto buf = [&](int c, int q) { return lds_dyn + (2 * c + q) * POLY_STRIDE; };
+    const int groups = (n + 1) / 2;
+    for (int g = 0; g < groups; ++g) {
+        unsigned am[NC][3];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            am[c][0] = modswitch_2n(lwe[c][2 * g]);
+            am[c][1] = 2 * g + 1 < n ? modswitch_2n(lwe[c][2 * g + 1]) : 0u;
+            am[c][2] = (am[c][0] + am[c][1]) & (2 * N - 1);
+        }
+        // addresses are recomputed per phase instead of living in registers across the step loop
+        unsigned tt = t, zero = 0;
+        asm volatile("" : "+v"(tt));
+        asm volatile("" : "+s"(zero));
+        const double* __restrict__ twf = T.tw_fwd[0] + zero;
+        const double* __restrict__ twi = T.tw_inv[0] + zero;
+        const double* __restrict__ mono = T.mono + zero;
+        const double* __restrict__ rows = bsk + (size_t)4 * g * BSKQ_ROW;
+        double w[7];
+        // ---- forward transform of the digits, four polynomials per pass
+        load_tw8(twf_small, 1, w);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                for (int j = 0; j < E; ++j) x[c][q][j] = __builtin_rint(x[c][q][j] * inv_g);
+                ct_radix8(x[c][q], w, P);
+                st_o1p12(buf(c, q), tt, x[c][q]);
+            }
+        load_tw8(twf_small, base2(tt), w);
+        __syncthreads();
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) ld_o2p12(buf(c, q), tt, x[c][q]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) ct_radix8(x[c][q], w, P);
+        phase_sync<g2_sync_after<LOCKSTEP>(1)>();
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) st_o2p23(buf(c, q), tt, x[c][q]);
+        load_tw8_pass3(twf_small, twf, base3(tt), w);
+        phase_sync<g2_sync_after<LOCKSTEP>(2)>();
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) ld_o3p23(buf(c, q), tt, x[c][q]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) ct_radix8(x[c][q], w, P);
+        phase_sync<g2_sync_after<LOCKSTEP>(3)>();
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) st_o3p34(buf(c, q), tt, x[c][q]);
+        load_tw4x2(twf, tt, w);
+        phase_sync<g2_sync_after<LOCKSTEP>(4)>();
+        // ---- last forward pass, the step's GGSW formed point by point and applied, first inverse pass
+        asm volatile("" : "+v"(tt));
+        {
+            const unsigned ut = 2 * rev8(tt) + 1;
+            double base[NC][3];
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int m = 0; m < 3; ++m) base[c][m] = ldt(mono, (am[c][m] * ut) & (2 * N - 1));
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) ld_o4p34(buf(c, q), tt, x[c][q]);
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) ct_radix4x2(x[c][q], w, P);
+            load_tw4x2(twi, tt, w);   // for the inverse pass below
+            const double* __restrict__ w8 = mono + MONO_WORDS;
+            // key words of unit u = 4 c4 + m: row m, the four polynomials q, positions 8 t + 2 c4 + {0, 1};
+            // the next unit's four 16-byte loads are in flight while this one is multiplied into both ciphertexts
+            double kc[4][2], kn[4][2];
+#pragma unroll
+            for (unsigned q = 0; q < 4; ++q) { const unsigned o = bsk_off(0, q, 0, tt); kc[q][0] = LFHE_LDK(rows, o); kc[q][1] = LFHE_LDK(rows, o + 1); }
+            auto chunk = [&](auto c4_tag) {
+                constexpr int c4 = decltype(c4_tag)::value;
+                double B[NC][4][2];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int u = 4 * c4 + m;
+                    if (u < 15) {
+                        const unsigned c4n = (unsigned)(u + 1) / 4, mn = (unsigned)(u + 1) % 4;
+#pragma unroll
+                        for (unsigned q = 0; q < 4; ++q) {
+                            const unsigned o = mn * (unsigned)BSKQ_ROW + bsk_off(0, q, c4n, tt);
+                            kn[q][0] = LFHE_LDK(rows, o); kn[q][1] = LFHE_LDK(rows, o + 1);
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        if (m == 0) {   // X^0: the row enters as it is
+#pragma unroll
+                            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) B[c][q][h] = kc[q][h];
+                        } else {
+                            double M[2];
+                            mono_pair<c4>(base[c][m - 1], w8, am[c][m - 1], P, M[0], M[1]);
+#pragma unroll
+                            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) B[c][q][h] += mmul(M[h], kc[q][h], P);
+                        }
+                    }
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { kc[q][0] = kn[q][0]; kc[q][1] = kn[q][1]; }
+                }
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int j = 2 * c4 + h;
+                        const double d0 = mnorm(x[c][0][j], P), d1 = mnorm(x[c][1][j], P);
+                        x[c][0][j] = mmul(B[c][0][h], d0, P) + mmul(B[c][2][h], d1, P);
+                        x[c][1][j] = mmul(B[c][1][h], d0, P) + mmul(B[c][3][h], d1, P);
+                    }
+            };
+            chunk(std::integral_constant<int, 0>{});
+            chunk(std::integral_constant<int, 1>{});
+            chunk(std::integral_constant<int, 2>{});
+            chunk(std::integral_constant<int, 3>{});
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) gs_radix4x2<GS_NORM_PASS4[0], GS_NORM_PASS4[1]>(x[c][q], w, P);
+        }
+        phase_sync<g2_sync_after<LOCKSTEP>(5)>();   // the next phase rewrites the words this thread has just read
+        // ---- inverse transform
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) st_o4p34(buf(c, q), tt, x[c][q]);
+        load_tw8_pass3(twi_small, twi, base3(tt), w);
+        phase_sync<g2_sync_after<LOCKSTEP>(6)>();
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) ld_o3p34(buf(c, q), tt, x[c][q]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) gs_radix8<GS_NORM_PASS3[0], GS_NORM_PASS3[1], GS_NORM_PASS3[2]>(x[c][q], w, P);
+        phase_sync<g2_sync_after<LOCKSTEP>(7)>();
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) st_o3p23(buf(c, q), tt, x[c][q]);
+        load_tw8(twi_small, base2(tt), w);
+        phase_sync<g2_sync_after<LOCKSTEP>(8)>();
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) ld_o2p23(buf(c, q), tt, x[c][q]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) gs_radix8<GS_NORM_PASS2[0], GS_NORM_PASS2[1], GS_NORM_PASS2[2]>(x[c][q], w, P);
+        phase_sync<g2_sync_after<LOCKSTEP>(9)>();
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) st_o2p12(buf(c, q), tt, x[c][q]);
+        load_tw8(twi_small, 1, w);
+        __syncthreads();
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) ld_o1p12(buf(c, q), tt, x[c][q]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                gs_radix8<GS_NORM_PASS1[0], GS_NORM_PASS1[1], GS_NORM_PASS1[2]>(x[c][q], w, P);
+#pragma unroll
+                for (int j = 0; j < E; ++j) x[c][q][j] = qp_canon(x[c][q][j], P);
+            }
+        __syncthreads();  // the last pass's reads are done before the next step overwrites the buffers
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (c > 0 && (size_t)blockIdx.x * NC + c >= count) break;   // odd batch: the duplicate is not stored
+        if (glwe_out) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    const double v = x[c][q][j];
+                    glwe_out[(ct[c] * 2 + q) * N + own1(t, j)] = v < 0 ? QP_U - (u64)(-v) : (u64)v;
+                }
+        }
+        if (lwe_out) {  // sample extraction of coefficient 0, every word switched back to 2^64
+            u64* o = lwe_out + omap.block(ct[c]) * (size_t)(N + 1);
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const unsigned e = own1(t, j);
+                if (e == 0) { o[0] = qp_to_torus(x[c][0][j]); o[N] = qp_to_torus(x[c][1][j]); }
+                else o[N - e] = qp_to_torus(-x[c][0][j]);
+            }
         }
     }
 }
@@ -819,12 +1095,12 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q2_wide(Tables T, co
                 for (unsigned k = 0; k < 2; ++k) { kx[m][2 * c4 + k] = ldt(rows, o0 + k); ky[m][2 * c4 + k] = ldt(rows, o1 + k); }
             }
     };
-    // the two exponents of step g; a step with both zero has the identity as its GGSW and is skipped
+    // the two exponents of step g (every step runs, also one whose exponents are both zero: the control
+    // flow does not depend on the ciphertext)
     auto exponent0 = [&](int g) { return g < groups ? modswitch_2n(lwe[2 * g]) : 0u; };
     auto exponent1 = [&](int g) { return 2 * g + 1 < n ? modswitch_2n(lwe[2 * g + 1]) : 0u; };
     int g = 0;
     unsigned a0 = exponent0(0), a1 = exponent1(0);
-    while (g < groups && (a0 | a1) == 0) { ++g; a0 = exponent0(g); a1 = exponent1(g); }
     if (g < groups) load_key(g, t0);
 
     while (g < groups) {
@@ -890,8 +1166,7 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q2_wide(Tables T, co
         // their addresses are made to depend on the point-wise results
         unsigned tk = t;
         asm volatile("" : "+v"(tk) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
-        int gnext = g + 1;
-        while (gnext < groups && (na0 | na1) == 0) { ++gnext; na0 = exponent0(gnext); na1 = exponent1(gnext); }
+        const int gnext = g + 1;
         if (gnext < groups) load_key(gnext, tk);
         gs_radix4x2<GS_NORM_PASS4[0], GS_NORM_PASS4[1]>(x, w, P);
         st_o4p34(back, t, x); load_tw8(twi, base3(t), w);
@@ -942,6 +1217,10 @@ void blind_rotate_setup(int dev) {
     if (dev < 0 || dev >= 64) throw std::runtime_error("device index out of range");
     if (lds_asked.load(std::memory_order_acquire) >> dev & 1) return;
     const bool ok = hipSetDevice(dev) == hipSuccess &&
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(k_blind_rotate_q2_pair<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2P_LDS_BYTES) == hipSuccess &&
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(k_blind_rotate_q2_pair<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2P_LDS_BYTES) == hipSuccess &&
                     hipFuncSetAttribute(reinterpret_cast<const void*>(k_blind_rotate_q2_wide),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE2_LDS_BYTES) == hipSuccess &&
                     hipFuncSetAttribute(reinterpret_cast<const void*>(k_blind_rotate_q_wide),
@@ -953,7 +1232,7 @@ void blind_rotate_setup(int dev) {
 void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
                            const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
                            const BlockMap& omap, double inv_g, int wide_below, int lockstep_above, int grouping,
-                           hipStream_t st) {
+                           int pair_above, hipStream_t st) {
     if (count <= (size_t)wide_below) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) throw std::runtime_error("hipGetDevice failed");
@@ -962,6 +1241,16 @@ void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_sm
     if (grouping == 2 && count <= (size_t)wide_below) {
         hipLaunchKernelGGL(k_blind_rotate_q2_wide, dim3((unsigned)count), dim3(2 * NT), WIDE2_LDS_BYTES, st, T, bsk,
                            lwe_small, n, luts, lut_index, glwe_out, lwe_out, omap, inv_g);
+        return;
+    }
+    if (grouping == 2 && pair_above >= 0 && count > (size_t)pair_above) {
+        const unsigned wgs = (unsigned)((count + G2P_NC - 1) / G2P_NC);
+        if (count > (size_t)lockstep_above)
+            hipLaunchKernelGGL(k_blind_rotate_q2_pair<true>, dim3(wgs), dim3(NT), G2P_LDS_BYTES, st, T, bsk, lwe_small, n,
+                               luts, lut_index, glwe_out, lwe_out, omap, inv_g, (unsigned)count);
+        else
+            hipLaunchKernelGGL(k_blind_rotate_q2_pair<false>, dim3(wgs), dim3(NT), G2P_LDS_BYTES, st, T, bsk, lwe_small, n,
+                               luts, lut_index, glwe_out, lwe_out, omap, inv_g, (unsigned)count);
         return;
     }
     if (grouping == 2) {

@@ -1006,7 +1006,8 @@ static void blind_rotate_qp_grouped(const orc_ctx* c, const orc_prepared_bsk* pb
     for (u32 g = 0; g < groups; ++g) {
         const u32 a0 = orc_modswitch(lwe_small[2 * g], log2n);
         const u32 a1 = 2 * g + 1 < n ? orc_modswitch(lwe_small[2 * g + 1], log2n) : 0;
-        if (a0 == 0 && a1 == 0) continue;   /* B encrypts 1: skipped, the accumulator is left as it is */
+        /* every step runs, also the one whose exponents are both zero (B then encrypts 1): the
+         * sequence of operations does not depend on the ciphertext */
         group_step_hat(c, pb->hat + (size_t)4 * g * pb->per_ggsw, pb->per_ggsw, a0, a1, acc);
     }
 }

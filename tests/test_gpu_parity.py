@@ -259,6 +259,7 @@ def _mk_prime(n, seed, ms_zeros=0, wide=True, grouped=False):
         p.ms_r_sigma_factor, p.ms_input_variance = d.ms_r_sigma_factor, d.ms_input_variance
         zeros = orc.gen_ms_zeros(lwe_sk, seed_bytes(seed), ms_zeros)
         orc.set_ms(zeros)
+    orc.test_zeros = zeros      # for tests that load the same keys into a second context
     ctx = Context(seed=seed_bytes(100 + seed), params=p)
     os.environ.pop("LFHE_WIDE_BELOW", None)
     ctx.import_server_keys_raw(bskq, ksk, zeros)
@@ -394,6 +395,21 @@ def test_grouped_key_pbs_full_parameters():
             assert np.array_equal(out[i], orc.pbs_qp(ksk, pb, cts[i], luts_o[idx[i]])), i
         # a small launch takes the 512-thread kernel: same bits
         assert np.array_equal(ctx.pbs_batch(cts[:8], luts_g, idx[:8]), out[:8])
+        # launches of more than two ciphertexts per CU put two ciphertexts in a workgroup; an odd batch
+        # leaves the last workgroup with one; one ciphertext per workgroup (forced) gives the same bits
+        assert np.array_equal(ctx.pbs_batch(cts[:577], luts_g, idx[:577]), out[:577])
+        import os
+        os.environ["LFHE_PAIR_ABOVE"] = "-1"
+        try:
+            from fhe_amd.native import Context
+            single = Context(seed=seed_bytes(107), params=ctx.params)
+        finally:
+            del os.environ["LFHE_PAIR_ABOVE"]
+        try:
+            single.import_server_keys_raw(bskg, ksk, orc.test_zeros)
+            assert np.array_equal(single.pbs_batch(cts, luts_g, idx), out)
+        finally:
+            single.close()
         # more than four workgroups per CU: the instantiation with a barrier after every phase, same bits
         big = ctx.pbs_batch(np.concatenate([cts, cts[:500]]), luts_g, np.concatenate([idx, idx[:500]]))
         assert np.array_equal(big[:B], out) and np.array_equal(big[B:], out[:500])
