@@ -66,7 +66,7 @@ KEY_IMAGE_BYTES = {"q64": 918 * 131072, "prime": 918 * 65536, "grouped": 1836 * 
 FLAVOURS = {
     "q64": (1, "2^64", "k_blind_rotate"),
     "prime": (2, "703687441727489 (NTT prime)", "k_blind_rotate_q"),
-    "grouped": (3, "703687441727489 (NTT prime), key bits in pairs", "k_blind_rotate_q2<true>"),
+    "grouped": (3, "703687441727489 (NTT prime), key bits in pairs", "k_blind_rotate_q2_pair<false>"),
 }
 
 

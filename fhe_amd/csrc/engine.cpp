@@ -48,7 +48,9 @@ Engine::Engine(int device, const EngineParams& p) : device_(device), prm_(p) {
     // 256, but 8.8 vs 7.4 ms at 512
     wide_below_ = (p.bsk_grouping == 2 ? 1 : 2) * cu_count_;
     if (const char* e = std::getenv("LFHE_WIDE_BELOW")) wide_below_ = std::atoi(e);   // tuning / A-B runs
-    pair_above_ = 2 * cu_count_;
+    pair_above_ = -2;   // automatic (pair_threshold)
+    lockstep_above_ = 4 * cu_count_;
+    if (const char* e = std::getenv("LFHE_LOCKSTEP_ABOVE")) lockstep_above_ = std::atoi(e);
     if (const char* e = std::getenv("LFHE_PAIR_ABOVE")) pair_above_ = std::atoi(e);   // -1: never
     if (const char* e = std::getenv("LFHE_BR_CHUNK")) br_chunk_ = std::atoi(e);       // 0: automatic
     if (const char* e = std::getenv("LFHE_KS_MFMA_MIN")) ksm_min_ = std::atoi(e);     // 0: VALU key switch only
@@ -387,6 +389,17 @@ static size_t launch_chunk(size_t count, size_t ops, size_t slots) {
     return best ? best : ops;
 }
 
+// Grouped key: which launches put two ciphertexts in a workgroup (returns the count above which they
+// do, for this launch).  Measured per launch size (ms, one ciphertext per workgroup / two): 384: 6.6 /
+// 6.4, 512: 7.0 / 6.6, 640: 9.9 / 11.4, 768: 10.2 / 11.4, 1024: 13.0 / 11.9, 2048: 24.5 / 22.2, 4096:
+// 46.8 / 42.0 -- two per workgroup win except between two and three and a half ciphertexts per CU,
+// where paired workgroups would double up on a quarter to a half of the CUs.
+int Engine::pair_threshold(size_t count) const {
+    if (pair_above_ != -2) return pair_above_;   // forced by LFHE_PAIR_ABOVE (-1: never)
+    const size_t cu = (size_t)cu_count_;
+    return (count <= 2 * cu || 2 * count > 7 * cu) ? 0 : -1;
+}
+
 void Engine::blind_rotate(const u64* lwe_small, const u64* luts, const u32* lut_index, u64* glwe_out, u64* lwe_out,
                           size_t count, const BlockMap& omap) {
     if (!d_bsk_) throw std::runtime_error("no bootstrapping key loaded");
@@ -416,7 +429,8 @@ void Engine::blind_rotate_with(const double* bsk, uint32_t n, const u64* lwe_sma
         }
         if (single_modulus())
             launch_blind_rotate_q(T_, bsk, in, (int)n, luts, li, gout, lout, cnt, omap,
-                                  1.0 / (double)qp_gadget(), wide_below_, 4 * cu_count_, (int)prm_.bsk_grouping, pair_above_,
+                                  1.0 / (double)qp_gadget(), wide_below_, lockstep_above_, (int)prm_.bsk_grouping,
+                                  pair_threshold(cnt),
                                   stream_);
         else
             launch_blind_rotate(T_, bsk, in, (int)n, luts, li, gout, lout, cnt, omap, stream_);

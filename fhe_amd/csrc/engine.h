@@ -231,7 +231,9 @@ private:
     int cu_count_ = 256;
     int br_chunk_ = 0;      // ciphertexts per blind-rotation launch; 0: about four rounds of resident workgroups
     int wide_below_ = -1;   // launches of at most this many ciphertexts use 512 threads each
-    int pair_above_ = -1;   // grouped key: launches of more ciphertexts put two in a workgroup (-1: never)
+    int lockstep_above_ = 1024;   // grouped key: larger launches keep a workgroup barrier after every phase
+    int pair_above_ = -2;   // grouped key: launches of more ciphertexts put two in a workgroup (-1: never, -2: automatic)
+    int pair_threshold(size_t count) const;
     void set_ms_params(u32 zcount);
     u64* ms_zeros_dev() const { return d_ksk_ + ksk_words() + prm_.lwe_dim + 1 + 1; }
 };

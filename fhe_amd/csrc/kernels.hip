@@ -808,6 +808,15 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_q2_pair(Tables T, const 
         lds_dyn[NC * LDS_WORDS + G2_TW_SMALL + i] = T.tw_inv[0][i];
     }
     __syncthreads();
+    // The twiddles of passes 3 and 4 (26 values per thread, both directions) depend on the thread
+    // alone: with 256 registers to spend they stay in registers for the whole blind rotation, which
+    // leaves the key words as the step's only vector memory loads besides three monomial gathers.
+    double w3f[7], w4f[7], w3i[7], w4i[7];
+    load_tw8(T.tw_fwd[0], base3(t), w3f);
+    load_tw4x2(T.tw_fwd[0], t, w4f);
+    load_tw8(T.tw_inv[0], base3(t), w3i);
+    load_tw4x2(T.tw_inv[0], t, w4i);
+    w4f[6] = 0.0; w4i[6] = 0.0;
 
     // polynomial q of ciphertext c
     auto buf = [&](int c, int q) { return lds_dyn + (2 * c + q) * POLY_STRIDE; };
@@ -824,8 +833,6 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_q2_pair(Tables T, const 
         unsigned tt = t, zero = 0;
         asm volatile("" : "+v"(tt));
         asm volatile("" : "+s"(zero));
-        const double* __restrict__ twf = T.tw_fwd[0] + zero;
-        const double* __restrict__ twi = T.tw_inv[0] + zero;
         const double* __restrict__ mono = T.mono + zero;
         const double* __restrict__ rows = bsk + (size_t)4 * g * BSKQ_ROW;
         double w[7];
@@ -857,7 +864,6 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_q2_pair(Tables T, const 
         for (int c = 0; c < NC; ++c)
 #pragma unroll
             for (int q = 0; q < 2; ++q) st_o2p23(buf(c, q), tt, x[c][q]);
-        load_tw8_pass3(twf_small, twf, base3(tt), w);
         phase_sync<g2_sync_after<LOCKSTEP>(2)>();
         asm volatile("" : "+v"(tt));
 #pragma unroll
@@ -867,14 +873,13 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_q2_pair(Tables T, const 
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) ct_radix8(x[c][q], w, P);
+            for (int q = 0; q < 2; ++q) ct_radix8(x[c][q], w3f, P);
         phase_sync<g2_sync_after<LOCKSTEP>(3)>();
         asm volatile("" : "+v"(tt));
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
             for (int q = 0; q < 2; ++q) st_o3p34(buf(c, q), tt, x[c][q]);
-        load_tw4x2(twf, tt, w);
         phase_sync<g2_sync_after<LOCKSTEP>(4)>();
         // ---- last forward pass, the step's GGSW formed point by point and applied, first inverse pass
         asm volatile("" : "+v"(tt));
@@ -885,6 +890,12 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_q2_pair(Tables T, const 
             for (int c = 0; c < NC; ++c)
 #pragma unroll
                 for (int m = 0; m < 3; ++m) base[c][m] = ldt(mono, (am[c][m] * ut) & (2 * N - 1));
+            // key words of unit u = 4 c4 + m: row m, the four polynomials q, positions 8 t + 2 c4 + {0, 1};
+            // the next unit's four 16-byte loads are in flight while this one is multiplied into both
+            // ciphertexts; the first unit's are requested here, ahead of the last forward pass
+            double kc[4][2], kn[4][2];
+#pragma unroll
+            for (unsigned q = 0; q < 4; ++q) { const unsigned o = bsk_off(0, q, 0, tt); kc[q][0] = LFHE_LDK(rows, o); kc[q][1] = LFHE_LDK(rows, o + 1); }
 #pragma unroll
             for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -892,14 +903,8 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_q2_pair(Tables T, const 
 #pragma unroll
             for (int c = 0; c < NC; ++c)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) ct_radix4x2(x[c][q], w, P);
-            load_tw4x2(twi, tt, w);   // for the inverse pass below
+                for (int q = 0; q < 2; ++q) ct_radix4x2(x[c][q], w4f, P);
             const double* __restrict__ w8 = mono + MONO_WORDS;
-            // key words of unit u = 4 c4 + m: row m, the four polynomials q, positions 8 t + 2 c4 + {0, 1};
-            // the next unit's four 16-byte loads are in flight while this one is multiplied into both ciphertexts
-            double kc[4][2], kn[4][2];
-#pragma unroll
-            for (unsigned q = 0; q < 4; ++q) { const unsigned o = bsk_off(0, q, 0, tt); kc[q][0] = LFHE_LDK(rows, o); kc[q][1] = LFHE_LDK(rows, o + 1); }
             auto chunk = [&](auto c4_tag) {
                 constexpr int c4 = decltype(c4_tag)::value;
                 double B[NC][4][2];
@@ -951,7 +956,7 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_q2_pair(Tables T, const 
 #pragma unroll
             for (int c = 0; c < NC; ++c)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) gs_radix4x2<GS_NORM_PASS4[0], GS_NORM_PASS4[1]>(x[c][q], w, P);
+                for (int q = 0; q < 2; ++q) gs_radix4x2<GS_NORM_PASS4[0], GS_NORM_PASS4[1]>(x[c][q], w4i, P);
         }
         phase_sync<g2_sync_after<LOCKSTEP>(5)>();   // the next phase rewrites the words this thread has just read
         // ---- inverse transform
@@ -960,7 +965,6 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_q2_pair(Tables T, const 
         for (int c = 0; c < NC; ++c)
 #pragma unroll
             for (int q = 0; q < 2; ++q) st_o4p34(buf(c, q), tt, x[c][q]);
-        load_tw8_pass3(twi_small, twi, base3(tt), w);
         phase_sync<g2_sync_after<LOCKSTEP>(6)>();
         asm volatile("" : "+v"(tt));
 #pragma unroll
@@ -970,7 +974,7 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_q2_pair(Tables T, const 
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) gs_radix8<GS_NORM_PASS3[0], GS_NORM_PASS3[1], GS_NORM_PASS3[2]>(x[c][q], w, P);
+            for (int q = 0; q < 2; ++q) gs_radix8<GS_NORM_PASS3[0], GS_NORM_PASS3[1], GS_NORM_PASS3[2]>(x[c][q], w3i, P);
         phase_sync<g2_sync_after<LOCKSTEP>(7)>();
         asm volatile("" : "+v"(tt));
 #pragma unroll
@@ -1245,7 +1249,10 @@ void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_sm
     }
     if (grouping == 2 && pair_above >= 0 && count > (size_t)pair_above) {
         const unsigned wgs = (unsigned)((count + G2P_NC - 1) / G2P_NC);
-        if (count > (size_t)lockstep_above)
+        // with two ciphertexts per workgroup the wave-level fences win at every launch size (4096: 42.7
+        // against 43.5 ms with a workgroup barrier after every phase); the lock-step instantiation stays for A/B runs
+        static const bool pair_lockstep = std::getenv("LFHE_PAIR_LOCKSTEP") != nullptr;
+        if (pair_lockstep && count > (size_t)lockstep_above)
             hipLaunchKernelGGL(k_blind_rotate_q2_pair<true>, dim3(wgs), dim3(NT), G2P_LDS_BYTES, st, T, bsk, lwe_small, n,
                                luts, lut_index, glwe_out, lwe_out, omap, inv_g, (unsigned)count);
         else
