@@ -28,7 +28,12 @@ def column(cts):
     return np.stack(rows) if rows else np.zeros((0, 0), dtype=np.uint8)
 
 
-def main():
+def main(argv=None, backend=None):
+    """backend: what bench.GpuBackend provides (device of a rank, context with replicated keys);
+    the CPU tests inject a plaintext stand-in to run this control flow under gloo."""
+    if backend is None:
+        from bench import GpuBackend
+        backend = GpuBackend()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--transfers", type=int, default=0,
@@ -38,28 +43,28 @@ def main():
                     help="random pairs, total over all GPUs (the reference's vectors are added)")
     ap.add_argument("--bsk-modulus", choices=["q64", "prime", "grouped"], default="grouped",
                     help="bootstrapping key: over 2^64, over the NTT prime, or over the prime with the key bits in pairs")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     import torch
     from fhe_amd import workloads
-    from fhe_amd.sharding import max_over_ranks, replicated_context, shard_bounds
+    from fhe_amd.sharding import max_over_ranks, shard_bounds
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if not torch.cuda.is_available():
-        raise SystemExit("no GPU: the HIP path is the only path")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    dev = backend.device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend.collective == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend.collective, rank=rank, world_size=world)
     seed = bytes((11 * i + 5) & 0xFF for i in range(32))
-    ctx, keep = replicated_context(dist, rank, world, dev, seed, {"q64": 1, "prime": 2, "grouped": 3}[args.bsk_modulus])
+    ctx, keep = backend.context(dist, rank, world, dev, seed, {"q64": 1, "prime": 2, "grouped": 3}[args.bsk_modulus])
 
     def timed(fn):
         """Wall time of fn over all ranks: barrier on both sides, maximum over ranks."""

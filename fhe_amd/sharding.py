@@ -41,33 +41,50 @@ class _DevMem:
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
 
-def replicated_context(dist, rank: int, world: int, device, seed: bytes, params_id: int):
+def key_image_tensors(ctx, device, owner: bool) -> list:
+    """The two key images of a context as flat byte tensors on `device`: on the rank that owns the
+    keys, zero-copy views of the library's own memory; elsewhere, fresh buffers of the same sizes to
+    receive into.  (A host device is served too -- views of host memory -- which is how the CPU
+    tests run this path on a stand-in context.)"""
+    import torch
+    bsk_bytes, ksk_bytes = ctx.device_keys_size()
+    if not owner:
+        return [torch.empty(bsk_bytes, dtype=torch.uint8, device=device),
+                torch.empty(ksk_bytes, dtype=torch.uint8, device=device)]
+    bp, _, kp, _ = ctx.device_keys()
+    if device.type == "cuda":
+        return [torch.as_tensor(_DevMem(bp, bsk_bytes), device=device),
+                torch.as_tensor(_DevMem(kp, ksk_bytes), device=device)]
+    import ctypes
+    return [torch.frombuffer((ctypes.c_uint8 * n).from_address(p), dtype=torch.uint8)
+            for p, n in ((bp, bsk_bytes), (kp, ksk_bytes))]
+
+
+def replicated_context(dist, rank: int, world: int, device, seed: bytes, params_id: int, context_cls=None,
+                       always_broadcast: bool = False):
     """A context with the same key set on every rank: rank 0 generates the keys, the two device key
     images go out with one broadcast each (straight out of / into device memory), the client key
     follows as a small host object.  Returns (context, tensors the context points at): keep the
-    tensors alive as long as the context."""
+    tensors alive as long as the context.  always_broadcast: run the collectives with one rank too
+    (a communicator of size one), which exercises the wrapping of library memory on a single GPU."""
     import torch
-    from .native import Context, KEY_CLIENT
-    ctx = Context(seed=seed, device=device.index or 0, params_id=params_id)
+    from .native import KEY_CLIENT
+    if context_cls is None:
+        from .native import Context as context_cls
+    ctx = context_cls(seed=seed, device=device.index or 0, params_id=params_id)
     keep = []
     blob = None
     if rank == 0:
         ctx.keygen()
         blob = ctx.export_keys(KEY_CLIENT)
-    if world > 1:
-        bsk_bytes, ksk_bytes = ctx.device_keys_size()
-        if rank == 0:
-            bp, _, kp, _ = ctx.device_keys()
-            tb = torch.as_tensor(_DevMem(bp, bsk_bytes), device=device)
-            tk = torch.as_tensor(_DevMem(kp, ksk_bytes), device=device)
-        else:
-            tb = torch.empty(bsk_bytes, dtype=torch.uint8, device=device)
-            tk = torch.empty(ksk_bytes, dtype=torch.uint8, device=device)
-        replicate(dist, [tb, tk])
-        torch.cuda.synchronize()
+    if world > 1 or (always_broadcast and dist is not None):
+        images = key_image_tensors(ctx, device, owner=rank == 0)
+        replicate(dist, images)
+        if device.type == "cuda":
+            torch.cuda.synchronize()
         if rank != 0:
-            ctx.attach_device_keys(tb.data_ptr(), tk.data_ptr())
-            keep += [tb, tk]
+            ctx.attach_device_keys(images[0].data_ptr(), images[1].data_ptr())
+            keep += images
         blob = replicate_blob(dist, blob if rank == 0 else None)
         if rank != 0:
             ctx.import_keys(KEY_CLIENT, blob)

@@ -183,6 +183,75 @@ def test_sharded_workloads_two_ranks_gloo():
     assert workloads.transfers(B, [], [], [], B.encrypt(0, 64)) == ([], [])
 
 
+def _run_driver(which, world, flags, corrupt_rank=None, timeout=240):
+    """bench.py / bench_workloads.py as `world` fresh processes on the stand-in; returns
+    (exit codes, stdout of rank 0)."""
+    import subprocess
+    import sys
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        cmd = [sys.executable, os.path.join(ROOT, "tests", "run_driver_on_mock.py"), which]
+        if corrupt_rank is not None:
+            cmd.append(str(corrupt_rank))
+        procs.append(subprocess.Popen(cmd + ["--"] + flags, env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=timeout))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return [p.returncode for p in procs], outs[0][0], [o[1] for o in outs]
+
+
+def test_bench_control_flow_two_ranks_gloo():
+    """bench.py --gpus 2 end to end on the stand-in: key images broadcast from rank 0 and attached
+    on rank 1, each rank bootstraps its own blocks, barrier + maximum over ranks around the timed
+    region, verification flag reduced over ranks, ONE JSON line from rank 0 with whole-job
+    throughput; then a rank whose outputs are wrong makes EVERY rank exit non-zero."""
+    import json
+    flags = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "64", "--no-cpu-baseline"]
+    codes, out, errs = _run_driver("bench", 2, flags)
+    assert codes == [0, 0], errs
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["verified"] is True
+    assert d["config"]["batch_per_gpu"] == 64 and "x2" in d["config"]["parallelism"]
+    assert abs(d["value"] - 64 * 2 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]      # all ranks' blocks
+    assert {a["flavour"] for a in d["other_bootstrapping_keys"]} == {"q64", "prime"} and "value_q64_key" in d
+    assert d["mul_pbs"] > 0 and "cpu_baseline" not in d and d["roofline"]["traffic"] is None
+    codes, out, errs = _run_driver("bench", 2, flags + ["--no-alt", "--no-operators"], corrupt_rank=1)
+    assert all(c != 0 for c in codes), (codes, errs)
+    assert '"verified": false' in out
+    # one rank, no process group
+    codes, out, errs = _run_driver("bench", 1, ["--steps", "1", "--warmup", "0", "--batch", "32", "--no-cpu-baseline",
+                                               "--no-alt"])
+    assert codes == [0] and json.loads(out.splitlines()[-1])["n_gpus"] == 1, errs
+    # a launch whose world size contradicts --gpus refuses to run
+    codes, _, _ = _run_driver("bench", 1, ["--gpus", "2"])
+    assert codes == [1]
+
+
+def test_workload_driver_two_ranks_gloo():
+    """bench_workloads.py --gpus 2 on the stand-in: instances sliced per rank, bootstrap counts
+    summed over ranks, the argmax winners gathered and reduced on rank 0, every decrypted result
+    checked on the rank that owns it."""
+    import json
+    flags = ["--gpus", "2", "--transfers", "10", "--bids", "21", "--mul-batch", "5"]
+    codes, out, errs = _run_driver("workloads", 2, flags)
+    assert codes == [0, 0], errs
+    d = json.loads([l for l in out.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["erc20"]["transfers"] == 10 and d["argmax"]["bids"] == 21
+    assert d["euint64"]["mul_batch"] == 5 + 6          # the reference's six vectors ride along
+    assert d["erc20"]["pbs"] > 0 and d["argmax"]["pbs"] > 0
+
+
 def test_lazy_reduction_schedule_stays_exact():
     """The per-register normalisation masks compiled into the kernels keep every lazily reduced
     value below 2^53 in the worst case (bound model: tools/lazy_bounds.py) and hand the

@@ -1,5 +1,12 @@
-"""Two ranks replicate the key set through torch.distributed on one GPU.  Collected last: the test
-starts two more processes that import torch, the slowest thing a fresh box does."""
+"""Key replication through torch.distributed on one GPU: two ranks over gloo (host-staged
+broadcasts), and one rank over RCCL (the product's own collectives on a communicator of size one).
+Both start fresh processes and watch them with a bound: a rank that dies or stalls inside a
+collective leaves its peer waiting forever, and a silent wait is what ends a GPU run.
+gloo is used on host tensors only: an earlier form of the two-rank test ran gloo broadcasts and an
+all-reduce directly on device tensors, passed once and stalled once in that section with nothing
+else changed; the ranks' start-up was not the cause (this file's four processes start and finish in
+seconds on a box that has run the suite).  The product never does that either -- its device-tensor
+collectives are RCCL's."""
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -68,8 +75,7 @@ def test_two_ranks_replicate_keys_through_torch_distributed(capsys):
     procs = [mpc.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    # the two ranks are the first processes of the run to import torch, which takes minutes on a box
-    # that has not paged the image in yet: wait with a sign of life every 20 s, give up after 10 min
+    # wait with a sign of life every 20 s, give up after 10 min
     got, t0 = [], time.time()
     try:
         while len(got) < len(procs):
@@ -94,3 +100,23 @@ def test_two_ranks_replicate_keys_through_torch_distributed(capsys):
     assert s0 == w0 and s1 == w1          # rank 1 decrypts with the replicated client key, computes with the replicated server keys
     assert t0 == t1 == 2.0
     assert k0 == 0 and k1 == 2            # rank 1 keeps the two received key images alive
+
+
+def test_key_replication_over_rccl_on_one_rank():
+    """fhe_amd.sharding.replicated_context as the benchmark calls it, with the nccl backend: library
+    memory wrapped as tensors, one RCCL broadcast per key image, the object broadcast of the client
+    key, attach on a second context, barrier / max / min reductions on device tensors.  One GPU
+    allows one RCCL rank, so the communicator has size one; a fresh process, watched with a bound."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, "-u", os.path.join(root, "tests", "rccl_one_rank.py")], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (p.stdout, p.stderr[-2000:])
