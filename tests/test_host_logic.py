@@ -267,3 +267,32 @@ def test_lazy_reduction_schedule_stays_exact():
     allr = set(range(8))
     w_old, _, n_old = lb.inverse({(0, 1): allr, (2, 0): allr, (3, 1): allr}, 2 * lb.prod(lb.forward()[-1]))
     assert w_old > lb.LIMIT and n_old == 24
+
+
+def test_typescript_surface_matches_the_binding_and_the_reference_class():
+    """bindings/node/index.d.ts declares exactly what index.js exports, and LuxFHEClient.ts carries
+    every public method of the reference class (packages/luxfhejs/src/index.ts:42-200)."""
+    import json
+    import shutil
+    import subprocess
+    node_dir = os.path.join(ROOT, "bindings", "node")
+    dts = open(os.path.join(node_dir, "index.d.ts")).read()
+    ts = open(os.path.join(node_dir, "LuxFHEClient.ts")).read()
+    reference_methods = ["initialize", "getPublicKey", "encrypt_uint8", "encrypt_uint16", "encrypt_uint32", "encrypt_uint64",
+                         "encrypt_uint128", "encrypt_uint256", "encrypt_address", "unseal", "extractPermitPermission",
+                         "storePermit", "getStoredPermit"]
+    for m in reference_methods:
+        assert re.search(r"^\s+(async\s+)?%s\(" % m, ts, re.M), f"LuxFHEClient.ts lacks {m}"
+    assert "serverUrl" in ts and "provider" in ts           # the reference's config fields
+    if not shutil.which("node") or not os.path.exists(os.path.join(node_dir, "lfhe_napi.node")):
+        pytest.skip("node or the built addon is not here")
+    js = "const m=require('./index.js');console.log(JSON.stringify({e:Object.keys(m)," \
+         "n:Object.getOwnPropertyNames(m.NativeEngine.prototype),c:Object.getOwnPropertyNames(m.LuxFHEClient.prototype)}))"
+    got = json.loads(subprocess.run(["node", "-e", js], cwd=node_dir, capture_output=True, text=True, check=True).stdout)
+    for name in got["e"]:
+        assert re.search(r"export (declare )?(class|const|function) %s\b" % name, dts), f"index.d.ts lacks export {name}"
+    block = lambda cls: re.search(r"export class %s \{(.*?)\n\}" % cls, dts, re.S).group(1)
+    for cls, names in (("NativeEngine", got["n"]), ("LuxFHEClient", got["c"])):
+        declared = set(re.findall(r"^\s+(?:readonly )?(\w+)[(:]", block(cls), re.M))
+        assert set(names) - {"constructor"} <= declared, (cls, set(names) - declared)
+        assert declared - set(names) <= {"engine", "constructor"}, (cls, declared - set(names))
