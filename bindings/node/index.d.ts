@@ -57,6 +57,8 @@ export class NativeEngine {
   importClientKeys(lweSk: BigUint64Array, glweSk: BigUint64Array): void;
   setPkeKey(pkeSk: BigUint64Array): void;
   castFromPke(ciphertext: Bytes): Buffer;
+  /** words: mask (2048) then one body word per list ciphertext; packed defaults to true */
+  expandCompactList(words: BigUint64Array, widths: BitWidth[], packed?: boolean): Buffer[];
   compressionKeygen(): void;
   compress(ciphertexts: Bytes[]): Buffer;
   decompress(blob: Bytes): Buffer;

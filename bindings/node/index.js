@@ -127,6 +127,26 @@ class NativeEngine {
   setPkeKey(pkeSk) { native.setPkeKey(this.handle, Buffer.from(pkeSk.buffer, pkeSk.byteOffset, pkeSk.byteLength)); }
   castFromPke(ciphertext) { return native.castFromPke(this.handle, Buffer.from(ciphertext)); }
 
+  /**
+   * A client's compact ciphertext list (mask of 2048 words, then one body word per ciphertext, as a
+   * BigUint64Array) -> one ciphertext per entry of `widths` under the compute key; packed: two radix
+   * blocks per list ciphertext (build_with_proof_packed).  Needs setPkeKey first.
+   * @returns {Buffer[]}
+   */
+  expandCompactList(words, widths, packed) {
+    const w = Uint32Array.from(widths);
+    const all = native.expandCompactList(this.handle, Buffer.from(words.buffer, words.byteOffset, words.byteLength),
+      packed !== false, Buffer.from(w.buffer));
+    const out = [];
+    let off = 0;
+    for (const bits of widths) {
+      const size = 16 + (bits === 1 ? 1 : bits / 2) * 2049 * 8;
+      out.push(all.slice(off, off + size));
+      off += size;
+    }
+    return out;
+  }
+
   /** Compression for storage: keys once, then any list of ciphertexts <-> one blob (one bootstrap per block on the way back). */
   compressionKeygen() { native.compressionKeygen(this.handle); }
   compress(ciphertexts) { return native.compress(this.handle, Buffer.concat(ciphertexts.map((c) => Buffer.from(c)))); }

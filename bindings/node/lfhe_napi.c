@@ -50,6 +50,8 @@ FN(int32_t, lfhe_keygen_server, (lfhe_ctx*))
 FN(int32_t, lfhe_client_keys_import_raw, (lfhe_ctx*, const uint64_t*, const uint64_t*))
 FN(int32_t, lfhe_pke_key_set, (lfhe_ctx*, const uint64_t*))
 FN(int32_t, lfhe_cast_from_pke, (lfhe_ctx*, const uint8_t*, uint64_t, uint8_t*, uint64_t*))
+FN(int32_t, lfhe_expand_compact_list, (lfhe_ctx*, const uint64_t*, const uint64_t*, uint64_t, int32_t, const uint32_t*,
+                                       uint32_t, uint8_t*, uint64_t*))
 FN(int32_t, lfhe_compression_keygen, (lfhe_ctx*))
 FN(int32_t, lfhe_compress, (lfhe_ctx*, const uint8_t*, uint64_t, uint8_t*, uint64_t*))
 FN(int32_t, lfhe_decompress, (lfhe_ctx*, const uint8_t*, uint64_t, uint8_t*, uint64_t*))
@@ -81,7 +83,7 @@ static int resolve_all(napi_env env, const char* path) {
     GET(lfhe_trivial_encrypt) GET(lfhe_encrypt_public) GET(lfhe_decrypt) GET(lfhe_ciphertext_size)
     GET(lfhe_op_from_name) GET(lfhe_evaluate) GET(lfhe_evaluate_batch) GET(lfhe_pbs_count)
     GET(lfhe_rand) GET(lfhe_keygen_server) GET(lfhe_client_keys_import_raw) GET(lfhe_pke_key_set) GET(lfhe_cast_from_pke)
-    GET(lfhe_compression_keygen) GET(lfhe_compress) GET(lfhe_decompress)
+    GET(lfhe_compression_keygen) GET(lfhe_compress) GET(lfhe_decompress) GET(lfhe_expand_compact_list)
 #undef GET
     return 1;
 }
@@ -487,6 +489,33 @@ static napi_value js_cast_from_pke(napi_env env, napi_callback_info info) {
     return out;
 }
 
+/* expandCompactList(ctx, words (mask[2048] then bodies, 64-bit LE), packed, widths (Uint32Array bytes)) -> Buffer */
+static napi_value js_expand_compact_list(napi_env env, napi_callback_info info) {
+    NEED_LIB();
+    napi_value argv[4];
+    if (!get_args(env, info, 4, argv)) return NULL;
+    lfhe_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return NULL;
+    const uint8_t *words, *widths; size_t wl, tl;
+    if (!get_bytes(env, argv[1], &words, &wl) || !get_bytes(env, argv[3], &widths, &tl)) return NULL;
+    bool packed = false;
+    if (napi_get_value_bool(env, argv[2], &packed) != napi_ok) return throw_msg(env, "packed must be a boolean");
+    if (wl <= 2048 * 8 || wl % 8 || ((uintptr_t)words & 7)) return throw_msg(env, "the list is 2048 mask words and one body word per ciphertext");
+    if (!tl || tl % 4 || ((uintptr_t)widths & 3)) return throw_msg(env, "widths is an array of 32-bit integers");
+    const uint64_t* w64 = (const uint64_t*)words;
+    const uint64_t n_lwe = wl / 8 - 2048;
+    uint64_t on = 0;
+    int32_t rc = p_lfhe_expand_compact_list(c, w64, w64 + 2048, n_lwe, packed ? 1 : 0, (const uint32_t*)widths,
+                                            (uint32_t)(tl / 4), NULL, &on);
+    if (rc != LFHE_OK) return fail(env, c, rc, "lfhe_expand_compact_list");
+    uint8_t* tmp = (uint8_t*)malloc(on ? on : 1);
+    rc = p_lfhe_expand_compact_list(c, w64, w64 + 2048, n_lwe, packed ? 1 : 0, (const uint32_t*)widths, (uint32_t)(tl / 4),
+                                    tmp, &on);
+    napi_value out = rc == LFHE_OK ? make_buffer(env, tmp, on) : fail(env, c, rc, "lfhe_expand_compact_list");
+    free(tmp);
+    return out;
+}
+
 static napi_value js_compression_keygen(napi_env env, napi_callback_info info) {
     NEED_LIB();
     napi_value argv[1];
@@ -547,7 +576,7 @@ static napi_value init(napi_env env, napi_value exports) {
         {"evaluateBatch", js_evaluate_batch}, {"pbsCount", js_pbs_count}, {"rand", js_rand},
         {"importClientKeys", js_import_client}, {"keygenServer", js_keygen_server}, {"setPkeKey", js_set_pke_key},
         {"castFromPke", js_cast_from_pke}, {"compressionKeygen", js_compression_keygen}, {"compress", js_compress},
-        {"decompress", js_decompress}};
+        {"decompress", js_decompress}, {"expandCompactList", js_expand_compact_list}};
     for (size_t i = 0; i < sizeof tab / sizeof tab[0]; ++i) {
         napi_value f;
         napi_create_function(env, tab[i].name, NAPI_AUTO_LENGTH, tab[i].fn, NULL, &f);

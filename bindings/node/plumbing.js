@@ -30,8 +30,22 @@ const { LuxFHEClient, NativeEngine } = require('./index.js');
   const back = engine.decompress(blob);
   res.blobBytes = blob.length;
   res.restored = [String(engine.decrypt(back.slice(0, a.length))), String(engine.decrypt(back.slice(a.length)))];
+  // a client's compact input list, when the caller prepared one (a JSON file: base64 of 64-bit words):
+  // keys made elsewhere are imported, the list is expanded, cast to the compute key and decrypted
+  let compactOk = true;
+  if (process.env.LFHE_COMPACT_CASE) {
+    const c = JSON.parse(require('fs').readFileSync(process.env.LFHE_COMPACT_CASE, 'utf8'));
+    const words = (b64) => { const b = Buffer.from(b64, 'base64'); return new BigUint64Array(b.buffer, b.byteOffset, b.length / 8); };
+    const e2 = new NativeEngine({ seed: Buffer.alloc(32, 9), keygen: false });
+    e2.importClientKeys(words(c.lweSk), words(c.glweSk));
+    e2.setPkeKey(words(c.pkeSk));
+    const cts = e2.expandCompactList(words(c.list), c.widths, c.packed);
+    res.compact = cts.map((ct) => String(e2.decrypt(ct)));
+    compactOk = res.compact.length === c.values.length && res.compact.every((v, i) => v === c.values[i]);
+    e2.close();
+  }
   console.log(JSON.stringify(res));
-  const ok = res.health === 'ok' && res.add === '59' && res.sub === '25' && res.lt === '0' && res.eq === '1' &&
+  const ok = compactOk && res.health === 'ok' && res.add === '59' && res.sub === '25' && res.lt === '0' && res.eq === '1' &&
     res.addScalar === '242' && res.shl === String((42 << 3) & 255) && res.mul64 === '18434227713315959936' &&
     res.batch[0] === '1' && res.batch[1] === '0' && Number(res.rand) < 1024 &&
     res.restored[0] === '42' && res.restored[1] === '17' && back.length === a.length + b.length && blob.length < a.length / 8;

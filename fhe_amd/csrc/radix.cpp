@@ -618,6 +618,73 @@ int32_t lfhe_cast_from_pke(lfhe_ctx* ctx, const uint8_t* ct, uint64_t ct_len, ui
     });
 }
 
+// A client's compact ciphertext list -> radix ciphertexts under the compute key.  The list is one
+// RLWE-style encryption under the public-key secret: mask polynomial c0 and one body word per LWE
+// (coefficient i of c1).  Expansion is the sample extraction of coefficient i in the convention of
+// tfhe-rs compact public keys (body = mask (*) rev(s) + e, so the extracted mask is reversed to give
+// an LWE under s itself), then the cast of lfhe_cast_from_pke.  A packed list holds two radix blocks
+// per LWE (low block + 4 * high block); the cast's bootstrap splits them with two tables.
+int32_t lfhe_expand_compact_list(lfhe_ctx* ctx, const uint64_t* mask, const uint64_t* bodies, uint64_t n_lwe,
+                                 int32_t packed, const uint32_t* bit_widths, uint32_t n_values, uint8_t* out,
+                                 uint64_t* out_len) {
+    return guarded(ctx, [&]() -> int32_t {
+        if (!mask || !bodies || !bit_widths || !out_len || !n_values) throw std::invalid_argument("null or empty argument");
+        uint64_t total = 0, need = 0;
+        for (uint32_t v = 0; v < n_values; ++v) {
+            if (!width_ok(bit_widths[v])) throw std::invalid_argument("unsupported bit width");
+            total += blocks_of(bit_widths[v]);
+            need += ct_bytes(bit_widths[v]);
+        }
+        if (n_lwe == 0 || n_lwe > (uint64_t)N) throw std::invalid_argument("a compact list holds 1 .. 2048 ciphertexts per mask");
+        if (n_lwe != (packed ? (total + 1) / 2 : total)) throw std::invalid_argument("list length does not match the bit widths");
+        if (!out) { *out_len = need; return LFHE_OK; }
+        if (*out_len < need) { *out_len = need; return LFHE_ERR_SIZE; }
+        Engine& E = *ctx->eng;
+        if (!E.has_keys() || !E.has_cast_key()) throw std::logic_error("server keys or cast key not loaded");
+        HC(hipSetDevice(E.device()));
+        std::vector<u64> lwe((size_t)n_lwe * BLK_WORDS);
+        for (uint64_t i = 0; i < n_lwe; ++i) {
+            u64* o = lwe.data() + i * BLK_WORDS;
+            for (uint64_t j = 0; j <= i; ++j) o[j] = mask[i - j];
+            for (uint64_t j = i + 1; j < (uint64_t)N; ++j) o[j] = (u64)0 - mask[N + i - j];
+            std::reverse(o, o + N);      // LWE under rev(s) -> LWE under s
+            o[N] = bodies[i];
+        }
+        const uint32_t mm = ctx->prm.message_modulus;
+        std::vector<u64> luts(2 * (size_t)N);
+        uint64_t tab[16];
+        for (uint32_t x = 0; x < 16; ++x) tab[x] = packed ? x % mm : x;
+        make_lut_body(ctx->space(), ctx->delta(), tab, luts.data());
+        for (uint32_t x = 0; x < 16; ++x) tab[x] = x / mm;
+        make_lut_body(ctx->space(), ctx->delta(), tab, luts.data() + N);
+        DevBuf<u64> din(lwe.size()), dlo(lwe.size()), dhi(packed ? lwe.size() : 0), dl(luts.size());
+        hipStream_t st = E.stream();
+        HC(hipMemcpyAsync(din.p, lwe.data(), lwe.size() * 8, hipMemcpyHostToDevice, st));
+        HC(hipMemcpyAsync(dl.p, luts.data(), luts.size() * 8, hipMemcpyHostToDevice, st));
+        E.cast_batch(din.p, dl.p, dlo.p, n_lwe);
+        if (packed) E.cast_batch(din.p, dl.p + N, dhi.p, n_lwe);
+        std::vector<u64> lo(lwe.size()), hi(packed ? lwe.size() : 0);
+        HC(hipMemcpyAsync(lo.data(), dlo.p, lo.size() * 8, hipMemcpyDeviceToHost, st));
+        if (packed) HC(hipMemcpyAsync(hi.data(), dhi.p, hi.size() * 8, hipMemcpyDeviceToHost, st));
+        E.sync();
+        ctx->pbs_count += n_lwe * (packed ? 2 : 1);
+        uint8_t* w = out;
+        uint64_t b = 0;   // running radix block number over the whole list
+        for (uint32_t v = 0; v < n_values; ++v) {
+            const uint32_t nb = blocks_of(bit_widths[v]);
+            CtHeader h{CT_MAGIC, 1, (uint16_t)bit_widths[v], nb, 1, (uint8_t)(bit_widths[v] == 1 ? 1 : 3), 0};
+            std::memcpy(w, &h, sizeof h);
+            for (uint32_t k = 0; k < nb; ++k, ++b) {
+                const u64* src = packed ? ((b & 1) ? hi.data() : lo.data()) + (b / 2) * BLK_WORDS : lo.data() + b * BLK_WORDS;
+                std::memcpy(w + sizeof h + (size_t)k * BLK_BYTES, src, BLK_BYTES);
+            }
+            w += ct_bytes(bit_widths[v]);
+        }
+        *out_len = need;
+        return LFHE_OK;
+    });
+}
+
 // ---- compression for storage ----------------------------------------------------------------------
 namespace {
 constexpr uint32_t CZ_MAGIC = 0x5a43464cu;  // "LFCZ"

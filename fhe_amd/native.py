@@ -113,6 +113,7 @@ def load():
         "lfhe_ciphertext_size": (i32, [vp, u32, pu64]),
         "lfhe_pke_key_set": (i32, [vp, vp]),
         "lfhe_cast_from_pke": (i32, [vp, vp, u64, vp, pu64]),
+        "lfhe_expand_compact_list": (i32, [vp, vp, vp, u64, i32, pu32, u32, vp, pu64]),
         "lfhe_op_from_name": (i32, [C.c_char_p]),
         "lfhe_evaluate": (i32, [vp, u32, u32, vp, u64, vp, u64, i32, vp, u64, vp, pu64]),
         "lfhe_evaluate_batch": (i32, [vp, u32, u32, u64, vp, vp, i32, vp, vp]),
@@ -342,6 +343,26 @@ class Context:
         out = np.zeros(buf.size, dtype=np.uint8)
         self._ck(self._L.lfhe_cast_from_pke(self._h, _ptr(buf), buf.size, _ptr(out), C.byref(n)))
         return out.tobytes()
+
+    def expand_compact_list(self, mask: np.ndarray, bodies: np.ndarray, widths: list, packed: bool = True) -> list:
+        """A client's compact ciphertext list (under the public-key secret given to set_pke_key) ->
+        one ciphertext under the compute key per entry of `widths`."""
+        m, b = _u64(mask).reshape(-1), _u64(bodies).reshape(-1)
+        if m.size != self.N:
+            raise ValueError("the mask of a compact list has 2048 words")
+        w = (C.c_uint32 * len(widths))(*widths)
+        n = C.c_uint64(0)
+        self._ck(self._L.lfhe_expand_compact_list(self._h, _ptr(m), _ptr(b), b.size, 1 if packed else 0, w, len(widths),
+                                                  None, C.byref(n)))
+        out = np.empty(n.value, dtype=np.uint8)
+        self._ck(self._L.lfhe_expand_compact_list(self._h, _ptr(m), _ptr(b), b.size, 1 if packed else 0, w, len(widths),
+                                                  _ptr(out), C.byref(n)))
+        res, off = [], 0
+        for wd in widths:
+            sz = self.ciphertext_size(wd)
+            res.append(out[off:off + sz].tobytes())
+            off += sz
+        return res
 
     def decrypt(self, ct: bytes) -> int:
         buf = np.frombuffer(ct, dtype=np.uint8)

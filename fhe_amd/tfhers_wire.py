@@ -141,3 +141,91 @@ def make_compact_public_key(pke_sk, seed: bytes, noise_log2: int = 17):
             body[i:] += mask[:n - i]
             body[:i] -= mask[n - i:]
     return mask, body
+
+
+# ---- ciphertexts ------------------------------------------------------------------------------------
+# No ciphertext fixture exists in the reference tree (sdk/relayer/src/test holds keys only), so the
+# version tags and field order of tfhe-rs' serialized ciphertext types cannot be pinned here.  What
+# IS certain is how bincode writes the payloads: a `Vec<u64>` is its length as a u64 followed by the
+# words.  The readers below therefore find the ciphertext words the same way the key readers find
+# the keys -- by walking the blob for length-prefixed runs of the right length whose content looks
+# like ciphertext words -- and ignore the framing around them.  Nothing here writes tfhe-rs
+# ciphertext blobs: a writer with guessed version tags would produce files tfhe-rs refuses.
+_LWE_WORDS = 2049
+
+
+def _looks_uniform(v) -> bool:
+    return bool((v >> np.uint64(48)).astype(bool).mean() > 0.9)
+
+
+def parse_compact_list(blob: bytes):
+    """(mask[2048], bodies[n]) of a serialized compact ciphertext list holding n <= 2048 LWE
+    ciphertexts under a 2048-dimensional public-key secret (tfhe-rs LweCompactCiphertextList: one
+    vector of 2048 + n words).  Works on the proven and the plain list alike: the proof bytes are
+    not 64-bit ciphertext words and are skipped."""
+    vecs = [(o, v) for o, v in _u64_vectors(blob, _looks_uniform, min_len=2049) if 2048 < len(v) <= 4096]
+    if not vecs:
+        raise ValueError("no compact ciphertext list found in the blob")
+    v = max(vecs, key=lambda ov: len(ov[1]))[1]
+    return v[:2048].copy(), v[2048:].copy()
+
+
+def parse_radix_ciphertext(blob: bytes, bit_width: int | None = None) -> bytes:
+    """A serialized tfhe-rs radix ciphertext (FheUintN / RadixCiphertext: a vector of shortint
+    blocks, each holding its LWE words as a length-prefixed vector of 2049) as this library's
+    ciphertext blob.  bit_width: checked against the number of blocks found (two bits per block;
+    one block: ebool) when given.  Degree and noise level are read from the two versioned u64
+    fields that follow a block's modulus when they look plausible, else taken as 3 and 1."""
+    vecs = _u64_vectors(blob, lambda v: len(v) == _LWE_WORDS and _looks_uniform(v[:2048]), min_len=_LWE_WORDS)
+    vecs = [(o, v) for o, v in vecs if len(v) == _LWE_WORDS]
+    if not vecs:
+        raise ValueError("no LWE blocks of 2049 words found in the blob")
+    nb = len(vecs)
+    width = 1 if nb == 1 and bit_width in (None, 1) else 2 * nb
+    if bit_width is not None and bit_width != width:
+        raise ValueError(f"{nb} blocks do not make a {bit_width}-bit ciphertext")
+    degree, noise = (1 if width == 1 else 3), 1
+    end = vecs[0][0] + 8 * _LWE_WORDS        # behind the words: modulus (u32 tag, u128, u64), then degree and noise level
+    if end + 52 <= len(blob):
+        d = int.from_bytes(blob[end + 32:end + 40], "little")
+        z = int.from_bytes(blob[end + 44:end + 52], "little")
+        if 0 < d <= 3 and 0 < z <= 2:
+            degree, noise = d, z
+    out = bytearray(struct.pack("<IHHIBBH", 0x5443464C, 1, width, nb, noise, degree, 0))
+    for _, v in vecs:
+        out += v.astype("<u8").tobytes()
+    return bytes(out)
+
+
+def build_compact_list(pk_mask, pk_body, values: list, widths: list, seed: bytes, packed: bool = True,
+                       noise_log2: int = 17):
+    """What a client's input builder does (sdk/relayer/src/sdk/encrypt.ts:54-196, without the proof):
+    all values' radix blocks in order, two per ciphertext when packed (low + 4 * high), encrypted
+    as ONE compact list under the compact public key (tfhe-rs convention: key body = mask (*) rev(s)
+    + e): u binary, c0 = a (*) u + e1, c1 = b (*) u + e2 + M.  Returns (mask c0[2048], bodies[n])."""
+    n = 2048
+    blocks = []
+    for v, w in zip(values, widths):
+        if w == 1:
+            blocks.append(int(v) & 1)
+        else:
+            blocks += [(int(v) >> (2 * i)) & 3 for i in range(w // 2)]
+    if packed:
+        blocks = [blocks[i] + 4 * (blocks[i + 1] if i + 1 < len(blocks) else 0) for i in range(0, len(blocks), 2)]
+    if not 0 < len(blocks) <= n:
+        raise ValueError("a compact list holds 1 .. 2048 ciphertexts")
+    rng = np.random.default_rng(list(seed))
+    u = rng.integers(0, 2, size=n, dtype=np.uint64)
+    tu = lambda: rng.integers(-(1 << noise_log2), (1 << noise_log2) + 1, size=n, dtype=np.int64).astype(np.uint64)
+    a, b = np.ascontiguousarray(pk_mask, dtype=np.uint64), np.ascontiguousarray(pk_body, dtype=np.uint64)
+    c0, c1 = tu(), tu()
+    with np.errstate(over="ignore"):
+        for i in np.nonzero(u)[0]:            # += X^i * polynomial (negacyclic)
+            i = int(i)
+            c0[i:] += a[:n - i]
+            c0[:i] -= a[n - i:]
+            c1[i:] += b[:n - i]
+            c1[:i] -= b[n - i:]
+        msg = np.array(blocks, dtype=np.uint64) << np.uint64(59)
+        c1[:len(blocks)] += msg
+    return c0, c1[:len(blocks)].copy()

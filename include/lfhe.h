@@ -157,6 +157,18 @@ int32_t lfhe_decrypt(lfhe_ctx* ctx, const uint8_t* ct, uint64_t ct_len, uint8_t 
  * -> the same values under the compute key, one key switch + bootstrap per block. */
 int32_t lfhe_pke_key_set(lfhe_ctx* ctx, const uint64_t* pke_sk);
 int32_t lfhe_cast_from_pke(lfhe_ctx* ctx, const uint8_t* ct, uint64_t ct_len, uint8_t* out, uint64_t* out_len);
+/* A client's compact ciphertext list (one mask polynomial of N words + one body word per LWE
+ * ciphertext, encrypted under the public-key secret set with lfhe_pke_key_set) -> n_values
+ * ciphertexts under the compute key, back to back, of the given bit widths in list order.
+ * packed != 0: every LWE ciphertext holds two radix blocks (low + 4 * high), as
+ * build_with_proof_packed makes them; the bootstrap of the cast splits them.  At most N = 2048 LWE
+ * ciphertexts (the reference caps an input at 2048 bits, sdk/relayer/src/constants.ts:1-3).
+ * Replaces: the coprocessor's expand-and-cast of the inputs built by
+ * sdk/relayer/src/sdk/encrypt.ts:54-196 (CompactCiphertextList.builder ... push_u64 ...
+ * build_with_proof_packed); the zero-knowledge proof is not checked here. */
+int32_t lfhe_expand_compact_list(lfhe_ctx* ctx, const uint64_t* mask, const uint64_t* bodies, uint64_t n_lwe,
+                                 int32_t packed, const uint32_t* bit_widths, uint32_t n_values, uint8_t* out,
+                                 uint64_t* out_len);
 int32_t lfhe_ciphertext_size(const lfhe_ctx* ctx, uint32_t bit_width, uint64_t* out_len);
 
 /* ---- compression for storage --------------------------------------------------------------------

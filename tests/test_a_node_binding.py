@@ -50,9 +50,29 @@ def test_context_creation_without_gpu_fails_loudly():
 def test_plumbing_case_through_node():
     """42 and 17 as euint8 -> add/sub/lt/eq, a clear operand, a shift, the reference's euint64
     product vector (fhevmOperations6.ts:647-660) and a batch, all from JavaScript."""
-    out = subprocess.run(["node", "plumbing.js"], cwd=NODE_DIR, capture_output=True, text=True, timeout=300)
+    # and a compact input list built under the reference's public key (tests/golden), expanded from JavaScript
+    import base64
+    import tempfile
+    import numpy as np
+    from fhe_amd import tfhers_wire as W
+    golden = os.path.join(ROOT, "tests", "golden")
+    k = W.parse_client_key(open(os.path.join(golden, "privateKey.bin"), "rb").read())
+    mask, body = W.parse_compact_public_key(open(os.path.join(golden, "publicKey.bin"), "rb").read())
+    vals, widths = [0xFEEDFACE12345678, 1, 77], [64, 1, 8]
+    c0, bodies = W.build_compact_list(mask, body, vals, widths, bytes(range(7, 39)))
+    b64 = lambda a: base64.b64encode(np.ascontiguousarray(a, dtype="<u8").tobytes()).decode()
+    with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+        json.dump({"lweSk": b64(k["lwe_sk"]), "glweSk": b64(k["glwe_sk"]), "pkeSk": b64(k["pke_sk"]),
+                   "list": b64(np.concatenate([c0, bodies])), "widths": widths, "packed": True,
+                   "values": [str(v) for v in vals]}, f)
+    try:
+        out = subprocess.run(["node", "plumbing.js"], cwd=NODE_DIR, capture_output=True, text=True, timeout=300,
+                             env=dict(os.environ, LFHE_COMPACT_CASE=f.name))
+    finally:
+        os.unlink(f.name)
     assert out.returncode == 0, out.stdout + out.stderr
     d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["compact"] == [str(v) for v in vals]
     assert d["add"] == "59" and d["sub"] == "25" and d["lt"] == "0" and d["eq"] == "1"
     assert d["mul64"] == "18434227713315959936" and d["batch"] == ["1", "0"]
     assert d["restored"] == ["42", "17"] and d["blobBytes"] < 8192      # compressed for storage and back

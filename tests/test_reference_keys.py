@@ -180,3 +180,86 @@ def test_inputs_under_the_reference_public_key_are_cast_and_computed_on():
         assert ctx.decrypt(raw) != 0xBEEF                                       # not decryptable before the cast
     finally:
         ctx.close()
+
+
+def _extract_under_pke_secret(c0, bodies, pke_sk):
+    """Phases of the LWE ciphertexts of a compact list under the public-key secret (numpy, no GPU):
+    block i = coefficient i of c1 - c0 (*) rev(s)."""
+    n = len(c0)
+    out = []
+    with np.errstate(over="ignore"):
+        for i in range(len(bodies)):
+            m = np.empty(n, dtype=np.uint64)
+            m[:i + 1] = c0[i::-1]
+            m[i + 1:] = np.uint64(0) - c0[n - 1:i:-1]
+            out.append(int(np.uint64(bodies[i]) - (m[::-1] * pke_sk).sum(dtype=np.uint64)))
+    return out
+
+
+def test_compact_lists_decrypt_under_the_reference_keys_and_are_found_in_a_container():
+    """A compact ciphertext list built under the reference's publicKey.bin decrypts, coefficient by
+    coefficient, under the public-key secret stored in privateKey.bin (two radix blocks per
+    ciphertext when packed); the list and radix ciphertexts are found inside a bincode-style
+    container whatever the framing around their length-prefixed word vectors."""
+    priv, pub = _blobs()
+    k = W.parse_client_key(priv)
+    mask, body = W.parse_compact_public_key(pub)
+    vals, widths = [0xDEADBEEFCAFEF00D, 1, 200, 0xABCD], [64, 1, 8, 16]
+    blocks = []
+    for v, w in zip(vals, widths):
+        blocks += [v & 1] if w == 1 else [(v >> (2 * i)) & 3 for i in range(w // 2)]
+    for packed in (True, False):
+        c0, bodies = W.build_compact_list(mask, body, vals, widths, bytes(range(32)), packed=packed)
+        want = [blocks[i] + 4 * (blocks[i + 1] if i + 1 < len(blocks) else 0) for i in range(0, len(blocks), 2)] if packed else blocks
+        assert len(bodies) == len(want)
+        got = [((p + (1 << 58)) >> 59) & 15 for p in _extract_under_pke_secret(c0, bodies, k["pke_sk"])]
+        assert got == want
+        noise = [((p - (m << 59) + (1 << 63)) % (1 << 64)) - (1 << 63) for p, m in zip(_extract_under_pke_secret(c0, bodies, k["pke_sk"]), want)]
+        assert max(abs(e) for e in noise) < 1 << 40
+        # a container in the style of the key fixtures: header strings, version tags, the vector, trailing fields, proof bytes
+        words = np.concatenate([c0, bodies]).astype("<u8")
+        blob = (b"\x03" + bytes(7) + b"0.5" + bytes(4) + b"\x19" + bytes(7) + b"CompactCiphertextList" + bytes(9)
+                + struct.pack("<Q", len(words)) + words.tobytes() + struct.pack("<IQQ", 0, 2049, len(bodies)) + bytes(range(200)))
+        m2, b2 = W.parse_compact_list(blob)
+        assert np.array_equal(m2, c0) and np.array_equal(b2, bodies)
+    with pytest.raises(ValueError):
+        W.parse_compact_list(bytes(5000))
+    # radix ciphertext: blocks as length-prefixed vectors of 2049 words, metadata behind each
+    rng = np.random.default_rng(3)
+    blks = rng.integers(0, 1 << 64, size=(4, 2049), dtype=np.uint64)
+    meta = struct.pack("<I", 0) + bytes(16) + struct.pack("<Q", 64) + struct.pack("<IQ", 0, 3) + struct.pack("<IQ", 0, 2) + bytes(24)
+    blob = b"hdr" + bytes(20) + struct.pack("<Q", 4) + b"".join(struct.pack("<IQ", 1, 2049) + b.tobytes() + meta for b in blks)
+    ct = W.parse_radix_ciphertext(blob, 8)
+    assert ct[:16] == struct.pack("<IHHIBBH", 0x5443464C, 1, 8, 4, 2, 3, 0)
+    assert np.array_equal(np.frombuffer(ct[16:], dtype=np.uint64).reshape(4, 2049), blks)
+    with pytest.raises(ValueError):
+        W.parse_radix_ciphertext(blob, 16)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("packed", [True, False], ids=["packed", "one-block-per-ciphertext"])
+def test_compact_input_list_is_expanded_cast_and_computed_on(packed):
+    """The reference's input flow end to end (sdk/relayer/src/sdk/encrypt.ts:54-196 on the client;
+    expand + cast on the coprocessor): values of mixed types in ONE compact list under the
+    reference's public key -> ciphertexts under the compute key -> operators -> decryption with the
+    reference's client key."""
+    from fhe_amd.native import Context, LfheError
+    priv, pub = _blobs()
+    k = W.parse_client_key(priv)
+    mask, body = W.parse_compact_public_key(pub)
+    vals, widths = [0xDEADBEEFCAFEF00D, 1, 200, 0xABCD, 0x0123456789ABCDEF], [64, 1, 8, 16, 64]
+    c0, bodies = W.build_compact_list(mask, body, vals, widths, bytes(range(1, 33)), packed=packed)
+    ctx = Context(seed=bytes(range(32)), params_id=3)
+    try:
+        ctx.import_client_keys_raw(k["lwe_sk"], k["glwe_sk"])
+        ctx.keygen_server()
+        ctx.set_pke_key(k["pke_sk"])
+        cts = ctx.expand_compact_list(c0, bodies, widths, packed=packed)
+        assert [ctx.decrypt(c) for c in cts] == vals
+        assert [len(c) for c in cts] == [ctx.ciphertext_size(w) for w in widths]
+        assert ctx.decrypt(ctx.evaluate("add", 64, cts[0], cts[4])) == (vals[0] + vals[4]) & ((1 << 64) - 1)
+        assert ctx.decrypt(ctx.evaluate("select", 16, cts[3], ctx.encrypt(7, 16), cts[1])) == 0xABCD
+        with pytest.raises(LfheError):
+            ctx.expand_compact_list(c0, bodies[:-1], widths, packed=packed)       # length does not match the types
+    finally:
+        ctx.close()
