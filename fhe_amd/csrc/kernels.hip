@@ -822,12 +822,11 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_q2_pair(Tables T, const 
     auto buf = [&](int c, int q) { return lds_dyn + (2 * c + q) * POLY_STRIDE; };
     const int groups = (n + 1) / 2;
     for (int g = 0; g < groups; ++g) {
-        unsigned am[NC][3];
+        unsigned am[NC][2];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             am[c][0] = modswitch_2n(lwe[c][2 * g]);
             am[c][1] = 2 * g + 1 < n ? modswitch_2n(lwe[c][2 * g + 1]) : 0u;
-            am[c][2] = (am[c][0] + am[c][1]) & (2 * N - 1);
         }
         // addresses are recomputed per phase instead of living in registers across the step loop
         unsigned tt = t, zero = 0;
@@ -885,11 +884,13 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_q2_pair(Tables T, const 
         asm volatile("" : "+v"(tt));
         {
             const unsigned ut = 2 * rev8(tt) + 1;
-            double base[NC][3];
+            // psi^(a u_t), psi^(a' u_t): X^(a + a') is never formed, the step's GGSW is evaluated as
+            // (K0 + X^a K1) + X^a' (K2 + X^a K3)
+            double base[NC][2];
 #pragma unroll
             for (int c = 0; c < NC; ++c)
 #pragma unroll
-                for (int m = 0; m < 3; ++m) base[c][m] = ldt(mono, (am[c][m] * ut) & (2 * N - 1));
+                for (int m = 0; m < 2; ++m) base[c][m] = ldt(mono, (am[c][m] * ut) & (2 * N - 1));
             // key words of unit u = 4 c4 + m: row m, the four polynomials q, positions 8 t + 2 c4 + {0, 1};
             // the next unit's four 16-byte loads are in flight while this one is multiplied into both
             // ciphertexts; the first unit's are requested here, ahead of the last forward pass
@@ -907,7 +908,12 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_q2_pair(Tables T, const 
             const double* __restrict__ w8 = mono + MONO_WORDS;
             auto chunk = [&](auto c4_tag) {
                 constexpr int c4 = decltype(c4_tag)::value;
-                double B[NC][4][2];
+                double B[NC][4][2], S[NC][4][2], M1[NC][2], M2[NC][2];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    mono_pair<c4>(base[c][0], w8, am[c][0], P, M1[c][0], M1[c][1]);
+                    mono_pair<c4>(base[c][1], w8, am[c][1], P, M2[c][0], M2[c][1]);
+                }
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     const int u = 4 * c4 + m;
@@ -926,13 +932,24 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_q2_pair(Tables T, const 
                             for (int h = 0; h < 2; ++h)
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) B[c][q][h] = kc[q][h];
-                        } else {
-                            double M[2];
-                            mono_pair<c4>(base[c][m - 1], w8, am[c][m - 1], P, M[0], M[1]);
+                        } else if (m == 1) {   // + X^a K1
 #pragma unroll
                             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                                for (int q = 0; q < 4; ++q) B[c][q][h] += mmul(M[h], kc[q][h], P);
+                                for (int q = 0; q < 4; ++q) B[c][q][h] += mmul(M1[c][h], kc[q][h], P);
+                        } else if (m == 2) {   // the second bracket starts with K2
+#pragma unroll
+                            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) S[c][q][h] = kc[q][h];
+                        } else {               // + X^a K3, then the bracket times X^a' (|S| < 1.1 p: the wide operand)
+#pragma unroll
+                            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const double sum = S[c][q][h] + mmul(M1[c][h], kc[q][h], P);
+                                    B[c][q][h] += mmul(sum, M2[c][h], P);
+                                }
                         }
                     }
                     asm volatile("" ::: "memory");
