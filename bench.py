@@ -59,12 +59,13 @@ def measured_traffic(flavour: str, batch: int):
 # algorithmic bytes of one batch launch: both keys once + one ciphertext in and out per bootstrap
 BSK_BYTES, KSK_BYTES, CT_BYTES = 60162048, 60227584, 16392
 # device image of the bootstrapping key (f64 residues in the transform domain)
-KEY_IMAGE_BYTES = {"q64": 918 * 131072, "prime": 918 * 65536, "grouped": 1836 * 65536}
+KEY_IMAGE_BYTES = {"q64": 918 * 131072, "q64_grouped": 1836 * 131072, "prime": 918 * 65536, "grouped": 1836 * 65536}
 
 
 # bootstrapping-key flavour -> (parameter set id, label, kernel, VALU peak in butterflies/s per GPU)
 FLAVOURS = {
     "q64": (1, "2^64", "k_blind_rotate"),
+    "q64_grouped": (4, "2^64, key bits in pairs", "k_blind_rotate_g64_pair"),
     "prime": (2, "703687441727489 (NTT prime)", "k_blind_rotate_q"),
     "grouped": (3, "703687441727489 (NTT prime), key bits in pairs", "k_blind_rotate_q2_pair<false>"),
 }
@@ -80,11 +81,13 @@ def cpu_baseline(seconds_budget: float = 20.0, flavour: str = "prime"):
     orc.set_ms(orc.gen_ms_zeros(lwe_sk, seed_bytes(9), orc.ms_params().zeros_count))   # same pipeline as the GPU's
     if flavour == "grouped":
         pb = orc.prepare_bsk_qp_grouped(orc.gen_bsk_qp_grouped(lwe_sk, glwe_sk, seed_bytes(9)))
+    elif flavour == "q64_grouped":
+        pb = orc.prepare_bsk_grouped(orc.gen_bsk_grouped(lwe_sk, glwe_sk, seed_bytes(9)))
     elif flavour == "prime":
         pb = orc.prepare_bsk_qp(orc.gen_bsk_qp(lwe_sk, glwe_sk, seed_bytes(9)))
     else:
         pb = orc.prepare_bsk(bsk)
-    pbs_batch = orc.pbs_batch if flavour == "q64" else orc.pbs_batch_qp
+    pbs_batch = orc.pbs_batch if flavour in ("q64", "q64_grouped") else orc.pbs_batch_qp
     r = Rng(seed_bytes(10))
     lut = orc.make_lut(lambda x: x)
     probe = np.stack([orc.encrypt_block(glwe_sk, int(r.u64() % 16), r) for _ in range(threads)])
@@ -266,9 +269,9 @@ def main(argv=None, backend=None):
         total = B * args.steps * world
         value = total / elapsed
         br_s = br_ms * 1e-3
-        modmul = MODMUL_PER_PBS_GROUPED if flavour == "grouped" else MODMUL_PER_PBS
+        modmul = MODMUL_PER_PBS_GROUPED if flavour in ("grouped", "q64_grouped") else MODMUL_PER_PBS
         achieved = B * modmul / br_s / 1e9
-        peak = PEAK_GBFLY_PER_PRIME / 2 if flavour == "q64" else PEAK_GBFLY_PER_PRIME
+        peak = PEAK_GBFLY_PER_PRIME / 2 if flavour in ("q64", "q64_grouped") else PEAK_GBFLY_PER_PRIME
         algo_bytes = BSK_BYTES + KSK_BYTES + 2 * CT_BYTES * B
         traffic, traffic_source = measured_traffic(flavour, B)
         res = {
@@ -306,12 +309,16 @@ def main(argv=None, backend=None):
             res["mul_pbs"] = probe[1]
         if alts:
             res["other_bootstrapping_keys"] = alts
-            # the parameter set exactly as the reference names it (bootstrapping key over 2^64)
-            q64 = [a for a in alts if a["flavour"] == "q64"]
-            if q64:
-                res["value_q64_key"] = q64[0]["value"]
-        elif flavour == "q64":
+            # the parameter set with every modulus as the reference names it (2^64): the one-bit key any
+            # 2^64 engine can load, and this library's own key with the bits in pairs
+            for name, field in (("q64", "value_q64_key"), ("q64_grouped", "value_q64_grouped_key")):
+                leg = [a for a in alts if a["flavour"] == name]
+                if leg:
+                    res[field] = leg[0]["value"]
+        if flavour == "q64":
             res["value_q64_key"] = value
+        if flavour == "q64_grouped":
+            res["value_q64_grouped_key"] = value
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(flavour=flavour)
         print(json.dumps(res), flush=True)

@@ -129,12 +129,17 @@ int32_t lfhe_ctx_create_custom(lfhe_ctx** out, const lfhe_params* p, int32_t dev
 int32_t lfhe_ctx_create(lfhe_ctx** out, uint32_t params_id, int32_t device, const uint8_t seed[32]) {
     if (params_id != LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128 &&
         params_id != LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK &&
-        params_id != LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK_GROUPED)
+        params_id != LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK_GROUPED &&
+        params_id != LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_GROUPED)
         return LFHE_ERR_UNSUPPORTED;
     lfhe_params p;
     lfhe_default_params(&p);
-    if (params_id != LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128) p.bsk_modulus = LFHE_BSK_MODULUS_PRIME;
-    if (params_id == LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK_GROUPED) p.bsk_grouping = 2;
+    if (params_id == LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK ||
+        params_id == LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK_GROUPED)
+        p.bsk_modulus = LFHE_BSK_MODULUS_PRIME;
+    if (params_id == LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK_GROUPED ||
+        params_id == LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_GROUPED)
+        p.bsk_grouping = 2;
     return lfhe_ctx_create_custom(out, &p, device, seed);
 }
 
@@ -505,7 +510,7 @@ int32_t lfhe_external_product(lfhe_ctx* ctx, uint64_t count, const uint32_t* ggs
         if (!count) return LFHE_OK;
         if (!ggsw_index || !glwe || !out) throw std::invalid_argument("null pointer");
         for (uint64_t i = 0; i < count; ++i)
-            if (ggsw_index[i] >= ctx->prm.lwe_dim) throw std::invalid_argument("ggsw_index out of range");
+            if (ggsw_index[i] >= ctx->eng->bsk_ggsw_count()) throw std::invalid_argument("ggsw_index out of range");
         if (ctx->prm.bsk_modulus)
             for (uint64_t i = 0; i < count * 2 * N; ++i)
                 if (glwe[i] >= ctx->prm.bsk_modulus) throw std::invalid_argument("residue not reduced");

@@ -25,8 +25,7 @@ Engine::Engine(int device, const EngineParams& p) : device_(device), prm_(p) {
     if (p.lwe_dim < 1 || p.lwe_dim > 4096) throw std::runtime_error("unsupported LWE dimension");
     if (p.bsk_modulus != 0 && p.bsk_modulus != QP_U)
         throw std::runtime_error("unsupported bootstrapping-key modulus: 0 (2^64) or 703687441727489");
-    if (p.bsk_grouping != 1 && !(p.bsk_grouping == 2 && p.bsk_modulus == QP_U))
-        throw std::runtime_error("unsupported key grouping: 1, or 2 with the prime bootstrapping-key modulus");
+    if (p.bsk_grouping != 1 && p.bsk_grouping != 2) throw std::runtime_error("unsupported key grouping: 1 or 2");
     if (p.ms_zeros_count && (p.ms_bound_log2 < 27 || p.ms_bound_log2 > 63 || !(p.ms_r_sigma_factor > 0) ||
                              !(p.ms_r_sigma_factor < 1024) || !(p.ms_input_variance >= 0) ||
                              !(p.ms_input_variance < 1e-3)))
@@ -58,7 +57,7 @@ Engine::Engine(int device, const EngineParams& p) : device_(device), prm_(p) {
 
     HostTables H;
     build_host_tables(H);
-    HC(hipMalloc(&d_tw_, sizeof(double) * (4 * N + MONO_WORDS + 8)));
+    HC(hipMalloc(&d_tw_, sizeof(double) * (4 * N + 2 * (MONO_WORDS + 8))));
     for (int r = 0; r < 2; ++r) {
         HC(hipMemcpy(d_tw_ + (2 * r) * N, H.tw_fwd[r].data(), sizeof(double) * N, hipMemcpyHostToDevice));
         HC(hipMemcpy(d_tw_ + (2 * r + 1) * N, H.tw_inv[r].data(), sizeof(double) * N, hipMemcpyHostToDevice));
@@ -70,16 +69,17 @@ Engine::Engine(int device, const EngineParams& p) : device_(device), prm_(p) {
         T_.ninv[r] = H.ninv[r];
     }
     T_.p0inv_mod_p1 = H.p0inv_mod_p1;
-    {   // psi^k over prime 0 for every exponent k of X^k (k < 2N), then the 8th roots of unity
+    for (int r = 0; r < 2; ++r) {   // psi^k over prime r for every exponent k of X^k (k < 2N), then the 8th roots of unity
         std::vector<double> mono(MONO_WORDS + 8);
         u64 w = 1;
         for (int k = 0; k < MONO_WORDS; ++k) {
-            mono[k] = h_centred(w, H.p[0]);
-            if (k % (N / 4) == 0) mono[MONO_WORDS + k / (N / 4)] = h_centred(w, H.p[0]);
-            w = h_mulmod(w, H.psi[0], H.p[0]);
+            mono[k] = h_centred(w, H.p[r]);
+            if (k % (N / 4) == 0) mono[MONO_WORDS + k / (N / 4)] = h_centred(w, H.p[r]);
+            w = h_mulmod(w, H.psi[r], H.p[r]);
         }
-        HC(hipMemcpy(d_tw_ + 4 * N, mono.data(), sizeof(double) * mono.size(), hipMemcpyHostToDevice));
-        T_.mono = d_tw_ + 4 * N;
+        double* dst = d_tw_ + 4 * N + r * (MONO_WORDS + 8);
+        HC(hipMemcpy(dst, mono.data(), sizeof(double) * mono.size(), hipMemcpyHostToDevice));
+        (r == 0 ? T_.mono : T_.mono1) = dst;
     }
 }
 
@@ -411,7 +411,8 @@ void Engine::blind_rotate_with(const double* bsk, uint32_t n, const u64* lwe_sma
     if (!count) return;
     HC(hipSetDevice(device_));
     const size_t n1 = (size_t)n + 1;
-    const size_t slots = (size_t)(single_modulus() ? 4 : 2) * (size_t)cu_count_;   // resident workgroups
+    // ciphertexts in flight: four per CU, two with the one-bit-per-step key over 2^64
+    const size_t slots = (size_t)(single_modulus() || prm_.bsk_grouping == 2 ? 4 : 2) * (size_t)cu_count_;
     if (omap.idx && !omap.ops) throw std::logic_error("block map without a period");
     const size_t chunk = br_chunk_ > 0 ? (omap.ops ? ((size_t)br_chunk_ + omap.ops - 1) / omap.ops * omap.ops : (size_t)br_chunk_)
                                        : launch_chunk(count, omap.ops, slots);
@@ -433,7 +434,7 @@ void Engine::blind_rotate_with(const double* bsk, uint32_t n, const u64* lwe_sma
                                   pair_threshold(cnt),
                                   stream_);
         else
-            launch_blind_rotate(T_, bsk, in, (int)n, luts, li, gout, lout, cnt, omap, stream_);
+            launch_blind_rotate(T_, bsk, in, (int)n, luts, li, gout, lout, cnt, omap, (int)prm_.bsk_grouping, stream_);
         HC(hipGetLastError());
     }
 }

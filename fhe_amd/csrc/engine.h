@@ -39,8 +39,8 @@ struct EngineParams {
     // ring modulus of the bootstrapping key and the accumulator: 0 = 2^64 (two-prime transform and
     // lift), QP_U = the NTT prime itself (single transform, modulus switch on the way in and out)
     uint64_t bsk_modulus = 0;
-    // key bits per blind-rotation step: 1, or 2 (needs the prime ring modulus): the key then holds
-    // four GGSWs per pair of bits and a step is one external product for two mask elements
+    // key bits per blind-rotation step: 1, or 2: the key then holds four GGSWs per pair of bits and a
+    // step is one external product for two mask elements (over either ring modulus)
     uint32_t bsk_grouping = 1;
 };
 
@@ -51,7 +51,7 @@ void launch_external_product(const Tables& T, const double* bsk, const u32* idx,
                              size_t count, hipStream_t st);
 void launch_blind_rotate(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
                          const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
-                         const BlockMap& omap, hipStream_t st);
+                         const BlockMap& omap, int grouping, hipStream_t st);
 void launch_bskq_prepare(const Tables& T, const u64* in, double* out, size_t polys, hipStream_t st);
 void launch_external_product_q(const Tables& T, const double* bsk, const u32* idx, const u64* glwe, u64* out,
                                size_t count, double inv_g, hipStream_t st);

@@ -99,31 +99,9 @@ static void parallel_for(size_t n, int threads, F&& fn) {
     for (auto& th : pool) th.join();
 }
 
-void gen_bsk(const EngineParams& p, const uint64_t* lwe_sk, const uint64_t* glwe_sk, const uint8_t seed[32],
-             uint64_t* bsk, int threads) {
-    const size_t rows = (size_t)p.lwe_dim * 2;  // one level, k + 1 = 2 rows per GGSW
-    parallel_for(rows, threads, [&](size_t row) {
-        ChaCha r(seed, 0x100000000ull + row);  // one stream per GLWE row: order-independent
-        uint64_t* mask = bsk + row * 2 * N;
-        uint64_t* body = mask + N;
-        for (int j = 0; j < N; ++j) mask[j] = r.next();
-        for (int j = 0; j < N; ++j) body[j] = r.tuniform(p.glwe_noise_log2);
-        add_mask_times_binary_key(mask, glwe_sk, body);
-        const size_t i = row >> 1;
-        const int rr = (int)(row & 1);
-        (rr == 0 ? mask : body)[0] += lwe_sk[i] << (64 - p.pbs_base_log);
-    });
-}
-
-// the same key over the ring modulus q': residues in [0, q'), noise uniform in [-E, E] with
-// E = round(2^glwe_noise_log2 q' / 2^64), gadget round(q' / 2^base_log)
-void gen_bsk_qp(const EngineParams& p, const uint64_t* lwe_sk, const uint64_t* glwe_sk, const uint8_t seed[32],
-                uint64_t* bsk, int threads) {
-    const uint64_t Q = QP_U;
-    const uint64_t G = (Q + (1ull << (p.pbs_base_log - 1))) >> p.pbs_base_log;
-    const uint64_t E = (uint64_t)((((unsigned __int128)1 << p.glwe_noise_log2) * Q + ((unsigned __int128)1 << 63)) >> 64);
-    // the bit each GGSW encrypts: the key bits themselves, or per pair (s, s') the four products
-    // (1-s)(1-s'), s(1-s'), (1-s)s', s s' (s' = 0 past the end of an odd-length key)
+// the bit each GGSW of the bootstrapping key encrypts: the key bits themselves, or per pair (s, s')
+// the four products (1-s)(1-s'), s(1-s'), (1-s)s', s s' (s' = 0 past the end of an odd-length key)
+static std::vector<uint64_t> bsk_messages(const EngineParams& p, const uint64_t* lwe_sk) {
     std::vector<uint64_t> msg;
     if (p.bsk_grouping == 2) {
         for (uint32_t g = 0; 2 * g < p.lwe_dim; ++g) {
@@ -134,6 +112,34 @@ void gen_bsk_qp(const EngineParams& p, const uint64_t* lwe_sk, const uint64_t* g
     } else {
         msg.assign(lwe_sk, lwe_sk + p.lwe_dim);
     }
+    return msg;
+}
+
+void gen_bsk(const EngineParams& p, const uint64_t* lwe_sk, const uint64_t* glwe_sk, const uint8_t seed[32],
+             uint64_t* bsk, int threads) {
+    const std::vector<uint64_t> msg = bsk_messages(p, lwe_sk);
+    const size_t rows = msg.size() * 2;  // one level, k + 1 = 2 rows per GGSW
+    parallel_for(rows, threads, [&](size_t row) {
+        ChaCha r(seed, 0x100000000ull + row);  // one stream per GLWE row: order-independent
+        uint64_t* mask = bsk + row * 2 * N;
+        uint64_t* body = mask + N;
+        for (int j = 0; j < N; ++j) mask[j] = r.next();
+        for (int j = 0; j < N; ++j) body[j] = r.tuniform(p.glwe_noise_log2);
+        add_mask_times_binary_key(mask, glwe_sk, body);
+        const size_t i = row >> 1;
+        const int rr = (int)(row & 1);
+        (rr == 0 ? mask : body)[0] += msg[i] << (64 - p.pbs_base_log);
+    });
+}
+
+// the same key over the ring modulus q': residues in [0, q'), noise uniform in [-E, E] with
+// E = round(2^glwe_noise_log2 q' / 2^64), gadget round(q' / 2^base_log)
+void gen_bsk_qp(const EngineParams& p, const uint64_t* lwe_sk, const uint64_t* glwe_sk, const uint8_t seed[32],
+                uint64_t* bsk, int threads) {
+    const uint64_t Q = QP_U;
+    const uint64_t G = (Q + (1ull << (p.pbs_base_log - 1))) >> p.pbs_base_log;
+    const uint64_t E = (uint64_t)((((unsigned __int128)1 << p.glwe_noise_log2) * Q + ((unsigned __int128)1 << 63)) >> 64);
+    const std::vector<uint64_t> msg = bsk_messages(p, lwe_sk);
     const size_t rows = msg.size() * 2;
     parallel_for(rows, threads, [&](size_t row) {
         ChaCha r(seed, 0x400000000ull + row);

@@ -1056,6 +1056,332 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_q2_pair(Tables T, const 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The grouped key over 2^64.  Four GGSWs per pair of key bits as above, but encryptions over the
+// torus 2^64 itself: ciphertexts, accumulator and key stay in the published ring, the step
+//     acc <- (G0 + X^a G1 + X^a' G2 + X^(a+a') G3) [.] acc
+// runs once per prime and the two results are lifted to 2^64 -- half the transforms of the
+// one-bit-per-step blind rotation over 2^64.  Two ciphertexts per workgroup share key words,
+// twiddles and addresses as in k_blind_rotate_q2_pair; the first prime's result waits in registers
+// while the second prime runs.
+//
+// Range of the lift.  A coefficient of the step's result is a sum of 2 N products of a digit
+// (|d| <= 2^22) and a coefficient of the step's GGSW, which is a sum of four key words (< 2^65):
+// the worst case is 2^99, above the +-2^97.6 the two primes tell apart (one GGSW alone stays below
+// 2^97, which is why the one-bit step is exact without condition).  The key words are uniform: the
+// sum has standard deviation 2^90.4 and the window ends at 149 standard deviations, a probability
+// far below 2^-10000 per coefficient against the 2^-128 failure probability of the scheme itself.
+// Inside the window the result is exact and equals the CPU restatement's bit for bit.
+// ------------------------------------------------------------------------------------------------
+constexpr int G64_TW_WORDS = 4 * G2_TW_SMALL;   // entries 0..63 of the forward and inverse tables of either prime
+static constexpr size_t G64_LDS_BYTES = G2P_NC * LDS_BYTES + G64_TW_WORDS * sizeof(double);
+
+// One prime's share of a step for the two ciphertexts of a workgroup: digits in x (pass-1
+// ownership) -> residues of the external product in x (|x| < 2 p, pass-1 ownership).  Ends with the
+// workgroup barrier that frees the exchange buffers.
+template <int R>
+__device__ __forceinline__ void g64_prime_pass(double (&x)[G2P_NC][2][E], const Tables& T,
+                                               const double* __restrict__ rows, const unsigned (&am)[G2P_NC][2],
+                                               unsigned t) {
+    constexpr int NC = G2P_NC;
+    const Prime P = T.pr[R];
+    const double* __restrict__ twf_small = lds_dyn + NC * LDS_WORDS + 2 * R * G2_TW_SMALL;
+    const double* __restrict__ twi_small = twf_small + G2_TW_SMALL;
+    auto buf = [&](int c, int q) { return lds_dyn + (2 * c + q) * POLY_STRIDE; };
+    // addresses are recomputed per phase instead of living in registers across the step loop
+    unsigned tt = t, zero = 0;
+    asm volatile("" : "+v"(tt));
+    asm volatile("" : "+s"(zero));
+    const double* __restrict__ mono = (R == 0 ? T.mono : T.mono1) + zero;
+    const double* __restrict__ twf = T.tw_fwd[R] + zero;
+    const double* __restrict__ twi = T.tw_inv[R] + zero;
+    double w[7];
+    // ---- forward transform of the digits, four polynomials per pass
+    load_tw8(twf_small, 1, w);
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            ct_radix8(x[c][q], w, P);
+            st_o1p12(buf(c, q), tt, x[c][q]);
+        }
+    load_tw8(twf_small, base2(tt), w);
+    __syncthreads();
+    asm volatile("" : "+v"(tt));
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) ld_o2p12(buf(c, q), tt, x[c][q]);
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) ct_radix8(x[c][q], w, P);
+    phase_sync<sync_after(1)>();
+    asm volatile("" : "+v"(tt));
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) st_o2p23(buf(c, q), tt, x[c][q]);
+    load_tw8(twf, base3(tt), w);   // the twiddles of a pass are requested one hand-over ahead
+    phase_sync<sync_after(2)>();
+    asm volatile("" : "+v"(tt));
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) ld_o3p23(buf(c, q), tt, x[c][q]);
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) ct_radix8(x[c][q], w, P);
+    phase_sync<sync_after(3)>();
+    asm volatile("" : "+v"(tt));
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) st_o3p34(buf(c, q), tt, x[c][q]);
+    load_tw4x2(twf, tt, w);
+    phase_sync<sync_after(4)>();
+    // ---- last forward pass, the step's GGSW formed point by point and applied, first inverse pass
+    asm volatile("" : "+v"(tt));
+    {
+        const unsigned ut = 2 * rev8(tt) + 1;
+        double base[NC][2];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) base[c][m] = ldt(mono, (am[c][m] * ut) & (2 * N - 1));
+        // key words of unit u = 4 c4 + m: GGSW m of the group, this prime, the four polynomials q,
+        // positions 8 t + 2 c4 + {0, 1}; the next unit's loads are in flight while this one is multiplied
+        double kc[4][2], kn[4][2];
+#pragma unroll
+        for (unsigned q = 0; q < 4; ++q) { const unsigned o = bsk_off(R, q, 0, tt); kc[q][0] = LFHE_LDK(rows, o); kc[q][1] = LFHE_LDK(rows, o + 1); }
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) ld_o4p34(buf(c, q), tt, x[c][q]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) ct_radix4x2(x[c][q], w, P);
+        load_tw4x2(twi, tt, w);   // for the inverse pass below: in flight during the point-wise stage
+        const double* __restrict__ w8 = mono + MONO_WORDS;
+        auto chunk = [&](auto c4_tag) {
+            constexpr int c4 = decltype(c4_tag)::value;
+            double B[NC][4][2], S[NC][4][2], M1[NC][2], M2[NC][2];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                mono_pair<c4>(base[c][0], w8, am[c][0], P, M1[c][0], M1[c][1]);
+                mono_pair<c4>(base[c][1], w8, am[c][1], P, M2[c][0], M2[c][1]);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int u = 4 * c4 + m;
+                if (u < 15) {
+                    const unsigned c4n = (unsigned)(u + 1) / 4, mn = (unsigned)(u + 1) % 4;
+#pragma unroll
+                    for (unsigned q = 0; q < 4; ++q) {
+                        const unsigned o = mn * (unsigned)BSK_ROW + bsk_off(R, q, c4n, tt);
+                        kn[q][0] = LFHE_LDK(rows, o); kn[q][1] = LFHE_LDK(rows, o + 1);
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    if (m == 0) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) B[c][q][h] = kc[q][h];
+                    } else if (m == 1) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) B[c][q][h] += mmul(M1[c][h], kc[q][h], P);
+                    } else if (m == 2) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) S[c][q][h] = kc[q][h];
+                    } else {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const double sum = S[c][q][h] + mmul(M1[c][h], kc[q][h], P);
+                                B[c][q][h] += mmul(sum, M2[c][h], P);
+                            }
+                    }
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { kc[q][0] = kn[q][0]; kc[q][1] = kn[q][1]; }
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int j = 2 * c4 + h;
+                    const double d0 = mnorm(x[c][0][j], P), d1 = mnorm(x[c][1][j], P);
+                    x[c][0][j] = mmul(B[c][0][h], d0, P) + mmul(B[c][2][h], d1, P);
+                    x[c][1][j] = mmul(B[c][1][h], d0, P) + mmul(B[c][3][h], d1, P);
+                }
+        };
+        chunk(std::integral_constant<int, 0>{});
+        chunk(std::integral_constant<int, 1>{});
+        chunk(std::integral_constant<int, 2>{});
+        chunk(std::integral_constant<int, 3>{});
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) gs_radix4x2<GS_NORM_PASS4[0], GS_NORM_PASS4[1]>(x[c][q], w, P);
+    }
+    phase_sync<sync_after(5)>();
+    // ---- inverse transform
+    asm volatile("" : "+v"(tt));
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) st_o4p34(buf(c, q), tt, x[c][q]);
+    load_tw8(twi, base3(tt), w);
+    phase_sync<sync_after(6)>();
+    asm volatile("" : "+v"(tt));
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) ld_o3p34(buf(c, q), tt, x[c][q]);
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) gs_radix8<GS_NORM_PASS3[0], GS_NORM_PASS3[1], GS_NORM_PASS3[2]>(x[c][q], w, P);
+    phase_sync<sync_after(7)>();
+    asm volatile("" : "+v"(tt));
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) st_o3p23(buf(c, q), tt, x[c][q]);
+    load_tw8(twi_small, base2(tt), w);
+    phase_sync<sync_after(8)>();
+    asm volatile("" : "+v"(tt));
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) ld_o2p23(buf(c, q), tt, x[c][q]);
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) gs_radix8<GS_NORM_PASS2[0], GS_NORM_PASS2[1], GS_NORM_PASS2[2]>(x[c][q], w, P);
+    phase_sync<sync_after(9)>();
+    asm volatile("" : "+v"(tt));
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) st_o2p12(buf(c, q), tt, x[c][q]);
+    load_tw8(twi_small, 1, w);
+    __syncthreads();
+    asm volatile("" : "+v"(tt));
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) ld_o1p12(buf(c, q), tt, x[c][q]);
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) gs_radix8<GS_NORM_PASS1[0], GS_NORM_PASS1[1], GS_NORM_PASS1[2]>(x[c][q], w, P);
+    __syncthreads();  // the last pass's reads are done before the buffers are written again
+}
+
+__global__ void __launch_bounds__(NT, 2) k_blind_rotate_g64_pair(Tables T, const double* __restrict__ bsk,
+                                                                const u64* __restrict__ lwe_small, int n,
+                                                                const u64* __restrict__ luts,
+                                                                const u32* __restrict__ lut_index,
+                                                                u64* __restrict__ glwe_out,
+                                                                u64* __restrict__ lwe_out, BlockMap omap,
+                                                                unsigned count) {
+    constexpr int NC = G2P_NC;
+    const unsigned t = threadIdx.x;
+    size_t ct[NC];
+    const u64* __restrict__ lwe[NC];
+    u64 acc[NC][2][E];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const size_t want = (size_t)blockIdx.x * NC + c;
+        ct[c] = want < count ? want : (size_t)count - 1;
+        lwe[c] = lwe_small + ct[c] * (size_t)(n + 1);
+        const u64* __restrict__ lut = luts + (size_t)(lut_index ? lut_index[omap.ops ? ct[c] % omap.ops : ct[c]] : 0) * N;
+        const unsigned bt = modswitch_2n(lwe[c][n]);
+        const unsigned a = (2 * N - bt) & (2 * N - 1);  // multiply by X^-b~
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            bool neg;
+            const u64 v = lut[rot_index(own1(t, j), a, neg)];
+            acc[c][0][j] = 0;
+            acc[c][1][j] = neg ? (u64)0 - v : v;
+        }
+    }
+    for (unsigned i = t; i < (unsigned)G64_TW_WORDS; i += NT) {
+        const unsigned r = i / (2 * G2_TW_SMALL), k = i % (2 * G2_TW_SMALL);
+        lds_dyn[NC * LDS_WORDS + i] = k < (unsigned)G2_TW_SMALL ? T.tw_fwd[r][k] : T.tw_inv[r][k - G2_TW_SMALL];
+    }
+    __syncthreads();
+
+    const int groups = (n + 1) / 2;
+    for (int g = 0; g < groups; ++g) {
+        unsigned am[NC][2];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            am[c][0] = modswitch_2n(lwe[c][2 * g]);
+            am[c][1] = 2 * g + 1 < n ? modswitch_2n(lwe[c][2 * g + 1]) : 0u;
+        }
+        const double* __restrict__ rows = bsk + (size_t)4 * g * BSK_ROW;
+        int dig[NC][2][E];
+        double x[NC][2][E], y0[NC][2][E];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    dig[c][q][j] = decomp23(acc[c][q][j]);
+                    x[c][q][j] = (double)dig[c][q][j];
+                }
+        g64_prime_pass<0>(x, T, rows, am, t);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    y0[c][q][j] = x[c][q][j];
+                    x[c][q][j] = (double)dig[c][q][j];
+                }
+        g64_prime_pass<1>(x, T, rows, am, t);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < E; ++j) acc[c][q][j] = crt_wrap(y0[c][q][j], x[c][q][j], T.p0inv_mod_p1, T.pr[1]);
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (c > 0 && (size_t)blockIdx.x * NC + c >= count) break;   // odd batch: the duplicate is not stored
+        if (glwe_out) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < E; ++j) glwe_out[(ct[c] * 2 + q) * N + own1(t, j)] = acc[c][q][j];
+        }
+        if (lwe_out) {  // sample extraction of coefficient 0
+            u64* o = lwe_out + omap.block(ct[c]) * (size_t)(N + 1);
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const unsigned e = own1(t, j);
+                if (e == 0) { o[0] = acc[c][0][j]; o[N] = acc[c][1][j]; }
+                else o[N - e] = (u64)0 - acc[c][0][j];
+            }
+        }
+    }
+}
+
 // The grouped blind rotation for launches too small to fill the GPU: 512 threads per ciphertext, one
 // half per polynomial as in k_blind_rotate_q_wide.  Each half forms the two entries of the step's
 // GGSW that feed its own output polynomial.  Results are bit-identical to k_blind_rotate_q2.
@@ -1242,6 +1568,8 @@ void blind_rotate_setup(int dev) {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2P_LDS_BYTES) == hipSuccess &&
                     hipFuncSetAttribute(reinterpret_cast<const void*>(k_blind_rotate_q2_pair<false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2P_LDS_BYTES) == hipSuccess &&
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(k_blind_rotate_g64_pair),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)G64_LDS_BYTES) == hipSuccess &&
                     hipFuncSetAttribute(reinterpret_cast<const void*>(k_blind_rotate_q2_wide),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE2_LDS_BYTES) == hipSuccess &&
                     hipFuncSetAttribute(reinterpret_cast<const void*>(k_blind_rotate_q_wide),
@@ -1447,7 +1775,12 @@ void launch_external_product(const Tables& T, const double* bsk, const u32* idx,
 }
 void launch_blind_rotate(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
                          const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
-                         const BlockMap& omap, hipStream_t st) {
+                         const BlockMap& omap, int grouping, hipStream_t st) {
+    if (grouping == 2) {   // four GGSWs per pair of key bits, two ciphertexts per workgroup
+        hipLaunchKernelGGL(k_blind_rotate_g64_pair, dim3((unsigned)((count + G2P_NC - 1) / G2P_NC)), dim3(NT), G64_LDS_BYTES,
+                           st, T, bsk, lwe_small, n, luts, lut_index, glwe_out, lwe_out, omap, (unsigned)count);
+        return;
+    }
     hipLaunchKernelGGL(k_blind_rotate, dim3((unsigned)count), dim3(NT), LDS_BYTES, st, T, bsk, lwe_small, n, luts,
                        lut_index, glwe_out, lwe_out, omap);
 }

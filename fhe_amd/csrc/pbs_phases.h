@@ -18,6 +18,7 @@ struct Tables {
     double ninv[2];            // N^-1 mod p, centred
     double p0inv_mod_p1;       // centred
     const double* mono;        // [2N] psi^k over prime 0, centred, then [8] psi^(N k / 4) (grouped blind rotation)
+    const double* mono1;       // the same over prime 1 (grouped key over 2^64)
 };
 
 // Bootstrapping key on the device: f64 residues, N^-1 folded in, transform (bit-reversed) order,

@@ -46,6 +46,11 @@ extern "C" {
  * only the server's bootstrapping key differs (twice the words, 1.4 times the blind-rotation
  * noise variance). */
 #define LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK_GROUPED 3u
+/* the named set itself -- every modulus 2^64, as published -- with the key bits taken two at a time:
+ * four GGSWs over 2^64 per pair of bits, half the transforms of set 1 (two-prime transform and lift
+ * per step).  The lift of a step is exact unless a sum of 4096 products leaves a window of 149
+ * standard deviations; set 1 is exact without condition. */
+#define LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_GROUPED 4u
 
 typedef struct lfhe_ctx lfhe_ctx;
 

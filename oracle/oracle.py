@@ -134,6 +134,10 @@ def lib():
         "orc_bsk_qp_grouped_count": (sz, [C.POINTER(_Params)]),
         "orc_gen_bsk_qp_grouped": (None, [vp, _u64p, _u64p, C.POINTER(_Rng), _u64p]),
         "orc_bsk_qp_grouped_prepare": (vp, [vp, _u64p]),
+        "orc_bsk_grouped_count": (sz, [C.POINTER(_Params)]),
+        "orc_gen_bsk_grouped": (None, [vp, _u64p, _u64p, C.POINTER(_Rng), _u64p]),
+        "orc_bsk_grouped_prepare": (vp, [vp, _u64p]),
+        "orc_group_step": (None, [vp, _u64p, u32, u32, _u64p]),
         "orc_blind_rotate_qp": (None, [vp, vp, _u64p, _u64p, _u64p]),
         "orc_pbs_qp": (None, [vp, _u64p, vp, _u64p, _u64p, _u64p]),
         "orc_pbs_batch_qp": (None, [vp, _u64p, vp, _u64p, _u64p, vp, _u64p, sz, C.c_int]),
@@ -329,6 +333,22 @@ class Oracle:
     def prepare_bsk(self, bsk: np.ndarray):
         return _PreparedBsk(self, bsk)
 
+    # -- grouped key over 2^64: four GGSWs per pair of key bits; blind_rotate / pbs / pbs_batch take
+    # the prepared key like the one-bit key's
+    def gen_bsk_grouped(self, lwe_sk: np.ndarray, glwe_sk: np.ndarray, seed: bytes) -> np.ndarray:
+        count = lib().orc_bsk_grouped_count(C.byref(self._cp))
+        bsk = np.zeros(count * self.ggsw_words(), dtype=np.uint64)
+        lib().orc_gen_bsk_grouped(self._ctx, lwe_sk, glwe_sk, Rng(seed, 8).ref, bsk)
+        return bsk
+
+    def prepare_bsk_grouped(self, bsk: np.ndarray):
+        return _PreparedBsk(self, bsk, grouped64=True)
+
+    def group_step(self, ggsw4: np.ndarray, a0: int, a1: int, acc: np.ndarray) -> np.ndarray:
+        acc = np.array(acc, dtype=np.uint64, copy=True)
+        lib().orc_group_step(self._ctx, np.ascontiguousarray(ggsw4, dtype=np.uint64), a0, a1, acc)
+        return acc
+
     def blind_rotate(self, pbsk, lwe_small: np.ndarray, lut: np.ndarray) -> np.ndarray:
         acc = np.zeros((self.k + 1) * self.N, dtype=np.uint64)
         lib().orc_blind_rotate_prepared(self._ctx, pbsk.h, np.ascontiguousarray(lwe_small),
@@ -426,11 +446,14 @@ class Oracle:
 
 
 class _PreparedBsk:
-    def __init__(self, orc: Oracle, bsk: np.ndarray, prime: bool = False, grouped: bool = False):
+    def __init__(self, orc: Oracle, bsk: np.ndarray, prime: bool = False, grouped: bool = False,
+                 grouped64: bool = False):
         self._orc = orc
         prep = lib().orc_bsk_qp_prepare if prime else lib().orc_bsk_prepare
         if grouped:
             prep = lib().orc_bsk_qp_grouped_prepare
+        if grouped64:
+            prep = lib().orc_bsk_grouped_prepare
         self.h = prep(orc._ctx, np.ascontiguousarray(bsk, dtype=np.uint64))
 
     def __del__(self):

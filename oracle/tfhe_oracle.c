@@ -676,7 +676,8 @@ void orc_sample_extract(const orc_ctx* c, const uint64_t* glwe, uint64_t* lwe_bi
 struct orc_prepared_bsk {
     u64* hat;        /* [i][level][row][poly][prime][N] */
     size_t per_ggsw; /* words per GGSW image */
-    u32 grouping;    /* key bits per blind-rotation step (1, or 2 for the grouped key over q') */
+    u32 grouping;    /* key bits per blind-rotation step (1, or 2 for a grouped key) */
+    u32 raw;         /* 1: hat holds the GGSWs as they are (coefficient domain, 2^64): grouped key over 2^64 */
 };
 
 orc_prepared_bsk* orc_bsk_prepare(const orc_ctx* c, const uint64_t* bsk) {
@@ -685,6 +686,7 @@ orc_prepared_bsk* orc_bsk_prepare(const orc_ctx* c, const uint64_t* bsk) {
     orc_prepared_bsk* b = (orc_prepared_bsk*)malloc(sizeof *b);
     b->per_ggsw = polys * 2 * P->poly_size;
     b->grouping = 1;
+    b->raw = 0;
     b->hat = (u64*)malloc(sizeof(u64) * b->per_ggsw * P->lwe_dim);
     for (u32 i = 0; i < P->lwe_dim; ++i)
         ggsw_to_hat(c, bsk + (size_t)i * polys * P->poly_size, b->hat + (size_t)i * b->per_ggsw);
@@ -697,8 +699,84 @@ void orc_bsk_prepared_free(orc_prepared_bsk* b) {
     free(b);
 }
 
+/* Grouped key over 2^64: the LWE key bits in pairs (s, s') = (s_2g, s_2g+1) (s' = 0 past the end
+ * of an odd-length key); group g holds four GGSWs over the torus, of (1-s)(1-s'), s(1-s'), (1-s)s'
+ * and s s'. */
+size_t orc_bsk_grouped_count(const orc_params* p) { return 4 * (((size_t)p->lwe_dim + 1) / 2); }
+
+void orc_gen_bsk_grouped(const orc_ctx* c, const uint64_t* lwe_sk, const uint64_t* glwe_sk, orc_rng* r,
+                         uint64_t* bsk) {
+    const orc_params* P = &c->prm;
+    const u32 N = P->poly_size, k = P->glwe_dim;
+    const size_t row_len = (size_t)(k + 1) * N;
+    const u32 groups = (P->lwe_dim + 1) / 2;
+    u64* row = bsk;
+    for (u32 g = 0; g < groups; ++g) {
+        const u64 s0 = lwe_sk[2 * g], s1 = 2 * g + 1 < P->lwe_dim ? lwe_sk[2 * g + 1] : 0;
+        const u64 msg[4] = {(1 - s0) & (1 - s1), s0 & (1 - s1), (1 - s0) & s1, s0 & s1};
+        for (u32 m = 0; m < 4; ++m)
+            for (u32 lv = 0; lv < P->pbs_level; ++lv)
+                for (u32 rr = 0; rr <= k; ++rr, row += row_len) {
+                    orc_glwe_encrypt(c, glwe_sk, NULL, r, row);
+                    row[(size_t)rr * N] += msg[m] << (64 - P->pbs_base_log * (lv + 1));
+                }
+    }
+}
+
+orc_prepared_bsk* orc_bsk_grouped_prepare(const orc_ctx* c, const uint64_t* bsk) {
+    const orc_params* P = &c->prm;
+    const size_t polys = (size_t)P->pbs_level * (P->glwe_dim + 1) * (P->glwe_dim + 1);
+    const size_t count = orc_bsk_grouped_count(P);
+    orc_prepared_bsk* b = (orc_prepared_bsk*)malloc(sizeof *b);
+    b->per_ggsw = polys * P->poly_size;
+    b->grouping = 2;
+    b->raw = 1;
+    b->hat = (u64*)malloc(sizeof(u64) * b->per_ggsw * count);
+    memcpy(b->hat, bsk, sizeof(u64) * b->per_ggsw * count);
+    return b;
+}
+
+/* One step with two mask elements over 2^64:  acc <- B [.] acc  with
+ *     B = G0 + X^a G1 + X^a' G2 + X^(a+a') G3,
+ * an encryption of X^(a s + a' s').  B is formed here in the coefficient domain with wrapping words
+ * (only its value modulo 2^64 enters the result), then the ordinary external product runs over the
+ * two 62-bit primes, whose product leaves no doubt about the lift. */
+void orc_group_step(const orc_ctx* c, const uint64_t* ggsw4, uint32_t a0, uint32_t a1, uint64_t* acc) {
+    const orc_params* P = &c->prm;
+    const u32 N = P->poly_size, k1 = P->glwe_dim + 1;
+    const size_t polys = (size_t)P->pbs_level * k1 * k1, per = polys * N;
+    const u32 a[4] = {0, a0, a1, (a0 + a1) % (2 * N)};
+    u64* B = (u64*)calloc(per + N + (size_t)k1 * N, sizeof(u64));
+    u64 *rot = B + per, *out = rot + N;
+    for (u32 m = 0; m < 4; ++m)
+        for (size_t q = 0; q < polys; ++q) {
+            orc_monomial_mul(rot, ggsw4 + (size_t)m * per + q * N, a[m], N);
+            for (u32 j = 0; j < N; ++j) B[q * N + j] += rot[j];
+        }
+    orc_external_product(c, B, acc, out);
+    memcpy(acc, out, sizeof(u64) * (size_t)k1 * N);
+    free(B);
+}
+
+static void blind_rotate_grouped(const orc_ctx* c, const orc_prepared_bsk* pb, const u64* lwe_small,
+                                 const u64* lut, u64* acc) {
+    const orc_params* P = &c->prm;
+    const u32 N = P->poly_size, k1 = P->glwe_dim + 1, n = P->lwe_dim;
+    const u32 log2n = c->logN + 1, groups = (n + 1) / 2;
+    const u32 bt = orc_modswitch(lwe_small[n], log2n);
+    for (u32 q = 0; q < k1; ++q)
+        orc_monomial_mul(acc + (size_t)q * N, lut + (size_t)q * N, (2 * N - bt) % (2 * N), N);
+    for (u32 g = 0; g < groups; ++g) {
+        const u32 a0 = orc_modswitch(lwe_small[2 * g], log2n);
+        const u32 a1 = 2 * g + 1 < n ? orc_modswitch(lwe_small[2 * g + 1], log2n) : 0;
+        /* every step runs, also the one whose exponents are both zero */
+        orc_group_step(c, pb->hat + (size_t)4 * g * pb->per_ggsw, a0, a1, acc);
+    }
+}
+
 static void blind_rotate_hat(const orc_ctx* c, const orc_prepared_bsk* pb, const u64* lwe_small,
                              const u64* lut, u64* acc) {
+    if (pb->raw) { blind_rotate_grouped(c, pb, lwe_small, lut, acc); return; }
     const orc_params* P = &c->prm;
     const u32 N = P->poly_size, k1 = P->glwe_dim + 1, n = P->lwe_dim;
     const u32 log2n = c->logN + 1;
@@ -910,6 +988,7 @@ static orc_prepared_bsk* bsk_qp_prepare_n(const orc_ctx* c, const u64* bsk, size
     orc_prepared_bsk* b = (orc_prepared_bsk*)malloc(sizeof *b);
     b->per_ggsw = per;
     b->grouping = grouping;
+    b->raw = 0;
     b->hat = (u64*)malloc(sizeof(u64) * per * count);
     for (size_t i = 0; i < count; ++i) ggsw_qp_to_hat(c, bsk + i * per, b->hat + i * per);
     return b;

@@ -202,6 +202,16 @@ orc_prepared_bsk* orc_bsk_qp_prepare(const orc_ctx* c, const uint64_t* bsk);
  * elements: acc <- (G0 + X^a G1 + X^a' G2 + X^(a+a') G3) [.] acc, the sum formed in the transform
  * domain (the multi-bit blind rotation of tfhe-rs, grouping factor 2; a pair with a = a' = 0 is
  * skipped).  orc_blind_rotate_qp / orc_pbs_qp / orc_pbs_batch_qp take either kind of prepared key. */
+/* Grouped key over 2^64: four GGSWs over the torus per pair of key bits (of (1-s)(1-s'), s(1-s'),
+ * (1-s)s', s s'); the prepared key goes to orc_blind_rotate_prepared / orc_pbs_prepared /
+ * orc_pbs_batch_prepared like the one-bit key's.  orc_group_step: acc <- (G0 + X^a0 G1 + X^a1 G2 +
+ * X^(a0+a1) G3) [.] acc for the four GGSWs at ggsw4. */
+size_t orc_bsk_grouped_count(const orc_params* p);
+void orc_gen_bsk_grouped(const orc_ctx* c, const uint64_t* lwe_sk, const uint64_t* glwe_sk, orc_rng* r,
+                         uint64_t* bsk);
+orc_prepared_bsk* orc_bsk_grouped_prepare(const orc_ctx* c, const uint64_t* bsk);
+void orc_group_step(const orc_ctx* c, const uint64_t* ggsw4, uint32_t a0, uint32_t a1, uint64_t* acc);
+
 size_t orc_bsk_qp_grouped_count(const orc_params* p);   /* GGSWs in the grouped key */
 void orc_gen_bsk_qp_grouped(const orc_ctx* c, const uint64_t* lwe_sk, const uint64_t* glwe_sk, orc_rng* r,
                             uint64_t* bsk);

@@ -15,14 +15,18 @@ N = 2048
 M64 = (1 << 64) - 1
 
 
-def _mk(n, ks_base_log=4, ks_level=4, seed=1, ms_zeros=0):
+def _mk(n, ks_base_log=4, ks_level=4, seed=1, ms_zeros=0, grouped=False):
     """Oracle and library context over the same keys.  ms_zeros > 0 adds that many encryptions of
-    zero and switches the modulus-switch noise reduction on in both."""
+    zero and switches the modulus-switch noise reduction on in both.  grouped: the bootstrapping key
+    with four GGSWs over 2^64 per pair of key bits."""
     from fhe_amd.native import Context, Params, default_params
     op = OParams(lwe_dim=n, ks_base_log=ks_base_log, ks_level=ks_level)
     orc = Oracle(op)
     keys = orc.gen_keys(seed_bytes(seed))
     p = Params(**{k: getattr(op, k) for k in op.__dataclass_fields__})
+    if grouped:
+        keys = (keys[0], keys[1], orc.gen_bsk_grouped(keys[0], keys[1], seed_bytes(seed)), keys[3])
+        p.bsk_grouping = 2
     zeros = None
     if ms_zeros:
         d = default_params()
@@ -417,7 +421,80 @@ def test_grouped_key_pbs_full_parameters():
         ctx.close()
 
 
-@pytest.mark.parametrize("params_id", [1, 2, 3])
+@pytest.mark.parametrize("n", [12, 13])
+def test_grouped_key_over_the_torus_bit_exact(n):
+    """Two key bits per step, every modulus 2^64 (two-prime transform and lift per step, two
+    ciphertexts per workgroup): accumulators and bootstrapped ciphertexts equal the oracle's bit for
+    bit, for an even and an odd key length, odd and even batches, all-zero masks, masks whose pairs
+    cancel (a + a' = 2N) and accumulators whose digits are all extreme."""
+    orc, keys, ctx = _mk(n, seed=9, grouped=True)
+    try:
+        lwe_sk, glwe_sk, bskg, ksk = keys
+        pb = orc.prepare_bsk_grouped(bskg)
+        r = Rng(seed_bytes(33))
+        W = orc.ggsw_words()
+        # the key rows as the external-product kernel sees them
+        glwe = np.stack([r.u64s(2 * N) for _ in range(3)])
+        glwe[2][:] = 1 << 63
+        gi = np.array([0, 5, 4 * ((n + 1) // 2) - 1], dtype=np.uint32)
+        got = ctx.external_product(gi, glwe)
+        for c in range(3):
+            assert np.array_equal(got[c].reshape(-1), orc.external_product(bskg[gi[c] * W:(gi[c] + 1) * W], glwe[c])), c
+        f = [lambda x: x, lambda x: (3 * x + 1) % 16]
+        luts_o = [orc.make_lut(g) for g in f]
+        luts_g = np.stack([ctx.make_lut(g) for g in f])
+        smalls = np.stack([r.u64s(orc.n + 1) for _ in range(7)])
+        smalls[3][:] = 0
+        smalls[4][0::2] = np.uint64(1 << 63)          # a = N for every first element of a pair
+        smalls[4][1:n:2] = np.uint64(1 << 63)         # ... and a' = N: a + a' = 2N
+        smalls[5][0:n:2] = 0                          # a = 0, a' random
+        li = np.array([0, 1, 1, 0, 1, 0, 1], dtype=np.uint32)
+        got = ctx.blind_rotate(smalls, luts_g, li)    # seven: the last workgroup holds one ciphertext
+        for c in range(7):
+            assert np.array_equal(got[c].reshape(-1), orc.blind_rotate(pb, smalls[c], luts_o[li[c]])), c
+        assert np.array_equal(ctx.blind_rotate(smalls[:6], luts_g, li[:6]), got[:6])
+        cts = np.stack([orc.encrypt_block(glwe_sk, m, r) for m in range(16)])
+        li = np.array([m % 2 for m in range(16)], dtype=np.uint32)
+        out = ctx.pbs_batch(cts, luts_g, li)
+        for m in range(16):
+            assert np.array_equal(out[m], orc.pbs(ksk, pb, cts[m], luts_o[li[m]])), m
+            assert orc.decrypt_block(glwe_sk, out[m]) == f[li[m]](m) % 16
+    finally:
+        ctx.close()
+
+
+def test_grouped_key_over_the_torus_full_parameters():
+    """n = 918, noise reduction on, grouped key over 2^64: outputs decrypt to f(m), a subsample is
+    bit-identical to the oracle (the two 49-bit primes of the kernel against the two 62-bit primes of
+    the oracle: the lift of every step stayed inside its window), noise far below half a message step."""
+    orc, keys, ctx = _mk(918, seed=10, ms_zeros=1449, grouped=True)
+    try:
+        lwe_sk, glwe_sk, bskg, ksk = keys
+        pb = orc.prepare_bsk_grouped(bskg)
+        r = Rng(seed_bytes(34))
+        f = [lambda x: x, lambda x: (x * x + 3) % 16]
+        luts_o = [orc.make_lut(g) for g in f]
+        luts_g = np.stack([ctx.make_lut(g) for g in f])
+        B = 601
+        msgs = [int(r.u64() % 16) for _ in range(B)]
+        cts = np.stack([orc.encrypt_block(glwe_sk, m, r) for m in msgs])
+        idx = np.array([i % 2 for i in range(B)], dtype=np.uint32)
+        out = ctx.pbs_batch(cts, luts_g, idx)
+        worst = 0
+        for i in range(B):
+            want = f[idx[i]](msgs[i]) % 16
+            assert orc.decrypt_block(glwe_sk, out[i]) == want, i
+            e = (orc.lwe_phase(glwe_sk, out[i]) - orc.encode(want)) % (1 << 64)
+            worst = max(worst, min(e, (1 << 64) - e))
+        assert worst < 1 << 53            # half a message step is 2^58
+        for i in (0, 1, 333, 600):
+            assert np.array_equal(out[i], orc.pbs(ksk, pb, cts[i], luts_o[idx[i]])), i
+        assert np.array_equal(ctx.pbs_batch(cts[:8], luts_g, idx[:8]), out[:8])
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("params_id", [1, 2, 3, 4])
 def test_library_keygen_round_trip(params_id):
     """Keys made by the library itself (both bootstrapping-key moduli): encrypt -> bootstrap ->
     decrypt, and the oracle decrypts library ciphertexts with the exported secret key."""
@@ -442,7 +519,7 @@ def test_library_keygen_round_trip(params_id):
         ctx.close()
 
 
-@pytest.mark.parametrize("params_id", [1, 2, 3], ids=["bsk_q64", "bsk_prime", "bsk_prime_grouped"])
+@pytest.mark.parametrize("params_id", [1, 2, 3, 4], ids=["bsk_q64", "bsk_prime", "bsk_prime_grouped", "bsk_q64_grouped"])
 def test_full_size_batch_properties(params_id):
     """The benchmark's configuration (4096 blocks, 16 distinct tables) through size-independent
     properties: every output decrypts to f(m); a second pass gives the same bits (no dependence on
