@@ -122,7 +122,7 @@ def extract(glwe: np.ndarray, count: int) -> np.ndarray:
 
 class Decompressor:
     """Bootstrap of extracted blocks under a key for the compression secret (an Oracle of LWE
-    dimension KC * NC, key of the given flavour: 'q64', 'prime' or 'grouped')."""
+    dimension KC * NC, key of the given flavour: 'q64', 'q64_grouped', 'prime' or 'grouped')."""
 
     def __init__(self, flavour: str, comp_sk: np.ndarray, glwe_sk: np.ndarray, seed: bytes):
         self.flavour = flavour
@@ -134,6 +134,9 @@ class Decompressor:
             self.bsk = np.zeros(L.orc_bsk_len(C.byref(self.orc._cp)), dtype=np.uint64)
             L.orc_gen_bsk(self.orc._ctx, comp_sk, glwe_sk, rng.ref, self.bsk)
             self.pb = self.orc.prepare_bsk(self.bsk)
+        elif flavour == "q64_grouped":
+            self.bsk = self.orc.gen_bsk_grouped(comp_sk, glwe_sk, seed)
+            self.pb = self.orc.prepare_bsk_grouped(self.bsk)
         elif flavour == "prime":
             self.bsk = self.orc.gen_bsk_qp(comp_sk, glwe_sk, seed)
             self.pb = self.orc.prepare_bsk_qp(self.bsk)
@@ -146,7 +149,7 @@ class Decompressor:
 
     def bootstrap(self, small: np.ndarray, lut: np.ndarray) -> np.ndarray:
         o = self.orc
-        if self.flavour == "q64":
+        if self.flavour in ("q64", "q64_grouped"):
             return o.sample_extract(o.blind_rotate(self.pb, small, lut))
         acc = o.blind_rotate_qp(self.pb, small, lut)
         q = o.qp
