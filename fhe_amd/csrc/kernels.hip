@@ -904,7 +904,7 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_q2_pair(Tables T, const 
 #pragma unroll
             for (int c = 0; c < NC; ++c)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) ct_radix4x2(x[c][q], w4f, P);
+                for (int q = 0; q < 2; ++q) ct_radix4x2_bounded(x[c][q], w4f, P);   // |d| < 3.4 p
             const double* __restrict__ w8 = mono + MONO_WORDS;
             auto chunk = [&](auto c4_tag) {
                 constexpr int c4 = decltype(c4_tag)::value;
@@ -961,7 +961,7 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_q2_pair(Tables T, const 
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int j = 2 * c4 + h;
-                        const double d0 = mnorm(x[c][0][j], P), d1 = mnorm(x[c][1][j], P);
+                        const double d0 = x[c][0][j], d1 = x[c][1][j];
                         x[c][0][j] = mmul(B[c][0][h], d0, P) + mmul(B[c][2][h], d1, P);
                         x[c][1][j] = mmul(B[c][1][h], d0, P) + mmul(B[c][3][h], d1, P);
                     }
@@ -1162,7 +1162,7 @@ __device__ __forceinline__ void g64_prime_pass(double (&x)[G2P_NC][2][E], const 
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) ct_radix4x2(x[c][q], w, P);
+            for (int q = 0; q < 2; ++q) ct_radix4x2_bounded(x[c][q], w, P);   // |d| < 3.4 p
         load_tw4x2(twi, tt, w);   // for the inverse pass below: in flight during the point-wise stage
         const double* __restrict__ w8 = mono + MONO_WORDS;
         auto chunk = [&](auto c4_tag) {
@@ -1220,7 +1220,7 @@ __device__ __forceinline__ void g64_prime_pass(double (&x)[G2P_NC][2][E], const 
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int j = 2 * c4 + h;
-                    const double d0 = mnorm(x[c][0][j], P), d1 = mnorm(x[c][1][j], P);
+                    const double d0 = x[c][0][j], d1 = x[c][1][j];
                     x[c][0][j] = mmul(B[c][0][h], d0, P) + mmul(B[c][2][h], d1, P);
                     x[c][1][j] = mmul(B[c][1][h], d0, P) + mmul(B[c][3][h], d1, P);
                 }
@@ -1468,9 +1468,7 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q2_wide(Tables T, co
         wave_sync();
         st_o3p34(mine, t, x); load_tw4x2(twf, t, w);
         wave_sync();
-        ld_o4p34(mine, t, x); ct_radix4x2(x, w, P);
-#pragma unroll
-        for (int j = 0; j < E; ++j) x[j] = mnorm(x[j], P);
+        ld_o4p34(mine, t, x); ct_radix4x2_bounded(x, w, P);   // |d| < 3.4 p for the wide operand of the point-wise stage
         // publish the transformed digits (a thread rewrites the words it has just read) and fetch
         // the other polynomial's
         st_o4p34(mine, t, x); load_tw4x2(twi, t, w);

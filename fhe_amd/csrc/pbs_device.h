@@ -174,6 +174,20 @@ LFHE_HD void ct_radix4x2(double (&x)[8], const double* __restrict__ tw, unsigned
     load_tw4x2(tw, t, w);
     ct_radix4x2(x, w, P);
 }
+LFHE_HD void ct_radix4x2_bounded(double (&x)[8], const double (&w)[7], const Prime& P) {
+    x[0] = mnorm(x[0], P);
+    x[4] = mnorm(x[4], P);
+    ct_radix4x2(x, w, P);
+}
+
+// Last forward pass of a transform whose outputs meet a wide operand in the point-wise stage (the
+// grouped blind rotation: the step's GGSW entry, |B| < 2.2 p): registers 0 and 4 are the only values
+// that reach the outputs of the pass without going through a product, so normalising these two
+// first leaves every output below 3.4 p (two products of operands below 10.2 p on top of 0.5 p) --
+// two normalisations per polynomial instead of eight on the outputs.  |B d| < 7.5 p^2 keeps the
+// quotient estimate of the product below 2^53 and the point-wise sum of two products below 4.5 p,
+// which the inverse transform's schedule takes (its first stage accepts up to 6.3 p).
+LFHE_HD void ct_radix4x2_bounded(double (&x)[8], const double (&w)[7], const Prime& P);
 
 LFHE_HD void norm8(double (&x)[8], const Prime& P) {
 #pragma unroll

@@ -239,7 +239,7 @@ LFHE_HD void ep_group2_phase5(EpState& s, double* lds, unsigned t, const Tables&
     double* b0 = lds;
     double* b1 = lds + POLY_STRIDE;
     ld_o4p34(b0, t, s.x[0]); ld_o4p34(b1, t, s.x[1]);
-    ct_radix4x2(s.x[0], s.tw, P); ct_radix4x2(s.x[1], s.tw, P);
+    ct_radix4x2_bounded(s.x[0], s.tw, P); ct_radix4x2_bounded(s.x[1], s.tw, P);   // |d| < 3.4 p
     load_tw4x2(twi, t, s.tw);   // for the inverse pass below
     // position 8 t + j evaluates at psi^(2 bitrev11(8 t + j) + 1) = psi^(512 bitrev3(j) + 2 rev8(t) + 1)
     const double* __restrict__ w8 = mono + MONO_WORDS;
@@ -284,9 +284,8 @@ LFHE_HD void ep_group2_phase5(EpState& s, double* lds, unsigned t, const Tables&
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int j = 2 * c4 + h;
-            // the transformed digits are brought to |d| <= p/2 (two reductions per point instead of
-            // four for B); B enters as the wide operand, |B| < 2.2 p
-            const double d0 = mnorm(s.x[0][j], P), d1 = mnorm(s.x[1][j], P);
+            // |B| < 2.2 p times |d| < 3.4 p (ct_radix4x2_bounded): within the product's range
+            const double d0 = s.x[0][j], d1 = s.x[1][j];
             s.x[0][j] = mmul(B[0][h], d0, P) + mmul(B[2][h], d1, P);
             s.x[1][j] = mmul(B[1][h], d0, P) + mmul(B[3][h], d1, P);
         }

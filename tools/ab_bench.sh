@@ -7,7 +7,7 @@ set -e
 batch=$1; reps=$2; shift 2
 for rep in $(seq "$reps"); do
   for lib in "$@"; do
-    LFHE_LIB=$PWD/$lib timeout -k 10 300 python bench.py --no-cpu-baseline --no-alt --steps 5 --warmup 1 --batch "$batch" 2>/dev/null \
+    LFHE_LIB=$PWD/$lib timeout -k 10 300 python bench.py --no-cpu-baseline --no-alt --steps 5 --warmup 1 --no-operators --batch "$batch" 2>/dev/null \
       | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('$lib', d['config']['batch_per_gpu'], round(d['value']), d['kernel_ms'], d['verified'])"
   done
 done

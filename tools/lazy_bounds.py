@@ -73,16 +73,37 @@ def schedule_from_header(path):
     return sched
 
 
+def prod2(b, w):
+    """General modular product, neither operand confined to p/2: the quotient estimate must stay
+    below 2^53 (b w < 2^53 / p) and carries the same three roundings."""
+    assert b * w < LIMIT, (b, w)
+    return 0.5 + 2 * C * b * w
+
+
+def grouped_pointwise(monomials=3):
+    """Grouped blind rotation: bound of the transformed digits after the last forward pass when only
+    registers 0 and 4 are normalised before it (ct_radix4x2_bounded), bound of the step's GGSW entry
+    (the gadget row plus `monomials` products of operands <= p/2; the two-factor form nests two of
+    them and stays below this), and bound of the point-wise sum of two products."""
+    f = forward()
+    a = NORM                      # the normalised register: the only value that reaches an output unmultiplied
+    d = a + prod(f[8]) + prod(f[8] + prod(f[8]))
+    B = 0.5 + monomials * prod(0.5)
+    return d, B, 2 * prod2(B, d)
+
+
 def check_header(path):
     """(worst bound, final bound, normalisations per polynomial) of the schedule compiled into the kernels."""
     f = forward()
     assert f[-1] < LIMIT and forward(0.5)[-1] < LIMIT        # digits, and canonical inputs (key preparation)
     w, x, n = inverse(schedule_from_header(path), 2 * prod(f[-1]))
-    # grouped blind rotation: the step's GGSW entry is a sum of three products of operands <= p/2
-    # plus the gadget constant (<= p/2), and multiplies a normalised digit: the point-wise sum is
-    # smaller than the one the schedule was checked for
-    assert 2 * prod(3 * prod(0.5) + 0.5) <= 2 * prod(f[-1])
-    return w, max(x), n
+    # grouped blind rotation: the step's GGSW entry (wide) multiplies transformed digits of which
+    # only two inputs of the last pass were normalised; the schedule's first stage normalises every
+    # sum, so it takes any point-wise bound whose double stays below the limit
+    d, B, pw = grouped_pointwise()
+    wg, xg, ng = inverse(schedule_from_header(path), pw)
+    assert d < 3.4 and B < 2.2 and 2 * pw < LIMIT and wg < LIMIT and max(xg) <= 2.0 and ng == n
+    return max(w, wg), max(max(x), max(xg)), n
 
 
 def main():
