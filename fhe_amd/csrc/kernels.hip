@@ -1008,7 +1008,7 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_q2_pair(Tables T, const 
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) gs_radix8<GS_NORM_PASS2[0], GS_NORM_PASS2[1], GS_NORM_PASS2[2]>(x[c][q], w, P);
+            for (int q = 0; q < 2; ++q) gs_radix8<GS_NORM_PASS2_GROUPED[0], GS_NORM_PASS2_GROUPED[1], GS_NORM_PASS2_GROUPED[2]>(x[c][q], w, P);
         phase_sync<g2_sync_after<LOCKSTEP>(9)>();
         asm volatile("" : "+v"(tt));
 #pragma unroll
@@ -1268,7 +1268,7 @@ __device__ __forceinline__ void g64_prime_pass(double (&x)[G2P_NC][2][E], const 
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) gs_radix8<GS_NORM_PASS2[0], GS_NORM_PASS2[1], GS_NORM_PASS2[2]>(x[c][q], w, P);
+        for (int q = 0; q < 2; ++q) gs_radix8<GS_NORM_PASS2_GROUPED[0], GS_NORM_PASS2_GROUPED[1], GS_NORM_PASS2_GROUPED[2]>(x[c][q], w, P);
     phase_sync<sync_after(9)>();
     asm volatile("" : "+v"(tt));
 #pragma unroll
@@ -1520,7 +1520,7 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q2_wide(Tables T, co
         wave_sync();
         st_o3p23(back, t, x); load_tw8(twi, base2(t), w);
         wave_sync();
-        ld_o2p23(back, t, x); gs_radix8<GS_NORM_PASS2[0], GS_NORM_PASS2[1], GS_NORM_PASS2[2]>(x, w, P);
+        ld_o2p23(back, t, x); gs_radix8<GS_NORM_PASS2_GROUPED[0], GS_NORM_PASS2_GROUPED[1], GS_NORM_PASS2_GROUPED[2]>(x, w, P);
         wave_sync();
         st_o2p12(back, t, x);
         __syncthreads();

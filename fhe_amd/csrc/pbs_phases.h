@@ -213,7 +213,12 @@ template <int C4>
 LFHE_HD void mono_pair(double base, const double* __restrict__ w8, unsigned e, const Prime& P, double& m0, double& m1) {
     constexpr unsigned R[4] = {0, 2, 1, 3};
     m0 = C4 == 0 ? base : mmul(base, w8[(e * R[C4]) & 7u], P);
-    m1 = (e & 1u) ? -m0 : m0;
+    // m1 = (-1)^e m0 as a flip of the sign bit (an exclusive-or with a scalar, where a select on a
+    // 64-bit value costs two conditional moves)
+    u64 bits;
+    __builtin_memcpy(&bits, &m0, 8);
+    bits ^= (u64)(e & 1u) << 63;
+    __builtin_memcpy(&m1, &bits, 8);
 }
 
 LFHE_HD void ep_group2_phase5(EpState& s, double* lds, unsigned t, const Tables& T,
