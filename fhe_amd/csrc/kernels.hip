@@ -1926,11 +1926,16 @@ __global__ void __launch_bounds__(64 * WAVES) k_ms_noise_reduce(u64* __restrict_
 
 void launch_ms_noise_reduce(u64* lwe_small, int n, const u64* zeros, const MsParams& m, int* chosen, size_t count,
                             hipStream_t st) {
-    if (count <= 512)
+    // Candidates per round = waves per workgroup.  The search of one ciphertext ends at the first
+    // candidate within the bound (about one in eighteen is), so the launch ends with its unluckiest
+    // ciphertext, some 150 candidates deep among 4096: measured per 4096 ciphertexts 296-341 us with
+    // four candidates per round, 160-169 with eight, 155-164 with sixteen.  Very long batches are bound
+    // by the candidates evaluated past the chosen one instead and take eight.
+    if (count <= 8192)
         hipLaunchKernelGGL(k_ms_noise_reduce<16>, dim3((unsigned)count), dim3(1024), (size_t)(n + 1) * sizeof(u64), st,
                            lwe_small, n, zeros, m, chosen);
     else
-        hipLaunchKernelGGL(k_ms_noise_reduce<4>, dim3((unsigned)count), dim3(256), (size_t)(n + 1) * sizeof(u64), st,
+        hipLaunchKernelGGL(k_ms_noise_reduce<8>, dim3((unsigned)count), dim3(512), (size_t)(n + 1) * sizeof(u64), st,
                            lwe_small, n, zeros, m, chosen);
 }
 

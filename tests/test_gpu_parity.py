@@ -224,8 +224,8 @@ def test_ms_noise_reduction_bit_exact(full):
         if i != 3:
             assert orc.decode(orc.lwe_phase(lwe_sk, got[i])) == i % 16
     assert chosen[3] == -1 and max(picks) > 3 and len(set(picks)) > 10   # the search really runs
-    # long batches search four candidates per round instead of sixteen: same choices, same words
-    reps = 9
+    # batches of more than 8192 search eight candidates per round instead of sixteen: same choices, same words
+    reps = 120
     got_l, chosen_l = ctx.ms_noise_reduce(np.tile(smalls, (reps, 1)))
     assert np.array_equal(chosen_l, np.tile(chosen, reps)) and np.array_equal(got_l, np.tile(got, (reps, 1)))
     # without encryptions of zero in the key set the stage refuses to run
