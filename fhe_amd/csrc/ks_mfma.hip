@@ -139,6 +139,83 @@ __global__ void __launch_bounds__(256, 2) k_ksm_gemm(const int8_t* __restrict__ 
         }
 }
 
+// The same product for large batches with 256 x 256 tiles: 512 threads = 2 x 4 waves of 128 x 64.
+// With 128 x 128 tiles the kernel is bound by what the tiles re-read through L2 (3.9 GB per 4096
+// ciphertexts at 8.4 TB/s); tiles of twice the side read half of it.  One workgroup per CU (128
+// accumulator registers per lane), two waves per SIMD.
+constexpr int KSM_BIG = 256;
+__global__ void __launch_bounds__(512, 1) k_ksm_gemm256(const int8_t* __restrict__ D, const int8_t* __restrict__ L,
+                                                        int* __restrict__ C, int K, int N) {
+    __shared__ __attribute__((aligned(16))) int8_t As[KSM_BIG * KSM_ROW];
+    __shared__ __attribute__((aligned(16))) int8_t Bs[KSM_BIG * KSM_ROW];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int r = lane & 31, h = lane >> 5;
+    const size_t m0 = (size_t)blockIdx.y * KSM_BIG, n0 = (size_t)blockIdx.x * KSM_BIG;
+
+    // staging: two 16-byte pieces of each tile per thread and stage (rows srow0 and srow0 + 128)
+    const int srow0 = t >> 2, sseg = t & 3;
+    const int8_t* ga0 = D + (m0 + srow0) * (size_t)K + sseg * 16;
+    const int8_t* ga1 = ga0 + (size_t)128 * K;
+    const int8_t* gb0 = L + (n0 + srow0) * (size_t)K + sseg * 16;
+    const int8_t* gb1 = gb0 + (size_t)128 * K;
+    const int so0 = srow0 * KSM_ROW + sseg * 16, so1 = so0 + 128 * KSM_ROW;
+
+    v16i acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
+
+    v4i ra0 = *reinterpret_cast<const v4i*>(ga0), ra1 = *reinterpret_cast<const v4i*>(ga1);
+    v4i rb0 = *reinterpret_cast<const v4i*>(gb0), rb1 = *reinterpret_cast<const v4i*>(gb1);
+    for (int k0 = 0; k0 < K; k0 += KSM_KB) {
+        __syncthreads();   // the previous stage has been read
+        *reinterpret_cast<v4i*>(As + so0) = ra0; *reinterpret_cast<v4i*>(As + so1) = ra1;
+        *reinterpret_cast<v4i*>(Bs + so0) = rb0; *reinterpret_cast<v4i*>(Bs + so1) = rb1;
+        __syncthreads();
+        if (k0 + KSM_KB < K) {   // next stage in flight during the products
+            ra0 = *reinterpret_cast<const v4i*>(ga0 + k0 + KSM_KB); ra1 = *reinterpret_cast<const v4i*>(ga1 + k0 + KSM_KB);
+            rb0 = *reinterpret_cast<const v4i*>(gb0 + k0 + KSM_KB); rb1 = *reinterpret_cast<const v4i*>(gb1 + k0 + KSM_KB);
+        }
+#pragma unroll
+        for (int s = 0; s < KSM_KB / 32; ++s) {
+            v4i a[4], b[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                a[i] = *reinterpret_cast<const v4i*>(As + (wm * 128 + i * 32 + r) * KSM_ROW + s * 32 + h * 16);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                b[j] = *reinterpret_cast<const v4i*>(Bs + (wn * 64 + j * 32 + r) * KSM_ROW + s * 32 + h * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const size_t col = n0 + wn * 64 + j * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const size_t row = m0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                C[row * (size_t)N + col] = acc[i][j][e];
+            }
+        }
+}
+
+// picks the tile size: the large tiles need whole tiles both ways and enough of them to fill the GPU
+static void launch_ksm_gemm(const int8_t* dig, const int8_t* limbs, int* prod, int M, int K, int N, hipStream_t st) {
+    if (M % KSM_BIG == 0 && N % KSM_BIG == 0 && (size_t)(M / KSM_BIG) * (N / KSM_BIG) >= 256)
+        hipLaunchKernelGGL(k_ksm_gemm256, dim3(N / KSM_BIG, M / KSM_BIG), dim3(512), 0, st, dig, limbs, prod, K, N);
+    else
+        hipLaunchKernelGGL(k_ksm_gemm, dim3(N / KSM_TILE, M / KSM_TILE), dim3(256), 0, st, dig, limbs, prod, K, N);
+}
+
 // ---- out[ct][col] = (col == n ? b : 0) - sum_b C[ct][b * cols_pad + col] * 256^b
 __global__ void __launch_bounds__(256) k_ksm_combine(const int* __restrict__ C, const u64* __restrict__ in,
                                                      u64* __restrict__ out, int count, int big, int n, int N, int cols_pad,
@@ -182,7 +259,7 @@ void launch_keyswitch_mfma(const int8_t* limbs, const u64* in, int8_t* dig, int*
     if (dblocks > 16384) dblocks = 16384;
     hipLaunchKernelGGL(k_ksm_digits, dim3(dblocks), dim3(256), 0, st, in, dig, (int)count, M, big, base_log, levels, imap,
                        (u64)1);
-    hipLaunchKernelGGL(k_ksm_gemm, dim3(N / KSM_TILE, M / KSM_TILE), dim3(256), 0, st, dig, limbs, prod, K, N);
+    launch_ksm_gemm(dig, limbs, prod, M, K, N, st);
     const size_t total = count * (size_t)(n + 1);
     unsigned cblocks = (unsigned)((total + 255) / 256);
     if (cblocks > 16384) cblocks = 16384;
@@ -250,7 +327,7 @@ void launch_pack(const int8_t* limbs, const u64* in, int8_t* dig, int* prod, uin
     if (dblocks > 16384) dblocks = 16384;
     hipLaunchKernelGGL(k_ksm_digits, dim3(dblocks), dim3(256), 0, st, in, dig, (int)count, M, big, base_log, levels, imap,
                        scale);
-    hipLaunchKernelGGL(k_ksm_gemm, dim3(N / KSM_TILE, M / KSM_TILE), dim3(256), 0, st, dig, limbs, prod, K, N);
+    launch_ksm_gemm(dig, limbs, prod, M, K, N, st);
     const unsigned groups = (unsigned)((count + nc - 1) / nc);
     hipLaunchKernelGGL(k_pack_combine, dim3(groups, kc + 1), dim3(256), 0, st, prod, in, out, (int)count, big, kc, nc, N,
                        cols, storage_log, scale, imap);
