@@ -18,7 +18,7 @@ def main():
     from fhe_amd.native import Context, KEY_CLIENT
     N, n, B = 2048, 918, int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     res = {}
-    for name, pid in (("q64", 1), ("prime", 2), ("grouped", 3)):
+    for name, pid in (("q64", 1), ("prime", 2), ("grouped", 3), ("q64_grouped", 4)):
         ctx = Context(seed=bytes((13 * i + 1) & 0xFF for i in range(32)), params_id=pid)
         ctx.keygen()
         blob = ctx.export_keys(KEY_CLIENT)
