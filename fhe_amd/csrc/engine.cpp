@@ -111,24 +111,57 @@ void Engine::load_bsk(const u64* host_bsk) {
         HC(hipMalloc(&d_bsk_, bsk_dev_bytes()));
         own_keys_ = true;
     }
-    build_bsk_image(host_bsk, bsk_ggsw_count(), d_bsk_);
+    bsk_factored_ = build_bsk_image(host_bsk, bsk_ggsw_count(), d_bsk_);
+    publish_key_flags();
 }
 
-void Engine::build_bsk_image(const u64* host_bsk, size_t total, double* dst) {
+// The count word of the key-switching key image (how many encryptions of zero follow) carries in its
+// top bit whether the bootstrapping-key image is in factored form, so that an engine which attaches
+// both images (received by a broadcast) knows without being told.
+static constexpr u64 FACTORED_FLAG = 1ull << 63;
+void Engine::publish_key_flags() {
+    if (!d_ksk_ || !own_keys_) return;
+    u64 word = 0;
+    HC(hipMemcpy(&word, ms_zeros_dev() - 1, sizeof word, hipMemcpyDeviceToHost));
+    word = (word & ~FACTORED_FLAG) | (bsk_factored_ ? FACTORED_FLAG : 0);
+    HC(hipMemcpy(ms_zeros_dev() - 1, &word, sizeof word, hipMemcpyHostToDevice));
+}
+
+bool Engine::build_bsk_image(const u64* host_bsk, size_t total, double* dst) {
     // upload and transform in slabs of 64 GGSWs to bound the staging buffer
     const size_t slab = 64;
     const size_t row = single_modulus() ? BSKQ_ROW : BSK_ROW;
     u64* d_raw = nullptr;
     HC(hipMalloc(&d_raw, slab * 4 * N * sizeof(u64)));
-    for (size_t i0 = 0; i0 < total; i0 += slab) {
-        const size_t cnt = (total - i0) < slab ? (total - i0) : slab;
-        HC(hipMemcpyAsync(d_raw, host_bsk + i0 * 4 * N, cnt * 4 * N * sizeof(u64), hipMemcpyHostToDevice, stream_));
-        if (single_modulus()) launch_bskq_prepare(T_, d_raw, dst + i0 * row, cnt * 4, stream_);
-        else launch_ntt_forward(T_, d_raw, dst + i0 * row, cnt * 4, 1, stream_);
+    auto transform_all = [&]() {
+        for (size_t i0 = 0; i0 < total; i0 += slab) {
+            const size_t cnt = (total - i0) < slab ? (total - i0) : slab;
+            HC(hipMemcpyAsync(d_raw, host_bsk + i0 * 4 * N, cnt * 4 * N * sizeof(u64), hipMemcpyHostToDevice, stream_));
+            if (single_modulus()) launch_bskq_prepare(T_, d_raw, dst + i0 * row, cnt * 4, stream_);
+            else launch_ntt_forward(T_, d_raw, dst + i0 * row, cnt * 4, 1, stream_);
+            HC(hipGetLastError());
+            HC(hipStreamSynchronize(stream_));
+        }
+    };
+    transform_all();
+    bool factored = false;
+    const char* env = std::getenv("LFHE_BSK_FACTORED");   // 0: keep the plain image (tests of that path, A/B runs)
+    const bool allow = !(env && std::atoi(env) == 0);
+    if (single_modulus() && prm_.bsk_grouping == 2 && allow) {
+        // the factored form needs every K3 word invertible; a key with a zero word (one in 10^8 keys) keeps
+        // the plain image and the kernels that go with it
+        int* d_flag = reinterpret_cast<int*>(d_raw);
+        int flag = 0;
+        HC(hipMemsetAsync(d_flag, 0, sizeof(int), stream_));
+        launch_bskq_factor(T_, dst, total / 4, d_flag, stream_);
         HC(hipGetLastError());
+        HC(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, stream_));
         HC(hipStreamSynchronize(stream_));
+        factored = flag == 0;
+        if (!factored) transform_all();
     }
     HC(hipFree(d_raw));
+    return factored;
 }
 
 void Engine::load_compression_keys(const CompShape& shape, const u64* host_pksk, const u64* host_decomp_bsk) {
@@ -148,7 +181,7 @@ void Engine::load_compression_keys(const CompShape& shape, const u64* host_pksk,
     HC(hipFree(d_raw));
     const size_t row = single_modulus() ? BSKQ_ROW : BSK_ROW;
     if (!d_decomp_bsk_) HC(hipMalloc(&d_decomp_bsk_, decomp_bsk_ggsw_count() * row * sizeof(double)));
-    build_bsk_image(host_decomp_bsk, decomp_bsk_ggsw_count(), d_decomp_bsk_);
+    decomp_factored_ = build_bsk_image(host_decomp_bsk, decomp_bsk_ggsw_count(), d_decomp_bsk_);
 }
 
 void Engine::compress(const u64* blocks, size_t count, uint16_t* out, u64 scale) {
@@ -181,7 +214,8 @@ void Engine::decompress(const uint16_t* glwe, size_t count, const u64* lut, u64*
     HC(hipMalloc(&small, count * ((size_t)comp_.small_dim() + 1) * sizeof(u64)));
     launch_unpack_extract(glwe, small, count, comp_.kc, comp_.nc, comp_.storage_log, stream_);
     HC(hipGetLastError());
-    blind_rotate_with(d_decomp_bsk_, (uint32_t)comp_.small_dim(), small, lut, nullptr, nullptr, blocks_out, count);
+    blind_rotate_with(d_decomp_bsk_, (uint32_t)comp_.small_dim(), small, lut, nullptr, nullptr, blocks_out, count, BlockMap(),
+                      decomp_factored_ ? 1 : 0);
     HC(hipStreamSynchronize(stream_));
     HC(hipFree(small));
 }
@@ -214,6 +248,7 @@ void Engine::load_ksk(const u64* host_ksk, const u64* ms_zeros) {
     build_ksk_limbs();
     HC(hipStreamSynchronize(stream_));
     set_ms_params((u32)zc);
+    publish_key_flags();
 }
 
 void Engine::build_ksk_limbs() {
@@ -234,7 +269,11 @@ void Engine::attach_device_keys(double* bsk_dev, u64* ksk_dev_image) {
     d_ksk_ = ksk_dev_image;
     u64 zc = 0;
     HC(hipMemcpy(&zc, ms_zeros_dev() - 1, sizeof zc, hipMemcpyDeviceToHost));
+    bsk_factored_ = (zc & FACTORED_FLAG) != 0;
+    zc &= ~FACTORED_FLAG;
     if (zc != 0 && zc != prm_.ms_zeros_count) throw std::runtime_error("attached key image does not match the parameter set");
+    if (bsk_factored_ && !(single_modulus() && prm_.bsk_grouping == 2))
+        throw std::runtime_error("attached key image does not match the parameter set");
     set_ms_params((u32)zc);
     build_ksk_limbs();
     HC(hipStreamSynchronize(stream_));
@@ -407,8 +446,9 @@ void Engine::blind_rotate(const u64* lwe_small, const u64* luts, const u32* lut_
 }
 
 void Engine::blind_rotate_with(const double* bsk, uint32_t n, const u64* lwe_small, const u64* luts, const u32* lut_index,
-                               u64* glwe_out, u64* lwe_out, size_t count, const BlockMap& omap) {
+                               u64* glwe_out, u64* lwe_out, size_t count, const BlockMap& omap, int factored) {
     if (!count) return;
+    const bool fact = factored < 0 ? bsk_factored_ : factored != 0;
     HC(hipSetDevice(device_));
     const size_t n1 = (size_t)n + 1;
     // ciphertexts in flight: four per CU, two with the one-bit-per-step key over 2^64
@@ -430,8 +470,8 @@ void Engine::blind_rotate_with(const double* bsk, uint32_t n, const u64* lwe_sma
         }
         if (single_modulus())
             launch_blind_rotate_q(T_, bsk, in, (int)n, luts, li, gout, lout, cnt, omap,
-                                  1.0 / (double)qp_gadget(), wide_below_, lockstep_above_, (int)prm_.bsk_grouping,
-                                  pair_threshold(cnt),
+                                  1.0 / (double)qp_gadget(), wide_below_, lockstep_above_,
+                                  prm_.bsk_grouping == 2 && fact ? 3 : (int)prm_.bsk_grouping, pair_threshold(cnt),
                                   stream_);
         else
             launch_blind_rotate(T_, bsk, in, (int)n, luts, li, gout, lout, cnt, omap, (int)prm_.bsk_grouping, stream_);
@@ -461,6 +501,7 @@ void Engine::external_product(const u32* ggsw_index, const u64* glwe, u64* out, 
     if (!d_bsk_) throw std::runtime_error("no bootstrapping key loaded");
     if (!count) return;
     HC(hipSetDevice(device_));
+    if (bsk_factored_) throw std::runtime_error("unsupported on a grouped key held in factored form: its rows are no longer GGSWs");
     if (single_modulus()) launch_external_product_q(T_, d_bsk_, ggsw_index, glwe, out, count, 1.0 / (double)qp_gadget(), stream_);
     else launch_external_product(T_, d_bsk_, ggsw_index, glwe, out, count, stream_);
     HC(hipGetLastError());

@@ -53,6 +53,8 @@ void launch_blind_rotate(const Tables& T, const double* bsk, const u64* lwe_smal
                          const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
                          const BlockMap& omap, int grouping, hipStream_t st);
 void launch_bskq_prepare(const Tables& T, const u64* in, double* out, size_t polys, hipStream_t st);
+// grouped single-modulus image -> factored form, in place; *degenerate (device) is set when a word has none
+void launch_bskq_factor(const Tables& T, double* img, size_t groups, int* degenerate, hipStream_t st);
 void launch_external_product_q(const Tables& T, const double* bsk, const u32* idx, const u64* glwe, u64* out,
                                size_t count, double inv_g, hipStream_t st);
 void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
@@ -180,8 +182,12 @@ public:
     void lin_layer(u64* arena, size_t instances, size_t inst_stride_blocks, const LinOp* ops, int nops, u64 delta);
     // the same blind rotation under another bootstrapping key image of this engine's flavour, for
     // small ciphertexts of dimension n
+    // factored: whether that image holds the grouped key in factored form (-1: as the main key's)
     void blind_rotate_with(const double* bsk, uint32_t n, const u64* lwe_small, const u64* luts, const u32* lut_index,
-                           u64* glwe_out, u64* lwe_out, size_t count, const BlockMap& omap = BlockMap());
+                           u64* glwe_out, u64* lwe_out, size_t count, const BlockMap& omap = BlockMap(), int factored = -1);
+    // the grouped key over the prime modulus is held in factored form (two products per GGSW entry
+    // instead of three, pbs_phases.h) unless one of its words has none
+    bool bsk_factored() const { return bsk_factored_; }
     // ---- compression: host keys in (packing key [N][level][(kc+1) nc]; bootstrapping key for the
     // flattened compression secret, same layout and flavour as load_bsk takes)
     void load_compression_keys(const CompShape& shape, const u64* host_pksk, const u64* host_decomp_bsk);
@@ -226,7 +232,9 @@ private:
     CompShape comp_{};
     int8_t* d_pack_limbs_ = nullptr;
     double* d_decomp_bsk_ = nullptr;
-    void build_bsk_image(const u64* host_bsk, size_t ggsw_count, double* dst);
+    bool build_bsk_image(const u64* host_bsk, size_t ggsw_count, double* dst);   // true: factored form
+    bool bsk_factored_ = false, decomp_factored_ = false;
+    void publish_key_flags();   // the count word of the key-switching key image also says how the other image is held
     MsParams ms_{};
     int cu_count_ = 256;
     int br_chunk_ = 0;      // ciphertexts per blind-rotation launch; 0: about four rounds of resident workgroups

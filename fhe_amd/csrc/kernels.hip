@@ -656,7 +656,7 @@ __device__ __forceinline__ void load_tw8_pass3(const double* __restrict__ small,
     }
 }
 
-template <bool LOCKSTEP>
+template <bool LOCKSTEP, bool FACTORED>
 __global__ void __launch_bounds__(NT, 4) k_blind_rotate_q2(Tables T, const double* __restrict__ bsk,
                                                                         const u64* __restrict__ lwe_small, int n,
                                                                         const u64* __restrict__ luts,
@@ -716,7 +716,7 @@ __global__ void __launch_bounds__(NT, 4) k_blind_rotate_q2(Tables T, const doubl
         load_tw8_pass3(twf_small, T.tw_fwd[0], base3(tt), s.tw);
         phase_sync<g2_sync_after<LOCKSTEP>(2)>();
         epq_run_range<LOCKSTEP>(s, lds_dyn, t, T, phase_range<3>(std::make_integer_sequence<int, 2>{}));
-        ep_group2_phase5(s, lds_dyn, t, T, bsk + (size_t)4 * g * BSKQ_ROW, a0, a1);
+        ep_group2_phase5<FACTORED>(s, lds_dyn, t, T, bsk + (size_t)4 * g * BSKQ_ROW, a0, a1);
         phase_sync<g2_sync_after<LOCKSTEP>(5)>();   // the next phase rewrites the words this thread has just read
         asm volatile("" : "+v"(tt));
         st_o4p34(b0, tt, s.x[0]); st_o4p34(b1, tt, s.x[1]);
@@ -771,7 +771,7 @@ __global__ void __launch_bounds__(NT, 4) k_blind_rotate_q2(Tables T, const doubl
 constexpr int G2P_NC = 2;
 static constexpr size_t G2P_LDS_BYTES = G2P_NC * LDS_BYTES + 2 * G2_TW_SMALL * sizeof(double);
 
-template <bool LOCKSTEP>
+template <bool LOCKSTEP, bool FACTORED>
 __global__ void __launch_bounds__(NT, 2) k_blind_rotate_q2_pair(Tables T, const double* __restrict__ bsk,
                                                                const u64* __restrict__ lwe_small, int n,
                                                                const u64* __restrict__ luts,
@@ -926,32 +926,12 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_q2_pair(Tables T, const 
                         }
                     }
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) {
-                        if (m == 0) {   // X^0: the row enters as it is
+                    for (int c = 0; c < NC; ++c)
 #pragma unroll
-                            for (int h = 0; h < 2; ++h)
+                        for (int h = 0; h < 2; ++h)
 #pragma unroll
-                                for (int q = 0; q < 4; ++q) B[c][q][h] = kc[q][h];
-                        } else if (m == 1) {   // + X^a K1
-#pragma unroll
-                            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) B[c][q][h] += mmul(M1[c][h], kc[q][h], P);
-                        } else if (m == 2) {   // the second bracket starts with K2
-#pragma unroll
-                            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) S[c][q][h] = kc[q][h];
-                        } else {               // + X^a K3, then the bracket times X^a' (|S| < 1.1 p: the wide operand)
-#pragma unroll
-                            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    const double sum = S[c][q][h] + mmul(M1[c][h], kc[q][h], P);
-                                    B[c][q][h] += mmul(sum, M2[c][h], P);
-                                }
-                        }
-                    }
+                            for (int q = 0; q < 4; ++q)
+                                ggsw_entry_row<FACTORED>(m, B[c][q][h], S[c][q][h], kc[q][h], M1[c][h], M2[c][h], P);
                     asm volatile("" ::: "memory");
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { kc[q][0] = kn[q][0]; kc[q][1] = kn[q][1]; }
@@ -1389,6 +1369,7 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_g64_pair(Tables T, const
 // step: after pass 1 of the forward transform has been published, after the transformed digits
 // have been published for the other half, and before pass 1 of the inverse transform reads.  Every
 // later write into a buffer is separated from the last cross-wave read of it by one of the three.
+template <bool FACTORED>
 __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q2_wide(Tables T, const double* __restrict__ bsk,
                                                                     const u64* __restrict__ lwe_small, int n,
                                                                     const u64* __restrict__ luts,
@@ -1477,25 +1458,24 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q2_wide(Tables T, co
             double y[E];
             ld_o4p34(theirs, t, y);
             const unsigned ut = 2 * rev8(t) + 1;
-            const unsigned am[3] = {a0, a1, (a0 + a1) & (2 * N - 1)};
+            const unsigned am[2] = {a0, a1};
             const double* __restrict__ w8 = mono + MONO_WORDS;
-            double base[3];
+            double base[2];
 #pragma unroll
-            for (int m = 0; m < 3; ++m) base[m] = ldt(mono, (am[m] * ut) & (2 * N - 1));
+            for (int m = 0; m < 2; ++m) base[m] = ldt(mono, (am[m] * ut) & (2 * N - 1));
             double o[E];
             auto chunk = [&](auto c4_tag) {
                 constexpr int c4 = decltype(c4_tag)::value;
-                double bx[2] = {kx[0][2 * c4], kx[0][2 * c4 + 1]}, by[2] = {ky[0][2 * c4], ky[0][2 * c4 + 1]};
+                double bx[2], by[2], sx[2], sy[2], M1[2], M2[2];
+                mono_pair<c4>(base[0], w8, am[0], P, M1[0], M1[1]);
+                mono_pair<c4>(base[1], w8, am[1], P, M2[0], M2[1]);
 #pragma unroll
-                for (int m = 1; m < 4; ++m) {
-                    double M[2];
-                    mono_pair<c4>(base[m - 1], w8, am[m - 1], P, M[0], M[1]);
+                for (int m = 0; m < 4; ++m)
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
-                        bx[k] += mmul(M[k], kx[m][2 * c4 + k], P);
-                        by[k] += mmul(M[k], ky[m][2 * c4 + k], P);
+                        ggsw_entry_row<FACTORED>(m, bx[k], sx[k], kx[m][2 * c4 + k], M1[k], M2[k], P);
+                        ggsw_entry_row<FACTORED>(m, by[k], sy[k], ky[m][2 * c4 + k], M1[k], M2[k], P);
                     }
-                }
 #pragma unroll
                 for (int k = 0; k < 2; ++k)
                     o[2 * c4 + k] = mmul(bx[k], x[2 * c4 + k], P) + mmul(by[k], y[2 * c4 + k], P);
@@ -1556,24 +1536,97 @@ void launch_external_product_q(const Tables& T, const double* bsk, const u32* id
     hipLaunchKernelGGL(k_external_product_q, dim3((unsigned)count), dim3(NT), LDS_BYTES, st, T, bsk, idx, glwe, out,
                        inv_g);
 }
+// ------------------------------------------------------------------------------------------------
+// Factored form of a grouped key image (pbs_phases.h: ggsw_entry_row).  In place, per group of four
+// rows and per word:  (K0, K1, K2, K3) -> (a, b, d, c) = (K2/K3, K1/K3, K3, K0 - K1 K2 / K3)  mod q'.
+// The rows keep their layout and their N^-1 factor (the ratios do not carry it, d and c do).  A word
+// whose K3 is zero has no factored form: the flag is raised and the caller rebuilds the plain image.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double qp_inverse(double x, const Prime& P) {   // x canonical, non-zero: x^(q' - 2)
+    double r = 1.0;
+#pragma unroll 1
+    for (int bit = 49; bit >= 0; --bit) {
+        r = mnorm(mmul(r, r, P), P);
+        if ((QP_U - 2) >> bit & 1) r = mnorm(mmul(r, x, P), P);
+    }
+    return r;
+}
+
+__global__ void __launch_bounds__(256) k_bskq_factor(Tables T, double* __restrict__ img, size_t groups,
+                                                     int* __restrict__ degenerate) {
+    const Prime P = T.pr[0];
+    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= groups * (size_t)BSKQ_ROW) return;
+    double* w = img + (id / BSKQ_ROW) * 4 * (size_t)BSKQ_ROW + id % BSKQ_ROW;
+    const double k0 = w[0], k1 = w[BSKQ_ROW], k2 = w[2 * (size_t)BSKQ_ROW];
+    const double k3 = qp_canon(mnorm(w[3 * (size_t)BSKQ_ROW], P), P);
+    if (k3 == 0.0) { atomicOr(degenerate, 1); return; }
+    const double inv = qp_inverse(k3, P);
+    const double a = mnorm(mmul(k2, inv, P), P), b = mnorm(mmul(k1, inv, P), P);
+    const double c = mnorm(k0 - mmul(k1, a, P), P);   // K1 K2 / K3 = K1 a
+    w[0] = a;
+    w[BSKQ_ROW] = b;
+    w[2 * (size_t)BSKQ_ROW] = k3;
+    w[3 * (size_t)BSKQ_ROW] = c;
+}
+
+void launch_bskq_factor(const Tables& T, double* img, size_t groups, int* degenerate, hipStream_t st) {
+    const size_t words = groups * (size_t)BSKQ_ROW;
+    hipLaunchKernelGGL(k_bskq_factor, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, T, img, groups, degenerate);
+}
+
 // more than 64 KiB of dynamic LDS has to be asked for, once per device the kernels run on
+template <class K>
+static bool ask_lds(K kernel, size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)bytes) == hipSuccess;
+}
 void blind_rotate_setup(int dev) {
     static std::atomic<uint64_t> lds_asked{0};
     if (dev < 0 || dev >= 64) throw std::runtime_error("device index out of range");
     if (lds_asked.load(std::memory_order_acquire) >> dev & 1) return;
     const bool ok = hipSetDevice(dev) == hipSuccess &&
-                    hipFuncSetAttribute(reinterpret_cast<const void*>(k_blind_rotate_q2_pair<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2P_LDS_BYTES) == hipSuccess &&
-                    hipFuncSetAttribute(reinterpret_cast<const void*>(k_blind_rotate_q2_pair<false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)G2P_LDS_BYTES) == hipSuccess &&
-                    hipFuncSetAttribute(reinterpret_cast<const void*>(k_blind_rotate_g64_pair),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)G64_LDS_BYTES) == hipSuccess &&
-                    hipFuncSetAttribute(reinterpret_cast<const void*>(k_blind_rotate_q2_wide),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE2_LDS_BYTES) == hipSuccess &&
-                    hipFuncSetAttribute(reinterpret_cast<const void*>(k_blind_rotate_q_wide),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)WIDE_LDS_BYTES) == hipSuccess;
+                    ask_lds(k_blind_rotate_q2_pair<true, false>, G2P_LDS_BYTES) &&
+                    ask_lds(k_blind_rotate_q2_pair<false, false>, G2P_LDS_BYTES) &&
+                    ask_lds(k_blind_rotate_q2_pair<true, true>, G2P_LDS_BYTES) &&
+                    ask_lds(k_blind_rotate_q2_pair<false, true>, G2P_LDS_BYTES) &&
+                    ask_lds(k_blind_rotate_g64_pair, G64_LDS_BYTES) &&
+                    ask_lds(k_blind_rotate_q2_wide<false>, WIDE2_LDS_BYTES) &&
+                    ask_lds(k_blind_rotate_q2_wide<true>, WIDE2_LDS_BYTES) &&
+                    ask_lds(k_blind_rotate_q_wide, WIDE_LDS_BYTES);
     if (!ok) throw std::runtime_error("the 512-thread blind rotation needs 136 KiB of LDS per workgroup");
     lds_asked.fetch_or(1ull << dev, std::memory_order_release);
+}
+
+// grouping: 1, 2 (four GGSWs per pair of key bits as generated) or 3 (the same in factored form)
+template <bool FACTORED>
+static void launch_grouped(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
+                           const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count, const BlockMap& omap,
+                           double inv_g, int wide_below, int lockstep_above, int pair_above, hipStream_t st) {
+    if (count <= (size_t)wide_below) {
+        hipLaunchKernelGGL(k_blind_rotate_q2_wide<FACTORED>, dim3((unsigned)count), dim3(2 * NT), WIDE2_LDS_BYTES, st, T, bsk,
+                           lwe_small, n, luts, lut_index, glwe_out, lwe_out, omap, inv_g);
+        return;
+    }
+    if (pair_above >= 0 && count > (size_t)pair_above) {
+        const unsigned wgs = (unsigned)((count + G2P_NC - 1) / G2P_NC);
+        // with two ciphertexts per workgroup the wave-level fences win at every launch size (4096: 42.7
+        // against 43.5 ms with a workgroup barrier after every phase); the lock-step instantiation stays for A/B runs
+        static const bool pair_lockstep = std::getenv("LFHE_PAIR_LOCKSTEP") != nullptr;
+        if (pair_lockstep && count > (size_t)lockstep_above)
+            hipLaunchKernelGGL((k_blind_rotate_q2_pair<true, FACTORED>), dim3(wgs), dim3(NT), G2P_LDS_BYTES, st, T, bsk,
+                               lwe_small, n, luts, lut_index, glwe_out, lwe_out, omap, inv_g, (unsigned)count);
+        else
+            hipLaunchKernelGGL((k_blind_rotate_q2_pair<false, FACTORED>), dim3(wgs), dim3(NT), G2P_LDS_BYTES, st, T, bsk,
+                               lwe_small, n, luts, lut_index, glwe_out, lwe_out, omap, inv_g, (unsigned)count);
+        return;
+    }
+    if (count > (size_t)lockstep_above)
+        hipLaunchKernelGGL((k_blind_rotate_q2<true, FACTORED>), dim3((unsigned)count), dim3(NT), G2_LDS_BYTES, st, T, bsk,
+                           lwe_small, n, luts, lut_index, glwe_out, lwe_out, omap, inv_g);
+    else
+        hipLaunchKernelGGL((k_blind_rotate_q2<false, FACTORED>), dim3((unsigned)count), dim3(NT), G2_LDS_BYTES, st, T, bsk,
+                           lwe_small, n, luts, lut_index, glwe_out, lwe_out, omap, inv_g);
 }
 
 void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
@@ -1585,31 +1638,14 @@ void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_sm
         if (hipGetDevice(&dev) != hipSuccess) throw std::runtime_error("hipGetDevice failed");
         blind_rotate_setup(dev);   // a no-op after the engine's own call at start-up
     }
-    if (grouping == 2 && count <= (size_t)wide_below) {
-        hipLaunchKernelGGL(k_blind_rotate_q2_wide, dim3((unsigned)count), dim3(2 * NT), WIDE2_LDS_BYTES, st, T, bsk,
-                           lwe_small, n, luts, lut_index, glwe_out, lwe_out, omap, inv_g);
-        return;
-    }
-    if (grouping == 2 && pair_above >= 0 && count > (size_t)pair_above) {
-        const unsigned wgs = (unsigned)((count + G2P_NC - 1) / G2P_NC);
-        // with two ciphertexts per workgroup the wave-level fences win at every launch size (4096: 42.7
-        // against 43.5 ms with a workgroup barrier after every phase); the lock-step instantiation stays for A/B runs
-        static const bool pair_lockstep = std::getenv("LFHE_PAIR_LOCKSTEP") != nullptr;
-        if (pair_lockstep && count > (size_t)lockstep_above)
-            hipLaunchKernelGGL(k_blind_rotate_q2_pair<true>, dim3(wgs), dim3(NT), G2P_LDS_BYTES, st, T, bsk, lwe_small, n,
-                               luts, lut_index, glwe_out, lwe_out, omap, inv_g, (unsigned)count);
-        else
-            hipLaunchKernelGGL(k_blind_rotate_q2_pair<false>, dim3(wgs), dim3(NT), G2P_LDS_BYTES, st, T, bsk, lwe_small, n,
-                               luts, lut_index, glwe_out, lwe_out, omap, inv_g, (unsigned)count);
+    if (grouping == 3) {
+        launch_grouped<true>(T, bsk, lwe_small, n, luts, lut_index, glwe_out, lwe_out, count, omap, inv_g, wide_below,
+                             lockstep_above, pair_above, st);
         return;
     }
     if (grouping == 2) {
-        if (count > (size_t)lockstep_above)
-            hipLaunchKernelGGL(k_blind_rotate_q2<true>, dim3((unsigned)count), dim3(NT), G2_LDS_BYTES, st, T, bsk, lwe_small,
-                               n, luts, lut_index, glwe_out, lwe_out, omap, inv_g);
-        else
-            hipLaunchKernelGGL(k_blind_rotate_q2<false>, dim3((unsigned)count), dim3(NT), G2_LDS_BYTES, st, T, bsk, lwe_small,
-                               n, luts, lut_index, glwe_out, lwe_out, omap, inv_g);
+        launch_grouped<false>(T, bsk, lwe_small, n, luts, lut_index, glwe_out, lwe_out, count, omap, inv_g, wide_below,
+                              lockstep_above, pair_above, st);
         return;
     }
     // up to two ciphertexts per CU: latency matters more than throughput, use 512 threads each

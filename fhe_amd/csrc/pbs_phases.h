@@ -221,6 +221,28 @@ LFHE_HD void mono_pair(double base, const double* __restrict__ w8, unsigned e, c
     __builtin_memcpy(&m1, &bits, 8);
 }
 
+// One entry of the step's GGSW, built up as its four key words arrive (row m = 0..3), m1 = psi^(a u)
+// and m2 = psi^(a' u) being the monomial factors at this position.
+//   rows as generated (K0..K3):   B = (K0 + m1 K1) + m2 (K2 + m1 K3)                 three products
+//   FACTORED rows (a, b, d, c):   B = d (m1 + a)(m2 + b) + c                          two products
+// with a = K2/K3, b = K1/K3, d = K3, c = K0 - K1 K2 / K3 computed once when the key is loaded
+// (k_bskq_factor): the same residue, 15 instead of 21 FP64 instructions per entry.  |B| < 2.2 p either way.
+template <bool FACTORED>
+LFHE_HD void ggsw_entry_row(int m, double& B, double& S, double k, double m1, double m2, const Prime& P) {
+    if constexpr (FACTORED) {
+        if (m == 0) B = m1 + k;
+        else if (m == 1) B = mmul(B, m2 + k, P);     // both operands below 1.1 p: within the product's range
+        else if (m == 2) B = mmul(B, k, P);
+        else B += k;
+    } else {
+        if (m == 0) B = k;
+        else if (m == 1) B += mmul(m1, k, P);
+        else if (m == 2) S = k;
+        else B += mmul(S + mmul(m1, k, P), m2, P);   // |S + ...| < 1.1 p: the wide operand
+    }
+}
+
+template <bool FACTORED = false>
 LFHE_HD void ep_group2_phase5(EpState& s, double* lds, unsigned t, const Tables& T,
                               const double* __restrict__ rows, unsigned a1, unsigned a2) {
     const Prime P = T.pr[0];
@@ -234,13 +256,13 @@ LFHE_HD void ep_group2_phase5(EpState& s, double* lds, unsigned t, const Tables&
     const double* __restrict__ twi = T.tw_inv[0];
     const double* __restrict__ mono = T.mono;
 #endif
-    // psi^(e u_t) for the three exponents, u_t = 2 rev8(t) + 1: three gathers, in flight during the
-    // last forward pass
+    // psi^(e u_t) for the two exponents, u_t = 2 rev8(t) + 1: two gathers, in flight during the
+    // last forward pass (X^(a + a') is never formed)
     const unsigned ut = 2 * rev8(t) + 1;
-    const unsigned am[3] = {a1, a2, (a1 + a2) & (2 * N - 1)};
-    double base[3];
+    const unsigned am[2] = {a1, a2};
+    double base[2];
 #pragma unroll
-    for (int m = 0; m < 3; ++m) base[m] = ldt(mono, (am[m] * ut) & (2 * N - 1));
+    for (int m = 0; m < 2; ++m) base[m] = ldt(mono, (am[m] * ut) & (2 * N - 1));
     double* b0 = lds;
     double* b1 = lds + POLY_STRIDE;
     ld_o4p34(b0, t, s.x[0]); ld_o4p34(b1, t, s.x[1]);
@@ -255,7 +277,9 @@ LFHE_HD void ep_group2_phase5(EpState& s, double* lds, unsigned t, const Tables&
     for (unsigned q = 0; q < 4; ++q) { const unsigned o = bsk_off(0, q, 0, t); kc[q][0] = LFHE_LDK(rows, o); kc[q][1] = LFHE_LDK(rows, o + 1); }
     auto chunk = [&](auto c4_tag) {
         constexpr int c4 = decltype(c4_tag)::value;
-        double B[4][2];
+        double B[4][2], S[4][2], M1[2], M2[2];
+        mono_pair<c4>(base[0], w8, am[0], P, M1[0], M1[1]);
+        mono_pair<c4>(base[1], w8, am[1], P, M2[0], M2[1]);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int u = 4 * c4 + m;
@@ -267,19 +291,10 @@ LFHE_HD void ep_group2_phase5(EpState& s, double* lds, unsigned t, const Tables&
                     kn[q][0] = LFHE_LDK(rows, o); kn[q][1] = LFHE_LDK(rows, o + 1);
                 }
             }
-            if (m == 0) {   // X^0: the row enters as it is
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) B[q][h] = kc[q][h];
-            } else {
-                double M[2];
-                mono_pair<c4>(base[m - 1], w8, am[m - 1], P, M[0], M[1]);
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) B[q][h] += mmul(M[h], kc[q][h], P);
-            }
+                for (int q = 0; q < 4; ++q) ggsw_entry_row<FACTORED>(m, B[q][h], S[q][h], kc[q][h], M1[h], M2[h], P);
 #if defined(__HIP_DEVICE_COMPILE__)
             asm volatile("" ::: "memory");
 #endif

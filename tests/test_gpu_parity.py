@@ -417,6 +417,20 @@ def test_grouped_key_pbs_full_parameters():
         # more than four workgroups per CU: the instantiation with a barrier after every phase, same bits
         big = ctx.pbs_batch(np.concatenate([cts, cts[:500]]), luts_g, np.concatenate([idx, idx[:500]]))
         assert np.array_equal(big[:B], out) and np.array_equal(big[B:], out[:500])
+        # the key image is held in factored form (two products per GGSW entry); the plain image, which a
+        # key with a non-invertible word falls back to, gives the same bits in every workgroup shape
+        os.environ["LFHE_BSK_FACTORED"] = "0"
+        try:
+            plain = Context(seed=seed_bytes(108), params=ctx.params)
+            plain.import_server_keys_raw(bskg, ksk, orc.test_zeros)
+        finally:
+            del os.environ["LFHE_BSK_FACTORED"]
+        try:
+            assert np.array_equal(plain.pbs_batch(cts, luts_g, idx), out)
+            assert np.array_equal(plain.pbs_batch(cts[:8], luts_g, idx[:8]), out[:8])
+            assert np.array_equal(plain.pbs_batch(cts[:300], luts_g, idx[:300]), out[:300])
+        finally:
+            plain.close()
     finally:
         ctx.close()
 
