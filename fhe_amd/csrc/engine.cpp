@@ -147,13 +147,13 @@ bool Engine::build_bsk_image(const u64* host_bsk, size_t total, double* dst) {
     bool factored = false;
     const char* env = std::getenv("LFHE_BSK_FACTORED");   // 0: keep the plain image (tests of that path, A/B runs)
     const bool allow = !(env && std::atoi(env) == 0);
-    if (single_modulus() && prm_.bsk_grouping == 2 && allow) {
+    if (prm_.bsk_grouping == 2 && allow) {
         // the factored form needs every K3 word invertible; a key with a zero word (one in 10^8 keys) keeps
         // the plain image and the kernels that go with it
         int* d_flag = reinterpret_cast<int*>(d_raw);
         int flag = 0;
         HC(hipMemsetAsync(d_flag, 0, sizeof(int), stream_));
-        launch_bskq_factor(T_, dst, total / 4, d_flag, stream_);
+        launch_bsk_factor(T_, dst, total / 4, row, d_flag, stream_);
         HC(hipGetLastError());
         HC(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, stream_));
         HC(hipStreamSynchronize(stream_));
@@ -272,7 +272,7 @@ void Engine::attach_device_keys(double* bsk_dev, u64* ksk_dev_image) {
     bsk_factored_ = (zc & FACTORED_FLAG) != 0;
     zc &= ~FACTORED_FLAG;
     if (zc != 0 && zc != prm_.ms_zeros_count) throw std::runtime_error("attached key image does not match the parameter set");
-    if (bsk_factored_ && !(single_modulus() && prm_.bsk_grouping == 2))
+    if (bsk_factored_ && prm_.bsk_grouping != 2)
         throw std::runtime_error("attached key image does not match the parameter set");
     set_ms_params((u32)zc);
     build_ksk_limbs();
@@ -474,7 +474,8 @@ void Engine::blind_rotate_with(const double* bsk, uint32_t n, const u64* lwe_sma
                                   prm_.bsk_grouping == 2 && fact ? 3 : (int)prm_.bsk_grouping, pair_threshold(cnt),
                                   stream_);
         else
-            launch_blind_rotate(T_, bsk, in, (int)n, luts, li, gout, lout, cnt, omap, (int)prm_.bsk_grouping, stream_);
+            launch_blind_rotate(T_, bsk, in, (int)n, luts, li, gout, lout, cnt, omap,
+                                prm_.bsk_grouping == 2 && fact ? 3 : (int)prm_.bsk_grouping, stream_);
         HC(hipGetLastError());
     }
 }

@@ -53,8 +53,9 @@ void launch_blind_rotate(const Tables& T, const double* bsk, const u64* lwe_smal
                          const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
                          const BlockMap& omap, int grouping, hipStream_t st);
 void launch_bskq_prepare(const Tables& T, const u64* in, double* out, size_t polys, hipStream_t st);
-// grouped single-modulus image -> factored form, in place; *degenerate (device) is set when a word has none
-void launch_bskq_factor(const Tables& T, double* img, size_t groups, int* degenerate, hipStream_t st);
+// grouped key image -> factored form, in place (row_words: BSKQ_ROW or BSK_ROW); *degenerate (device) is set
+// when a word has none
+void launch_bsk_factor(const Tables& T, double* img, size_t groups, size_t row_words, int* degenerate, hipStream_t st);
 void launch_external_product_q(const Tables& T, const double* bsk, const u32* idx, const u64* glwe, u64* out,
                                size_t count, double inv_g, hipStream_t st);
 void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
@@ -185,7 +186,7 @@ public:
     // factored: whether that image holds the grouped key in factored form (-1: as the main key's)
     void blind_rotate_with(const double* bsk, uint32_t n, const u64* lwe_small, const u64* luts, const u32* lut_index,
                            u64* glwe_out, u64* lwe_out, size_t count, const BlockMap& omap = BlockMap(), int factored = -1);
-    // the grouped key over the prime modulus is held in factored form (two products per GGSW entry
+    // a grouped key is held in factored form (two products per GGSW entry
     // instead of three, pbs_phases.h) unless one of its words has none
     bool bsk_factored() const { return bsk_factored_; }
     // ---- compression: host keys in (packing key [N][level][(kc+1) nc]; bootstrapping key for the

@@ -1059,7 +1059,7 @@ static constexpr size_t G64_LDS_BYTES = G2P_NC * LDS_BYTES + G64_TW_WORDS * size
 // One prime's share of a step for the two ciphertexts of a workgroup: digits in x (pass-1
 // ownership) -> residues of the external product in x (|x| < 2 p, pass-1 ownership).  Ends with the
 // workgroup barrier that frees the exchange buffers.
-template <int R>
+template <int R, bool FACTORED>
 __device__ __forceinline__ void g64_prime_pass(double (&x)[G2P_NC][2][E], const Tables& T,
                                                const double* __restrict__ rows, const unsigned (&am)[G2P_NC][2],
                                                unsigned t) {
@@ -1165,32 +1165,12 @@ __device__ __forceinline__ void g64_prime_pass(double (&x)[G2P_NC][2][E], const 
                     }
                 }
 #pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    if (m == 0) {
+                for (int c = 0; c < NC; ++c)
 #pragma unroll
-                        for (int h = 0; h < 2; ++h)
+                    for (int h = 0; h < 2; ++h)
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) B[c][q][h] = kc[q][h];
-                    } else if (m == 1) {
-#pragma unroll
-                        for (int h = 0; h < 2; ++h)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) B[c][q][h] += mmul(M1[c][h], kc[q][h], P);
-                    } else if (m == 2) {
-#pragma unroll
-                        for (int h = 0; h < 2; ++h)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) S[c][q][h] = kc[q][h];
-                    } else {
-#pragma unroll
-                        for (int h = 0; h < 2; ++h)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const double sum = S[c][q][h] + mmul(M1[c][h], kc[q][h], P);
-                                B[c][q][h] += mmul(sum, M2[c][h], P);
-                            }
-                    }
-                }
+                        for (int q = 0; q < 4; ++q)
+                            ggsw_entry_row<FACTORED>(m, B[c][q][h], S[c][q][h], kc[q][h], M1[c][h], M2[c][h], P);
                 asm volatile("" ::: "memory");
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { kc[q][0] = kn[q][0]; kc[q][1] = kn[q][1]; }
@@ -1269,6 +1249,7 @@ __device__ __forceinline__ void g64_prime_pass(double (&x)[G2P_NC][2][E], const 
     __syncthreads();  // the last pass's reads are done before the buffers are written again
 }
 
+template <bool FACTORED>
 __global__ void __launch_bounds__(NT, 2) k_blind_rotate_g64_pair(Tables T, const double* __restrict__ bsk,
                                                                 const u64* __restrict__ lwe_small, int n,
                                                                 const u64* __restrict__ luts,
@@ -1323,7 +1304,7 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_g64_pair(Tables T, const
                     dig[c][q][j] = decomp23(acc[c][q][j]);
                     x[c][q][j] = (double)dig[c][q][j];
                 }
-        g64_prime_pass<0>(x, T, rows, am, t);
+        g64_prime_pass<0, FACTORED>(x, T, rows, am, t);
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -1333,7 +1314,7 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_g64_pair(Tables T, const
                     y0[c][q][j] = x[c][q][j];
                     x[c][q][j] = (double)dig[c][q][j];
                 }
-        g64_prime_pass<1>(x, T, rows, am, t);
+        g64_prime_pass<1, FACTORED>(x, T, rows, am, t);
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -1541,38 +1522,43 @@ void launch_external_product_q(const Tables& T, const double* bsk, const u32* id
 // rows and per word:  (K0, K1, K2, K3) -> (a, b, d, c) = (K2/K3, K1/K3, K3, K0 - K1 K2 / K3)  mod q'.
 // The rows keep their layout and their N^-1 factor (the ratios do not carry it, d and c do).  A word
 // whose K3 is zero has no factored form: the flag is raised and the caller rebuilds the plain image.
+// The grouped key over 2^64 is factored the same way, residue by residue of either prime.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double qp_inverse(double x, const Prime& P) {   // x canonical, non-zero: x^(q' - 2)
+__device__ __forceinline__ double mod_inverse(double x, const Prime& P, u64 p) {   // x canonical, non-zero: x^(p - 2)
     double r = 1.0;
 #pragma unroll 1
     for (int bit = 49; bit >= 0; --bit) {
         r = mnorm(mmul(r, r, P), P);
-        if ((QP_U - 2) >> bit & 1) r = mnorm(mmul(r, x, P), P);
+        if ((p - 2) >> bit & 1) r = mnorm(mmul(r, x, P), P);
     }
     return r;
 }
 
-__global__ void __launch_bounds__(256) k_bskq_factor(Tables T, double* __restrict__ img, size_t groups,
-                                                     int* __restrict__ degenerate) {
-    const Prime P = T.pr[0];
+// row_words: BSKQ_ROW (single modulus) or BSK_ROW (both primes: the first half of a row belongs to prime 0)
+__global__ void __launch_bounds__(256) k_bsk_factor(Tables T, double* __restrict__ img, size_t groups, size_t row_words,
+                                                    int* __restrict__ degenerate) {
     const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (id >= groups * (size_t)BSKQ_ROW) return;
-    double* w = img + (id / BSKQ_ROW) * 4 * (size_t)BSKQ_ROW + id % BSKQ_ROW;
-    const double k0 = w[0], k1 = w[BSKQ_ROW], k2 = w[2 * (size_t)BSKQ_ROW];
-    const double k3 = qp_canon(mnorm(w[3 * (size_t)BSKQ_ROW], P), P);
+    if (id >= groups * row_words) return;
+    const size_t e = id % row_words;
+    const int r = e >= (size_t)BSKQ_ROW ? 1 : 0;
+    const Prime P = T.pr[r];
+    double* w = img + (id / row_words) * 4 * row_words + e;
+    const double k0 = w[0], k1 = w[row_words], k2 = w[2 * row_words];
+    const double k3 = mnorm(mnorm(w[3 * row_words], P), P);
     if (k3 == 0.0) { atomicOr(degenerate, 1); return; }
-    const double inv = qp_inverse(k3, P);
+    const double inv = mod_inverse(k3, P, r ? P1_U : P0_U);
     const double a = mnorm(mmul(k2, inv, P), P), b = mnorm(mmul(k1, inv, P), P);
     const double c = mnorm(k0 - mmul(k1, a, P), P);   // K1 K2 / K3 = K1 a
     w[0] = a;
-    w[BSKQ_ROW] = b;
-    w[2 * (size_t)BSKQ_ROW] = k3;
-    w[3 * (size_t)BSKQ_ROW] = c;
+    w[row_words] = b;
+    w[2 * row_words] = k3;
+    w[3 * row_words] = c;
 }
 
-void launch_bskq_factor(const Tables& T, double* img, size_t groups, int* degenerate, hipStream_t st) {
-    const size_t words = groups * (size_t)BSKQ_ROW;
-    hipLaunchKernelGGL(k_bskq_factor, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, T, img, groups, degenerate);
+void launch_bsk_factor(const Tables& T, double* img, size_t groups, size_t row_words, int* degenerate, hipStream_t st) {
+    const size_t words = groups * row_words;
+    hipLaunchKernelGGL(k_bsk_factor, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, T, img, groups, row_words,
+                       degenerate);
 }
 
 // more than 64 KiB of dynamic LDS has to be asked for, once per device the kernels run on
@@ -1590,7 +1576,8 @@ void blind_rotate_setup(int dev) {
                     ask_lds(k_blind_rotate_q2_pair<false, false>, G2P_LDS_BYTES) &&
                     ask_lds(k_blind_rotate_q2_pair<true, true>, G2P_LDS_BYTES) &&
                     ask_lds(k_blind_rotate_q2_pair<false, true>, G2P_LDS_BYTES) &&
-                    ask_lds(k_blind_rotate_g64_pair, G64_LDS_BYTES) &&
+                    ask_lds(k_blind_rotate_g64_pair<false>, G64_LDS_BYTES) &&
+                    ask_lds(k_blind_rotate_g64_pair<true>, G64_LDS_BYTES) &&
                     ask_lds(k_blind_rotate_q2_wide<false>, WIDE2_LDS_BYTES) &&
                     ask_lds(k_blind_rotate_q2_wide<true>, WIDE2_LDS_BYTES) &&
                     ask_lds(k_blind_rotate_q_wide, WIDE_LDS_BYTES);
@@ -1810,9 +1797,14 @@ void launch_external_product(const Tables& T, const double* bsk, const u32* idx,
 void launch_blind_rotate(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
                          const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
                          const BlockMap& omap, int grouping, hipStream_t st) {
-    if (grouping == 2) {   // four GGSWs per pair of key bits, two ciphertexts per workgroup
-        hipLaunchKernelGGL(k_blind_rotate_g64_pair, dim3((unsigned)((count + G2P_NC - 1) / G2P_NC)), dim3(NT), G64_LDS_BYTES,
-                           st, T, bsk, lwe_small, n, luts, lut_index, glwe_out, lwe_out, omap, (unsigned)count);
+    if (grouping >= 2) {   // four GGSWs per pair of key bits (3: in factored form), two ciphertexts per workgroup
+        const dim3 grid((unsigned)((count + G2P_NC - 1) / G2P_NC));
+        if (grouping == 3)
+            hipLaunchKernelGGL(k_blind_rotate_g64_pair<true>, grid, dim3(NT), G64_LDS_BYTES, st, T, bsk, lwe_small, n, luts,
+                               lut_index, glwe_out, lwe_out, omap, (unsigned)count);
+        else
+            hipLaunchKernelGGL(k_blind_rotate_g64_pair<false>, grid, dim3(NT), G64_LDS_BYTES, st, T, bsk, lwe_small, n, luts,
+                               lut_index, glwe_out, lwe_out, omap, (unsigned)count);
         return;
     }
     hipLaunchKernelGGL(k_blind_rotate, dim3((unsigned)count), dim3(NT), LDS_BYTES, st, T, bsk, lwe_small, n, luts,

@@ -15,7 +15,7 @@ N = 2048
 M64 = (1 << 64) - 1
 
 
-def _mk(n, ks_base_log=4, ks_level=4, seed=1, ms_zeros=0, grouped=False):
+def _mk(n, ks_base_log=4, ks_level=4, seed=1, ms_zeros=0, grouped=False, factored=True):
     """Oracle and library context over the same keys.  ms_zeros > 0 adds that many encryptions of
     zero and switches the modulus-switch noise reduction on in both.  grouped: the bootstrapping key
     with four GGSWs over 2^64 per pair of key bits."""
@@ -36,7 +36,13 @@ def _mk(n, ks_base_log=4, ks_level=4, seed=1, ms_zeros=0, grouped=False):
         orc.set_ms(zeros)
         orc.zeros = zeros
     ctx = Context(seed=seed_bytes(100 + seed), params=p)
-    ctx.import_server_keys_raw(keys[2], keys[3], zeros)
+    import os
+    if not factored:                      # keep the grouped key's image as generated (the fall-back path)
+        os.environ["LFHE_BSK_FACTORED"] = "0"
+    try:
+        ctx.import_server_keys_raw(keys[2], keys[3], zeros)
+    finally:
+        os.environ.pop("LFHE_BSK_FACTORED", None)
     ctx.import_client_keys_raw(keys[0], keys[1])
     return orc, keys, ctx
 
@@ -435,25 +441,30 @@ def test_grouped_key_pbs_full_parameters():
         ctx.close()
 
 
+@pytest.mark.parametrize("factored", [True, False], ids=["factored", "plain"])
 @pytest.mark.parametrize("n", [12, 13])
-def test_grouped_key_over_the_torus_bit_exact(n):
+def test_grouped_key_over_the_torus_bit_exact(n, factored):
     """Two key bits per step, every modulus 2^64 (two-prime transform and lift per step, two
     ciphertexts per workgroup): accumulators and bootstrapped ciphertexts equal the oracle's bit for
     bit, for an even and an odd key length, odd and even batches, all-zero masks, masks whose pairs
     cancel (a + a' = 2N) and accumulators whose digits are all extreme."""
-    orc, keys, ctx = _mk(n, seed=9, grouped=True)
+    from fhe_amd.native import LfheError
+    orc, keys, ctx = _mk(n, seed=9, grouped=True, factored=factored)
     try:
         lwe_sk, glwe_sk, bskg, ksk = keys
         pb = orc.prepare_bsk_grouped(bskg)
         r = Rng(seed_bytes(33))
         W = orc.ggsw_words()
-        # the key rows as the external-product kernel sees them
         glwe = np.stack([r.u64s(2 * N) for _ in range(3)])
         glwe[2][:] = 1 << 63
         gi = np.array([0, 5, 4 * ((n + 1) // 2) - 1], dtype=np.uint32)
-        got = ctx.external_product(gi, glwe)
-        for c in range(3):
-            assert np.array_equal(got[c].reshape(-1), orc.external_product(bskg[gi[c] * W:(gi[c] + 1) * W], glwe[c])), c
+        if factored:    # the image holds (K2/K3, K1/K3, K3, K0 - K1 K2/K3) per group: its rows are no GGSWs
+            with pytest.raises(LfheError):
+                ctx.external_product(gi, glwe)
+        else:           # the key rows as the external-product kernel sees them
+            got = ctx.external_product(gi, glwe)
+            for c in range(3):
+                assert np.array_equal(got[c].reshape(-1), orc.external_product(bskg[gi[c] * W:(gi[c] + 1) * W], glwe[c])), c
         f = [lambda x: x, lambda x: (3 * x + 1) % 16]
         luts_o = [orc.make_lut(g) for g in f]
         luts_g = np.stack([ctx.make_lut(g) for g in f])
