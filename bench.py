@@ -30,6 +30,8 @@ MODMUL_PER_PBS = 3672 * 11264 + 918 * 4 * 2048
 # with the key bits in pairs: 459 steps of 4 transforms, and per transform-domain point 12 products
 # for the step's GGSW (3 key rows x 4 polynomials) + 4 for the external product itself
 MODMUL_PER_PBS_GROUPED = 459 * (4 * 11264 + 16 * 2048)
+# with the key image in factored form the entry sums cost 2 products each instead of 3: 8 + 4 per point
+MODMUL_PER_PBS_GROUPED_FACTORED = 459 * (4 * 11264 + 12 * 2048)
 # register-resident calibration on MI355X (profiles/r01/valu_rates_8wg_per_cu.txt): 4748 G/s exact
 # f64 butterflies (modular multiply + add + sub) per prime.  Over q = 2^64 a logical modular product
 # costs one butterfly in each of two primes; over the prime ring modulus it costs one.
@@ -65,9 +67,9 @@ KEY_IMAGE_BYTES = {"q64": 918 * 131072, "q64_grouped": 1836 * 131072, "prime": 9
 # bootstrapping-key flavour -> (parameter set id, label, kernel, VALU peak in butterflies/s per GPU)
 FLAVOURS = {
     "q64": (1, "2^64", "k_blind_rotate"),
-    "q64_grouped": (4, "2^64, key bits in pairs", "k_blind_rotate_g64_pair"),
+    "q64_grouped": (4, "2^64, key bits in pairs", "k_blind_rotate_g64_pair<true>"),
     "prime": (2, "703687441727489 (NTT prime)", "k_blind_rotate_q"),
-    "grouped": (3, "703687441727489 (NTT prime), key bits in pairs", "k_blind_rotate_q2_pair<false>"),
+    "grouped": (3, "703687441727489 (NTT prime), key bits in pairs", "k_blind_rotate_q2_pair<false, true>"),
 }
 
 
@@ -246,30 +248,34 @@ def main(argv=None, backend=None):
         probe = mul_latency(ctx) if operators and rank == 0 else None
         if probe is not None:
             ok = ok and probe[2]
+        factored = bool(ctx.bsk_factored()) if hasattr(ctx, "bsk_factored") else False
         ctx.close()
         del keep
-        return elapsed, ks_ms, br_ms, ok, probe
+        return elapsed, ks_ms, br_ms, ok, probe, factored
 
     flavour = args.bsk_modulus
-    elapsed, ks_ms, br_ms, ok, probe = run_leg(flavour, args.steps, args.warmup, operators=not args.no_operators)
+    elapsed, ks_ms, br_ms, ok, probe, factored = run_leg(flavour, args.steps, args.warmup, operators=not args.no_operators)
     alts = []
     if not args.no_alt:
         a_steps = max(1, min(args.steps, 3))
         for other in FLAVOURS:
             if other == flavour:
                 continue
-            a_el, a_ks, a_br, a_ok, _ = run_leg(other, a_steps, 1)
+            a_el, a_ks, a_br, a_ok, _, a_fact = run_leg(other, a_steps, 1)
             ok = ok and a_ok
             alts.append({"flavour": other, "bsk_modulus": FLAVOURS[other][1], "kernel": FLAVOURS[other][2],
                          "value": B * a_steps * world / a_el, "unit": "PBS/s", "steps": a_steps,
                          "kernel_ms": {"keyswitch_and_ms_noise_reduction": a_ks, "blind_rotate": a_br},
-                         "verified": a_ok})
+                         "key_image": "factored" if a_fact else "as generated", "verified": a_ok})
 
     if rank == 0:
         total = B * args.steps * world
         value = total / elapsed
         br_s = br_ms * 1e-3
-        modmul = MODMUL_PER_PBS_GROUPED if flavour in ("grouped", "q64_grouped") else MODMUL_PER_PBS
+        # priced with the products the kernel really executes (12 per point with the factored key image, 16 without)
+        modmul = MODMUL_PER_PBS
+        if flavour in ("grouped", "q64_grouped"):
+            modmul = MODMUL_PER_PBS_GROUPED_FACTORED if factored else MODMUL_PER_PBS_GROUPED
         achieved = B * modmul / br_s / 1e9
         peak = PEAK_GBFLY_PER_PRIME / 2 if flavour in ("q64", "q64_grouped") else PEAK_GBFLY_PER_PRIME
         algo_bytes = BSK_BYTES + KSK_BYTES + 2 * CT_BYTES * B
@@ -289,7 +295,7 @@ def main(argv=None, backend=None):
             "data": "synthetic",
             "config": {"workload": f"batched PBS microbench: {B} independent euint8 blocks per GPU, "
                                    "PARAM_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128 (n=918, N=2048), 16 distinct LUTs",
-                       "bsk_modulus": FLAVOURS[flavour][1],
+                       "bsk_modulus": FLAVOURS[flavour][1], "key_image": "factored" if factored else "as generated",
                        "batch_per_gpu": B, "parallelism": f"batch-shard x{world}, keys broadcast once"},
             "verified": ok,
             "kernel_ms": {"keyswitch_and_ms_noise_reduction": ks_ms, "blind_rotate": br_ms},

@@ -1042,4 +1042,10 @@ int32_t lfhe_pbs_count(const lfhe_ctx* ctx, uint64_t* out) {
     return LFHE_OK;
 }
 
+int32_t lfhe_bsk_image_form(const lfhe_ctx* ctx, uint32_t* out) {
+    if (!ctx || !out) return LFHE_ERR_ARG;
+    *out = ctx->eng->bsk_factored() ? 1u : 0u;
+    return LFHE_OK;
+}
+
 }  // extern "C"

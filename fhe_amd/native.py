@@ -123,6 +123,7 @@ def load():
         "lfhe_fused_dump": (i32, [vp, u32, u32, pu32, vp, vp, u32, C.c_char_p, pu64]),
         "lfhe_rand": (i32, [vp, u32, C.c_char_p, u32, vp, pu64]),
         "lfhe_pbs_count": (i32, [vp, pu64]),
+        "lfhe_bsk_image_form": (i32, [vp, C.POINTER(C.c_uint32)]),
         "lfhe_make_lut": (i32, [vp, vp, vp]),
         "lfhe_pbs_batch": (i32, [vp, u64, vp, vp, u32, vp, vp]),
         "lfhe_pbs_batch_device": (i32, [vp, u64, vp, vp, vp, vp]),
@@ -502,6 +503,13 @@ class Context:
             res.append(bytes(raw[off:off + size]))
             off += size
         return res
+
+    def bsk_factored(self) -> bool:
+        """Whether the device holds the grouped bootstrapping key in factored form (two modular
+        products per entry of a step's GGSW instead of three)."""
+        f = C.c_uint32(0)
+        self._ck(self._L.lfhe_bsk_image_form(self._h, C.byref(f)))
+        return bool(f.value)
 
     def pbs_count(self) -> int:
         n = C.c_uint64()

@@ -274,6 +274,13 @@ int32_t lfhe_rand(lfhe_ctx* ctx, uint32_t bit_width, const uint8_t seed[16], uin
                   uint64_t* out_len);
 /* cumulative count of programmable bootstraps issued by this context */
 int32_t lfhe_pbs_count(const lfhe_ctx* ctx, uint64_t* out);
+/* How the device holds a grouped bootstrapping key (sets 3 and 4): *out = 1 when its four GGSWs per
+ * pair of key bits are held in factored form -- the step's GGSW entry K0 + m1 K1 + m2 K2 + m1 m2 K3
+ * as K3 (m1 + K2/K3)(m2 + K1/K3) + (K0 - K1 K2/K3), two modular products per entry instead of
+ * three, same results --, 0 for the rows as generated (one-bit keys; a grouped key with a
+ * non-invertible word).  No counterpart in the reference: a measurement aid (the benchmark prices
+ * the work that is actually done). */
+int32_t lfhe_bsk_image_form(const lfhe_ctx* ctx, uint32_t* out);
 
 /* ---- the bootstrap path itself ------------------------------------------------------------------
  * Replaces: tfhe-rs keyswitch_programmable_bootstrap + generate_accumulator as the reference calls

@@ -109,6 +109,12 @@ def check_header(path):
     # the one-bit kernels' schedule takes the grouped point-wise bound as well (the 256-thread grouped kernel uses it)
     w1, x1, _ = inverse(schedule_from_header(path), pw)
     assert w1 < LIMIT and max(x1) <= 2.0
+    # factored key image: entry d (m1 + a)(m2 + b) + c with m <= prod(0.5) and a, b, d, c <= p/2: a smaller
+    # entry than the plain form's, so everything above covers it.  (It would even take the transformed
+    # digits un-normalised -- 2 * 6.2 p at the first inverse stage -- for 0.15 % of the time: not taken.)
+    m = prod(0.5)
+    Bf = prod(prod2(m + NORM, m + NORM)) + NORM
+    assert Bf < 1.1 and Bf < B and 2 * prod2(Bf, f[-1]) * 2 < LIMIT
     return max(w, wg), max(x), n
 
 
