@@ -378,6 +378,32 @@ def test_grouped_key_blind_rotation_bit_exact(n, wide):
         ctx.close()
 
 
+def test_grouped_key_with_a_non_invertible_word_keeps_the_plain_image():
+    """The factored image divides by the words of every fourth GGSW; a key in which one of them is zero
+    (here: a whole GGSW of zeros, which no key generation produces) is detected at load, held as
+    generated and bootstrapped by the plain instantiation of the kernels: same bits as the oracle."""
+    orc, keys, ctx = _mk_prime(12, seed=11, grouped=True)
+    try:
+        lwe_sk, glwe_sk, bskg, ksk = keys
+        assert ctx.bsk_factored()
+        W = orc.ggsw_words()
+        broken = bskg.copy()
+        broken[7 * W:8 * W] = 0                      # K3 of the second pair of key bits
+        ctx.import_server_keys_raw(broken, ksk, None)
+        assert not ctx.bsk_factored()
+        pb = orc.prepare_bsk_qp_grouped(broken)
+        r = Rng(seed_bytes(35))
+        lut_o, lut_g = orc.make_lut(lambda x: (5 * x + 2) % 16), ctx.make_lut(lambda x: (5 * x + 2) % 16)
+        smalls = np.stack([r.u64s(orc.n + 1) for _ in range(5)])
+        got = ctx.blind_rotate(smalls, lut_g[None], None)
+        for c in range(5):
+            assert np.array_equal(got[c].reshape(-1), orc.blind_rotate_qp(pb, smalls[c], lut_o)), c
+        ctx.import_server_keys_raw(bskg, ksk, None)
+        assert ctx.bsk_factored()
+    finally:
+        ctx.close()
+
+
 def test_grouped_key_pbs_full_parameters():
     """n = 918, noise reduction on, grouped key: outputs decrypt to f(m), a subsample is
     bit-identical to the oracle, the output noise stays far below half a message step."""
