@@ -203,8 +203,7 @@ def test_pbs_full_parameters(full):
     out = ctx.pbs_batch(cts, luts_g, idx)
     for i in range(B):
         assert orc.decrypt_block(glwe_sk, out[i]) == f[idx[i]](msgs[i]) % 16, i
-    for i in (0, 1, 50, 95):
-        assert np.array_equal(out[i], orc.pbs(ksk, pb, cts[i], luts_o[idx[i]])), i
+    assert np.array_equal(out, orc.pbs_batch(ksk, pb, cts, np.stack(luts_o), idx, nthreads=16))   # all 96, bit for bit
     # idempotence of a second bootstrap by the identity: value preserved
     out2 = ctx.pbs_batch(out, luts_g[:1])
     for i in range(0, B, 7):
@@ -339,8 +338,7 @@ def test_prime_modulus_pbs_full_parameters(wide):
             e = (orc.lwe_phase(glwe_sk, out[i]) - orc.encode(want)) % (1 << 64)
             worst = max(worst, min(e, (1 << 64) - e))
         assert worst < 1 << 53            # half a message step is 2^58
-        for i in (0, 1, 33, 63):
-            assert np.array_equal(out[i], orc.pbs_qp(ksk, pb, cts[i], luts_o[idx[i]])), i
+        assert np.array_equal(out, orc.pbs_batch_qp(ksk, pb, cts, np.stack(luts_o), idx, nthreads=16))   # all 64, bit for bit
     finally:
         ctx.close()
 
@@ -429,6 +427,8 @@ def test_grouped_key_pbs_full_parameters():
         assert worst < 1 << 53            # half a message step is 2^58
         for i in (0, 1, 333, 599):
             assert np.array_equal(out[i], orc.pbs_qp(ksk, pb, cts[i], luts_o[idx[i]])), i
+        # and every one of the 600, bit for bit (the oracle on the host's cores)
+        assert np.array_equal(out, orc.pbs_batch_qp(ksk, pb, cts, np.stack(luts_o), idx, nthreads=16))
         # a small launch takes the 512-thread kernel: same bits
         assert np.array_equal(ctx.pbs_batch(cts[:8], luts_g, idx[:8]), out[:8])
         # launches of more than two ciphertexts per CU put two ciphertexts in a workgroup; an odd batch
@@ -540,6 +540,9 @@ def test_grouped_key_over_the_torus_full_parameters():
         assert worst < 1 << 53            # half a message step is 2^58
         for i in (0, 1, 333, 600):
             assert np.array_equal(out[i], orc.pbs(ksk, pb, cts[i], luts_o[idx[i]])), i
+        # and every one of the 601, bit for bit (the oracle on the host's cores): every lift of every
+        # step stayed inside its window
+        assert np.array_equal(out, orc.pbs_batch(ksk, pb, cts, np.stack(luts_o), idx, nthreads=16))
         assert np.array_equal(ctx.pbs_batch(cts[:8], luts_g, idx[:8]), out[:8])
     finally:
         ctx.close()
