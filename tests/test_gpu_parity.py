@@ -607,6 +607,21 @@ def test_full_size_batch_properties(params_id):
         assert np.array_equal(got, want)
         assert worst < 1 << 53
         assert np.array_equal(ctx.pbs_batch(blocks, luts, idx), out)
+        # a subsample spread over the launch is the oracle's output bit for bit, under the keys the LIBRARY
+        # made (exported, handed to the oracle as raw words)
+        from fhe_amd.native import KEY_SERVER
+        words = np.frombuffer(ctx.export_keys(KEY_SERVER), dtype=np.uint8)
+        n_ggsw = {1: 918, 2: 918, 3: 1836, 4: 1836}[params_id]
+        nb, nk, nz = n_ggsw * 4 * N, N * 4 * 919, 1449 * 919
+        raw = np.frombuffer(words[-(nb + nk + nz) * 8:].tobytes(), dtype=np.uint64)
+        bsk_raw, ksk_raw, zeros_raw = raw[:nb].copy(), raw[nb:nb + nk].copy(), raw[nb + nk:].reshape(1449, 919).copy()
+        orc = Oracle()
+        orc.set_ms(zeros_raw)
+        prep = {1: orc.prepare_bsk, 2: orc.prepare_bsk_qp, 3: orc.prepare_bsk_qp_grouped, 4: orc.prepare_bsk_grouped}[params_id]
+        batch = orc.pbs_batch if params_id in (1, 4) else orc.pbs_batch_qp
+        pick = np.arange(0, B, 31)[:128]
+        luts_o = np.stack([np.concatenate([np.zeros(N, dtype=np.uint64), l]) for l in luts])
+        assert np.array_equal(out[pick], batch(ksk_raw, prep(bsk_raw), blocks[pick], luts_o, idx[pick], nthreads=16))
         ident = ctx.pbs_batch(blocks, luts[:1])
         got2, _ = decode(ctx.pbs_batch(ident, luts, idx))
         assert np.array_equal(got2, want)
