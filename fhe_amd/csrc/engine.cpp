@@ -475,7 +475,8 @@ void Engine::blind_rotate_with(const double* bsk, uint32_t n, const u64* lwe_sma
                                   stream_);
         else
             launch_blind_rotate(T_, bsk, in, (int)n, luts, li, gout, lout, cnt, omap,
-                                prm_.bsk_grouping == 2 && fact ? 3 : (int)prm_.bsk_grouping, stream_);
+                                prm_.bsk_grouping == 2 && fact ? 3 : (int)prm_.bsk_grouping,
+                                pair_above_ != -2 ? pair_above_ : (cnt > 2 * (size_t)cu_count_ ? 0 : -1), stream_);
         HC(hipGetLastError());
     }
 }

@@ -51,7 +51,7 @@ void launch_external_product(const Tables& T, const double* bsk, const u32* idx,
                              size_t count, hipStream_t st);
 void launch_blind_rotate(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
                          const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
-                         const BlockMap& omap, int grouping, hipStream_t st);
+                         const BlockMap& omap, int grouping, int pair_above, hipStream_t st);
 void launch_bskq_prepare(const Tables& T, const u64* in, double* out, size_t polys, hipStream_t st);
 // grouped key image -> factored form, in place (row_words: BSKQ_ROW or BSK_ROW); *degenerate (device) is set
 // when a word has none

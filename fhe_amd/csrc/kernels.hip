@@ -1054,16 +1054,15 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_q2_pair(Tables T, const 
 // Inside the window the result is exact and equals the CPU restatement's bit for bit.
 // ------------------------------------------------------------------------------------------------
 constexpr int G64_TW_WORDS = 4 * G2_TW_SMALL;   // entries 0..63 of the forward and inverse tables of either prime
-static constexpr size_t G64_LDS_BYTES = G2P_NC * LDS_BYTES + G64_TW_WORDS * sizeof(double);
+constexpr size_t g64_lds_bytes(int nc) { return (size_t)nc * LDS_BYTES + G64_TW_WORDS * sizeof(double); }
 
-// One prime's share of a step for the two ciphertexts of a workgroup: digits in x (pass-1
+// One prime's share of a step for the NC (two, or one for launches that do not fill the GPU) ciphertexts of a workgroup: digits in x (pass-1
 // ownership) -> residues of the external product in x (|x| < 2 p, pass-1 ownership).  Ends with the
 // workgroup barrier that frees the exchange buffers.
-template <int R, bool FACTORED>
-__device__ __forceinline__ void g64_prime_pass(double (&x)[G2P_NC][2][E], const Tables& T,
-                                               const double* __restrict__ rows, const unsigned (&am)[G2P_NC][2],
+template <int R, bool FACTORED, int NC>
+__device__ __forceinline__ void g64_prime_pass(double (&x)[NC][2][E], const Tables& T,
+                                               const double* __restrict__ rows, const unsigned (&am)[NC][2],
                                                unsigned t) {
-    constexpr int NC = G2P_NC;
     const Prime P = T.pr[R];
     const double* __restrict__ twf_small = lds_dyn + NC * LDS_WORDS + 2 * R * G2_TW_SMALL;
     const double* __restrict__ twi_small = twf_small + G2_TW_SMALL;
@@ -1249,7 +1248,7 @@ __device__ __forceinline__ void g64_prime_pass(double (&x)[G2P_NC][2][E], const 
     __syncthreads();  // the last pass's reads are done before the buffers are written again
 }
 
-template <bool FACTORED>
+template <bool FACTORED, int NC>
 __global__ void __launch_bounds__(NT, 2) k_blind_rotate_g64_pair(Tables T, const double* __restrict__ bsk,
                                                                 const u64* __restrict__ lwe_small, int n,
                                                                 const u64* __restrict__ luts,
@@ -1257,7 +1256,6 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_g64_pair(Tables T, const
                                                                 u64* __restrict__ glwe_out,
                                                                 u64* __restrict__ lwe_out, BlockMap omap,
                                                                 unsigned count) {
-    constexpr int NC = G2P_NC;
     const unsigned t = threadIdx.x;
     size_t ct[NC];
     const u64* __restrict__ lwe[NC];
@@ -1304,7 +1302,7 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_g64_pair(Tables T, const
                     dig[c][q][j] = decomp23(acc[c][q][j]);
                     x[c][q][j] = (double)dig[c][q][j];
                 }
-        g64_prime_pass<0, FACTORED>(x, T, rows, am, t);
+        g64_prime_pass<0, FACTORED, NC>(x, T, rows, am, t);
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -1314,7 +1312,7 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_g64_pair(Tables T, const
                     y0[c][q][j] = x[c][q][j];
                     x[c][q][j] = (double)dig[c][q][j];
                 }
-        g64_prime_pass<1, FACTORED>(x, T, rows, am, t);
+        g64_prime_pass<1, FACTORED, NC>(x, T, rows, am, t);
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -1576,8 +1574,8 @@ void blind_rotate_setup(int dev) {
                     ask_lds(k_blind_rotate_q2_pair<false, false>, G2P_LDS_BYTES) &&
                     ask_lds(k_blind_rotate_q2_pair<true, true>, G2P_LDS_BYTES) &&
                     ask_lds(k_blind_rotate_q2_pair<false, true>, G2P_LDS_BYTES) &&
-                    ask_lds(k_blind_rotate_g64_pair<false>, G64_LDS_BYTES) &&
-                    ask_lds(k_blind_rotate_g64_pair<true>, G64_LDS_BYTES) &&
+                    ask_lds(k_blind_rotate_g64_pair<false, 2>, g64_lds_bytes(2)) &&
+                    ask_lds(k_blind_rotate_g64_pair<true, 2>, g64_lds_bytes(2)) &&
                     ask_lds(k_blind_rotate_q2_wide<false>, WIDE2_LDS_BYTES) &&
                     ask_lds(k_blind_rotate_q2_wide<true>, WIDE2_LDS_BYTES) &&
                     ask_lds(k_blind_rotate_q_wide, WIDE_LDS_BYTES);
@@ -1796,15 +1794,18 @@ void launch_external_product(const Tables& T, const double* bsk, const u32* idx,
 }
 void launch_blind_rotate(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
                          const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
-                         const BlockMap& omap, int grouping, hipStream_t st) {
-    if (grouping >= 2) {   // four GGSWs per pair of key bits (3: in factored form), two ciphertexts per workgroup
-        const dim3 grid((unsigned)((count + G2P_NC - 1) / G2P_NC));
-        if (grouping == 3)
-            hipLaunchKernelGGL(k_blind_rotate_g64_pair<true>, grid, dim3(NT), G64_LDS_BYTES, st, T, bsk, lwe_small, n, luts,
-                               lut_index, glwe_out, lwe_out, omap, (unsigned)count);
-        else
-            hipLaunchKernelGGL(k_blind_rotate_g64_pair<false>, grid, dim3(NT), G64_LDS_BYTES, st, T, bsk, lwe_small, n, luts,
-                               lut_index, glwe_out, lwe_out, omap, (unsigned)count);
+                         const BlockMap& omap, int grouping, int pair_above, hipStream_t st) {
+    if (grouping >= 2) {
+        // four GGSWs per pair of key bits (3: in factored form); two ciphertexts per workgroup, one when
+        // the launch would leave CUs without a workgroup otherwise (pair_above: as for the prime modulus)
+        const bool pair = pair_above >= 0 && count > (size_t)pair_above;
+        const dim3 grid((unsigned)(pair ? (count + 1) / 2 : count));
+        auto go = [&](auto kernel, int nc) {
+            hipLaunchKernelGGL(kernel, grid, dim3(NT), g64_lds_bytes(nc), st, T, bsk, lwe_small, n, luts, lut_index, glwe_out,
+                               lwe_out, omap, (unsigned)count);
+        };
+        if (grouping == 3) { if (pair) go(k_blind_rotate_g64_pair<true, 2>, 2); else go(k_blind_rotate_g64_pair<true, 1>, 1); }
+        else { if (pair) go(k_blind_rotate_g64_pair<false, 2>, 2); else go(k_blind_rotate_g64_pair<false, 1>, 1); }
         return;
     }
     hipLaunchKernelGGL(k_blind_rotate, dim3((unsigned)count), dim3(NT), LDS_BYTES, st, T, bsk, lwe_small, n, luts,
