@@ -226,7 +226,7 @@ LFHE_HD void mono_pair(double base, const double* __restrict__ w8, unsigned e, c
 //   rows as generated (K0..K3):   B = (K0 + m1 K1) + m2 (K2 + m1 K3)                 three products
 //   FACTORED rows (a, b, d, c):   B = d (m1 + a)(m2 + b) + c                          two products
 // with a = K2/K3, b = K1/K3, d = K3, c = K0 - K1 K2 / K3 computed once when the key is loaded
-// (k_bskq_factor): the same residue, 15 instead of 21 FP64 instructions per entry.  |B| < 2.2 p either way.
+// (k_bsk_factor): the same residue, 15 instead of 21 FP64 instructions per entry.  |B| < 2.2 p either way.
 template <bool FACTORED>
 LFHE_HD void ggsw_entry_row(int m, double& B, double& S, double k, double m1, double m2, const Prime& P) {
     if constexpr (FACTORED) {
