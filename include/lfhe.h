@@ -48,8 +48,9 @@ extern "C" {
 #define LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK_GROUPED 3u
 /* the named set itself -- every modulus 2^64, as published -- with the key bits taken two at a time:
  * four GGSWs over 2^64 per pair of bits, half the transforms of set 1 (two-prime transform and lift
- * per step).  The lift of a step is exact unless a sum of 4096 products leaves a window of 149
- * standard deviations; set 1 is exact without condition. */
+ * per step).  The lift of a step is exact unless a sum of 4096 products of a 23-bit digit and a sum of
+ * four uniform 64-bit key words (standard deviation 2^90.4) leaves the +-2^97.6 the two primes tell
+ * apart, 149 standard deviations out; set 1 is exact without condition. */
 #define LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_GROUPED 4u
 
 typedef struct lfhe_ctx lfhe_ctx;
