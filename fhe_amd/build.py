@@ -20,15 +20,36 @@ def _stale() -> bool:
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
+OBJ_DIR = os.path.join(HERE, "_build")
+
+
 def build(force: bool = False, verbose: bool = False, out: str = OUT, defines: tuple = ()) -> str:
+    """One object per source under fhe_amd/_build (compiled side by side, kept between builds: a
+    change to one source recompiles that source, a change to a header everything), then one link."""
     if out == OUT and not force and not _stale():
         return OUT
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-pthread",
-           "-Wall", "-Wno-unused-function", "-x", "hip"]
-    cmd += [f"-D{d}" for d in defines]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", out]
+    flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-pthread", "-Wall", "-Wno-unused-function"]
+    flags += [f"-D{d}" for d in defines]
+    tag = "" if out == OUT else "." + str(abs(hash((out,) + tuple(defines))) % 10 ** 8)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    newest_header = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+
+    def compile_one(src: str) -> str:
+        obj = os.path.join(OBJ_DIR, src + tag + ".o")
+        path = os.path.join(CSRC, src)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), newest_header):
+            return obj
+        cmd = [hipcc] + flags + ["-x", "hip", "-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), int(os.environ.get("MAX_JOBS", "8")))) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-pthread"] + objs + ["-o", out]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

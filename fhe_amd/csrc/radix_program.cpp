@@ -23,22 +23,25 @@ Builder::Info Builder::eval(const Expr& e) const {
     return r;
 }
 
-uint32_t Builder::lut_id(const std::function<int(int)>& f) {
+uint32_t Builder::lut_id(const std::function<int(int)>& f, bool wraps) {
     std::array<uint64_t, 16> tab;
     for (int x = 0; x < 16; ++x) {
         const int v = f(x);
-        if (v < 0 || v > BLOCK_MAX) throw std::logic_error("lookup table value outside the block");
-        tab[x] = (uint64_t)v;
+        // a value of 16 and more has the padding bit set: for the input of a wrapped bootstrap only
+        if (wraps ? (v < -BLOCK_MAX || v > BLOCK_MAX) : (v < 0 || v > 2 * BLOCK_MAX + 1))
+            throw std::logic_error("lookup table value outside the block");
+        tab[x] = (uint64_t)((v + 2 * (BLOCK_MAX + 1)) % (2 * (BLOCK_MAX + 1)));
     }
-    auto it = lut_ids_.find(tab);
+    auto it = lut_ids_.find({tab, wraps});
     if (it != lut_ids_.end()) return it->second;
     const uint32_t id = (uint32_t)P.luts.size();
     P.luts.push_back(tab);
-    lut_ids_[tab] = id;
+    P.lut_wraps.push_back(wraps ? 1 : 0);
+    lut_ids_[{tab, wraps}] = id;
     return id;
 }
 
-uint32_t Builder::lin(const Expr& e0, const Info& i) {
+uint32_t Builder::lin(const Expr& e0, const Info& i, int limit) {
     // the linear operations of one layer run side by side in one launch: a term that is itself the
     // output of a linear operation of this layer is replaced by the combination that defines it
     Expr e;
@@ -50,7 +53,7 @@ uint32_t Builder::lin(const Expr& e0, const Info& i) {
         e.cst += c * it->second.cst;
     }
     if (e.t.size() > (size_t)LIN_MAX_TERMS) throw std::logic_error("linear combination too long");
-    if (i.lo < 0 || i.hi > BLOCK_MAX) throw std::logic_error("block value range overflows the carry space");
+    if (i.lo < 0 || i.hi > limit) throw std::logic_error("block value range overflows the carry space");
     if (i.noise > MAX_NOISE) throw std::logic_error("noise level above the parameter set's budget");
     const uint32_t out = new_block(i.level, i.lo, i.hi, i.noise);
     LinOp op{};
@@ -63,12 +66,29 @@ uint32_t Builder::lin(const Expr& e0, const Info& i) {
     return out;
 }
 
-uint32_t Builder::mat(const Expr& e, int hi_known, int lo_known) {
-    if (e.t.size() == 1 && e.t[0].first == 1 && e.cst == 0) return e.t[0].second;
+uint32_t Builder::mat(const Expr& e, int hi_known, int lo_known, int limit) {
+    if (e.t.size() == 1 && e.t[0].first == 1 && e.cst == 0 && info_[e.t[0].second].lo >= 0) return e.t[0].second;
     Info i = eval(e);
     if (hi_known >= 0) i.hi = std::min(i.hi, hi_known);
     if (lo_known >= 0) i.lo = std::max(i.lo, lo_known);
-    return lin(e, i);
+    return lin(e, i, limit);
+}
+
+uint32_t Builder::pbs_wrapped(const Expr& e, const std::function<int(int)>& f) {
+    const int space = BLOCK_MAX + 1;
+    const Info i = eval(e);
+    if (i.lo < 0 || i.hi >= 2 * space) throw std::logic_error("bootstrap input range overflows the padding bit");
+    if (i.noise > MAX_NOISE) throw std::logic_error("bootstrap input noise above the parameter set's budget");
+    const uint32_t in = mat(e, -1, -1, 2 * space - 1);
+    int lo = space, hi = -space;
+    for (int x = i.lo; x <= i.hi; ++x) {
+        const int v = x < space ? f(x) : -f(x - space);
+        lo = std::min(lo, v);
+        hi = std::max(hi, v);
+    }
+    const uint32_t out = new_block(i.level + 1, lo, hi, 1);
+    layer(i.level).pbs.push_back({in, out, lut_id(f, true)});
+    return out;
 }
 
 uint32_t Builder::pbs(const Expr& e, const std::function<int(int)>& f) {
@@ -114,6 +134,8 @@ std::string Program::to_json() const {
         for (int x = 0; x < 16; ++x) o << (x ? "," : "") << luts[i][x];
         o << "]";
     }
+    o << "],\"lut_wraps\":[";
+    for (size_t i = 0; i < lut_wraps.size(); ++i) o << (i ? "," : "") << (int)lut_wraps[i];
     o << "],\"layers\":[";
     for (size_t l = 0; l < layers.size(); ++l) {
         o << (l ? "," : "") << "{\"lin\":[";
@@ -157,44 +179,62 @@ Expr pack(Builder& B, uint32_t hi_blk, uint32_t lo_blk) { return Builder::add(Bu
 
 // Three-valued states (0 kill, 1 pass, 2 set) and their composition "the most significant state
 // that is not `pass` decides" -- carry states of an addition (none / propagate / generate), signs of a
-// comparison (less / equal / greater).  Up to THREE states compose in one bootstrap: with the state
-// at position k (0 = least significant) held as state * 2^k, the plain sum of the blocks is the
-// addition the states describe -- `pass` is a one bit that hands a carry on, `set` a carry into the
-// next position -- so the composed state is set when the sum reaches 2^g, pass when it is 2^g - 1
-// (all pass), kill otherwise; the largest sum, 2 + 4 + 8, still fits a block.  A state is a
-// function of one bootstrap input, so the table that produces it can hand it out at whatever
-// position its consumer needs; a second consumer at another position costs a second bootstrap of
-// the same input in the same layer, never an extra layer.
+// comparison (less / equal / greater).  With the state at position k (0 = least significant) held
+// as state * 2^k, the plain sum of the blocks is the addition the states describe -- `pass` is a
+// one bit that hands a carry on, `set` a carry into the next position -- so g composed states are
+// set when the sum reaches 2^g, pass when it is 2^g - 1 (all pass), kill otherwise.
+//   * Three states: the largest sum, 2 + 4 + 8, fits a block.
+//   * FOUR states: the sum reaches 30 and runs into the padding bit, where a blind rotation returns
+//     minus the table entry of x - 16.  The table holds -1 below 15 and 0 at 15, so the rotation
+//     returns +1 from 16 on: state - 1, and the 1 is a constant added afterwards (Builder::
+//     pbs_wrapped).  A node made this way is `wrapped`.
+//   * A state that is never `pass` (a resolved carry) can join either sum below position 0 as the
+//     single bit "carry in": 1 + 2 + 4 + 8 and 1 + 2 + 4 + 8 + 16 still fit, and the result is again
+//     resolved.  The bit is half a state: only a node that is not wrapped can hand it out; a
+//     wrapped resolved carry takes the least significant state position instead.
+// A state is a function of one bootstrap input, so the table that produces it can hand it out at
+// whatever position its consumer needs; a second consumer at another position costs a second
+// bootstrap of the same input in the same layer, never an extra layer.
 class States {
 public:
     explicit States(Builder& b) : B(b) {}
     int leaf(const Expr& in, std::function<int(int)> fn) {
-        nodes.push_back({in, std::move(fn), {-1, -1, -1}});
+        nodes.push_back({in, std::move(fn), false, {-1, -1, -1, -1, -1}});
         return (int)nodes.size() - 1;
     }
-    // states[0] is the most significant
-    int combine(const std::vector<int>& states) {
-        const int g = (int)states.size();
+    bool wrapped(int node) const { return nodes[node].wrapped; }
+    // how many state positions combine(states, carry) needs
+    size_t positions(size_t nstates, int carry) const { return nstates + (carry >= 0 && nodes[carry].wrapped ? 1 : 0); }
+    // states[0] is the most significant; carry (optional): a resolved state entering below states.back()
+    int combine(std::vector<int> states, int carry = -1) {
         Expr in;
-        for (int j = 0; j < g; ++j) in = Builder::add(in, B.E(at(states[j], g - 1 - j)));
-        return leaf(in, [g](int x) { return x >= (1 << g) ? 2 : (x == (1 << g) - 1 ? 1 : 0); });
-    }
-    // the block holding state * 2^k
-    uint32_t at(int node, int k) {
-        if (nodes[node].blk[k] < 0) {
-            const auto fn = nodes[node].fn;
-            nodes[node].blk[k] = (int)B.pbs(nodes[node].in, [fn, k](int x) { return fn(x) << k; });
+        if (carry >= 0) {
+            if (nodes[carry].wrapped) states.push_back(carry);
+            else in = at(carry, -1);
         }
-        return (uint32_t)nodes[node].blk[k];
+        const int g = (int)states.size();
+        if (g > 4) throw std::logic_error("more than four states in one bootstrap");
+        for (int j = 0; j < g; ++j) in = Builder::add(in, at(states[j], g - 1 - j));
+        const bool resolved = carry >= 0;
+        if (g <= 3) return leaf(in, [g, resolved](int x) { return x >= (1 << g) ? 2 : (x == (1 << g) - 1 && !resolved ? 1 : 0); });
+        nodes.push_back({in, [resolved](int x) { return x == 15 && !resolved ? 0 : -1; }, true, {-1, -1, -1, -1, -1}});
+        return (int)nodes.size() - 1;
     }
-    // state * 4 as an expression, from a block that exists already if there is one
-    Expr times4(int node) {
-        for (int k = 2; k >= 0; --k)
-            if (nodes[node].blk[k] >= 0) return Builder::scale(B.E((uint32_t)nodes[node].blk[k]), 4 >> k);
-        return B.E(at(node, 2));
+    // state * 2^k as an expression; k = -1 (resolved states that are not wrapped): the bit "set"
+    Expr at(int node, int k) {
+        Node& n = nodes[node];
+        if (n.wrapped && k < 0) throw std::logic_error("a wrapped state has no carry bit");
+        if (n.blk[k + 1] < 0) {
+            const auto fn = n.fn;
+            if (n.wrapped) n.blk[k + 1] = (int)B.pbs_wrapped(n.in, [fn, k](int x) { return fn(x) * (1 << k); });
+            else n.blk[k + 1] = (int)B.pbs(n.in, [fn, k](int x) { return k < 0 ? fn(x) >> 1 : fn(x) << k; });
+        }
+        const Expr e = B.E((uint32_t)nodes[node].blk[k + 1]);
+        return nodes[node].wrapped ? Builder::add(e, Builder::C(1 << k)) : e;
     }
     // a bootstrap of the state's own input through g(state)
     uint32_t map(int node, std::function<int(int)> g) {
+        if (nodes[node].wrapped) throw std::logic_error("map of a wrapped state");
         const auto fn = nodes[node].fn;
         return B.pbs(nodes[node].in, [fn, g](int x) { return g(fn(x)); });
     }
@@ -202,46 +242,88 @@ public:
 private:
     struct Node {
         Expr in;
-        std::function<int(int)> fn;
-        int blk[3];
+        std::function<int(int)> fn;  // the state on [0,16); wrapped: state - 1
+        bool wrapped;
+        int blk[5];  // state * 2^k for k = -1 .. 3
     };
     Builder& B;
     std::vector<Node> nodes;
 };
 
-// Carry propagation over per-block sums v[i] in [0,7]: digit i = (v[i] + carry_in[i]) mod 4,
-// carry_out[i] = (v[i] + carry_in[i]) >= 4.  One layer extracts digit and carry state (none,
-// propagate, generate), a prefix network over the states resolves them in ceil(log3 (m - 1))
-// layers, a last layer adds the incoming carry.
+// Carry propagation over per-block sums v[i] in [0,7] (v[i] + carry_in[i] <= 7): digit i =
+// (v[i] + carry_in[i]) mod 4, carry_out[i] = (v[i] + carry_in[i]) >= 4.  One layer extracts digit and
+// carry state (none, propagate, generate); position 0 has no carry in, so its state is resolved from
+// the start.  A prefix network in base four then grows two things at once.  With q = position - 1
+// and F the number of q whose carry out is resolved, level L (w = 4^L) holds for every q >= F the
+// state of the run from the start of q's group of width w (groups counted from F) up to q.  The next
+// level resolves q in [F + w, F + R w) from the resolved carry into F and the states of up to R
+// groups (R = 4 when the carry can enter as a bit, else 3), and composes the states beyond into
+// groups of width 4 w.  The last bootstrap of a position adds its incoming carry to the digit; it
+// has room for a resolved carry AND one unresolved state on top (digit + 4 (carry + state), carry in
+// = the sum reaches 2), so q in [F, F + w) never need a resolved carry of their own.  Two prefix
+// levels serve 32 blocks, three serve 128, and none of them waits for the others to finish: blocks
+// whose sums arrive early (the low columns of a product) resolve early.
+namespace {
+// prefix levels still needed when q < F are resolved and states span w; bit: the carry into F can be
+// handed out as a bit.  *R: the number of groups to resolve at this level.
+int prefix_levels(size_t F, size_t w, bool bit, size_t nq, int* R) {
+    if (F + w >= nq) return 0;
+    int best = 1 << 20;
+    for (int r = bit ? 4 : 3; r >= 2; --r) {
+        // the carry into the new F composes r states and the carry: wrapped when that needs four positions
+        const bool next_bit = r + (bit ? 0 : 1) <= 3;
+        const int l = 1 + prefix_levels(F + r * w, 4 * w, next_bit, nq, nullptr);
+        if (l < best) { best = l; if (R) *R = r; }
+    }
+    return best;
+}
+}  // namespace
+
 Blocks propagate(Builder& B, const std::vector<Expr>& v) {
-    const size_t m = v.size(), n = m ? m - 1 : 0;
-    Blocks msg(m);
+    const size_t m = v.size();
+    Blocks res(m), msg(m);
+    for (size_t i = 0; i < m; ++i) msg[i] = B.pbs(v[i], lo2);
+    if (m) res[0] = msg[0];
+    if (m < 2) return res;
     States S(B);
-    std::vector<int> st(n);
-    for (size_t i = 0; i < m; ++i) {
-        msg[i] = B.pbs(v[i], lo2);
-        if (i < n) {
-            if (i == 0) st[i] = S.leaf(v[i], [](int x) { return x >= 4 ? 2 : 0; });
-            else st[i] = S.leaf(v[i], [](int x) { return x >= 4 ? 2 : (x == 3 ? 1 : 0); });
-        }
-    }
-    // Sklansky network in base three: at the level of width w every group of 3 w positions is cut
-    // into thirds A, B, C; a position of B absorbs the last position of A, a position of C the last
-    // positions of B and of A.  Afterwards st[i] composes everything from the start of the group.
-    for (size_t w = 1; w < n; w *= 3) {
+    const int c0 = S.leaf(v[0], [](int x) { return x >= 4 ? 2 : 0; });
+    const size_t nq = m - 2;  // q = 0 .. nq-1: positions 1 .. m-2, the ones whose carry out is used
+    std::vector<int> st(nq);
+    for (size_t q = 0; q < nq; ++q) st[q] = S.leaf(v[q + 1], [](int x) { return x >= 4 ? 2 : (x == 3 ? 1 : 0); });
+    // what the last bootstrap of a position adds to its digit: a resolved carry, and a state above it
+    struct CarryIn { int carry, state; };
+    std::vector<CarryIn> cin(m, CarryIn{-1, -1});
+    cin[1] = {c0, -1};
+    size_t F = 0;
+    int carry = c0;  // the resolved carry into q = F
+    for (size_t w = 1; F < nq; w *= 4) {
+        for (size_t q = F; q < std::min(F + w, nq); ++q) cin[q + 2] = {carry, st[q]};
+        int R = 0;
+        if (prefix_levels(F, w, !S.wrapped(carry), nq, &R) == 0) break;
         std::vector<int> nx = st;
-        for (size_t i = 0; i < n; ++i) {
-            const size_t third = (i / w) % 3, start = (i / w) * w;
-            if (third == 1) nx[i] = S.combine({st[i], st[start - 1]});
-            else if (third == 2) nx[i] = S.combine({st[i], st[start - 1], st[start - 1 - w]});
+        for (size_t q = F + w; q < nq; ++q) {
+            const bool resolve = q < F + R * w;
+            const size_t start = resolve ? F : F + R * w + (q - F - R * w) / (4 * w) * (4 * w);
+            const size_t part = (q - start) / w;
+            std::vector<int> run{st[q]};
+            for (size_t k = part; k >= 1; --k) run.push_back(st[start + k * w - 1]);
+            if (resolve) {
+                nx[q] = S.combine(run, carry);
+                cin[q + 2] = {nx[q], -1};
+            } else if (part >= 1) {
+                nx[q] = S.combine(run);
+            }
         }
-        st = nx;
+        st.swap(nx);
+        F += R * w;
+        if (F - 1 < nq) carry = st[F - 1];
     }
-    Blocks res(m);
-    for (size_t i = 0; i < m; ++i) {
-        if (i == 0) res[i] = msg[i];
-        else res[i] = B.pbs(Builder::add(B.E(msg[i]), S.times4(st[i - 1])),
-                            [](int x) { return (lo2(x) + (hi2(x) == 2 ? 1 : 0)) & 3; });
+    for (size_t i = 1; i < m; ++i) {
+        // above the digit: carry bit + state (0 .. 3), or the carry alone as the state `set` (0 / 2)
+        Expr in = B.E(msg[i]);
+        if (cin[i].state >= 0) in = Builder::add(Builder::add(in, S.at(cin[i].carry, 1)), S.at(cin[i].state, 2));
+        else in = Builder::add(in, S.at(cin[i].carry, 2));
+        res[i] = B.pbs(in, [](int x) { return (lo2(x) + (hi2(x) >= 2 ? 1 : 0)) & 3; });
     }
     return res;
 }
@@ -354,7 +436,7 @@ uint32_t op_eq(Builder& B, const Blocks& a0, const Blocks& b0, bool negate) {
 }
 
 // order: per-block sign (0 less, 1 equal, 2 greater), most significant non-equal block wins; the
-// signs compose three at a time (States)
+// signs compose four at a time (States)
 uint32_t op_cmp(Builder& B, const Blocks& a0, const Blocks& b0, uint32_t op) {
     const Blocks a = clean(B, a0), b = clean(B, b0);
     const size_t m = a.size();
@@ -370,10 +452,19 @@ uint32_t op_cmp(Builder& B, const Blocks& a0, const Blocks& b0, uint32_t op) {
     std::vector<int> cur;  // most significant first
     for (size_t i = m; i-- > 0;)
         cur.push_back(S.leaf(pack(B, a[i], b[i]), [](int x) { return hi2(x) > lo2(x) ? 2 : (hi2(x) < lo2(x) ? 0 : 1); }));
+    // four at a time (wrapped nodes) or three; the last node must not be wrapped (its verdict is a
+    // table of the state itself), so the last round composes at most three
+    std::function<int(size_t)> rounds = [&](size_t n) -> int {
+        if (n <= 1) return 0;
+        if (n <= 3) return 1;
+        return 1 + std::min(rounds((n + 2) / 3), n > 4 ? rounds((n + 3) / 4) : 1 << 20);
+    };
     while (cur.size() > 1) {
+        const size_t n = cur.size();
+        const size_t fan = n > 4 && rounds((n + 3) / 4) <= rounds((n + 2) / 3) ? 4 : 3;
         std::vector<int> nx;
-        for (size_t k = 0; k < cur.size(); k += 3) {
-            const size_t g = std::min<size_t>(3, cur.size() - k);
+        for (size_t k = 0; k < n; k += fan) {
+            const size_t g = std::min<size_t>(fan, n - k);
             if (g == 1) nx.push_back(cur[k]);
             else nx.push_back(S.combine(std::vector<int>(cur.begin() + k, cur.begin() + k + g)));
         }

@@ -47,6 +47,10 @@ struct Program {
     std::vector<uint32_t> lhs, rhs, cond;  // input block ids
     std::vector<uint32_t> out;             // output block ids, little-endian
     std::vector<std::array<uint64_t, 16>> luts;
+    // per table: 1 when its bootstraps take inputs up to 31 (padding bit in use).  A blind rotation
+    // maps an input x + 16 to minus the entry of x, so such a table holds values modulo 32 (an entry
+    // t >= 16 stands for t - 32) and its output may be negative until a constant is added.
+    std::vector<uint8_t> lut_wraps;
     std::vector<Layer> layers;
     uint8_t out_noise = 1, out_degree = 3;
     // fused programs (build_fused): any number of inputs and outputs instead of lhs / rhs / cond / out
@@ -89,10 +93,12 @@ public:
 
     // bootstrap of e through the table f : [0,16) -> [0,16)
     uint32_t pbs(const Expr& e, const std::function<int(int)>& f);
+    // bootstrap of an input in [0,32) through f : [0,16) -> (-16,16), continued as f(x + 16) = -f(x)
+    uint32_t pbs_wrapped(const Expr& e, const std::function<int(int)>& f);
     // e as a block (a linear op unless e already is a plain block); hi_known / lo_known >= 0
     // override the interval bounds when the caller knows tighter ones (e.g. a sum whose terms
     // exclude each other)
-    uint32_t mat(const Expr& e, int hi_known = -1, int lo_known = -1);
+    uint32_t mat(const Expr& e, int hi_known = -1, int lo_known = -1, int limit = BLOCK_MAX);
     int hi(uint32_t b) const { return info_[b].hi; }
     int noise(uint32_t b) const { return info_[b].noise; }
     void finish();
@@ -100,7 +106,7 @@ public:
 private:
     struct Info { int level, lo, hi, noise; };
     std::vector<Info> info_;
-    std::map<std::array<uint64_t, 16>, uint32_t> lut_ids_;
+    std::map<std::pair<std::array<uint64_t, 16>, bool>, uint32_t> lut_ids_;
     std::map<uint32_t, Expr> lin_expr_;  // blocks defined by a linear operation
     uint32_t new_block(int level, int lo, int hi, int noise) {
         info_.push_back({level, lo, hi, noise});
@@ -111,8 +117,8 @@ private:
         if ((int)P.layers.size() <= l) P.layers.resize(l + 1);
         return P.layers[l];
     }
-    uint32_t lut_id(const std::function<int(int)>& f);
-    uint32_t lin(const Expr& e, const Info& i);
+    uint32_t lut_id(const std::function<int(int)>& f, bool wraps = false);
+    uint32_t lin(const Expr& e, const Info& i, int limit);
 };
 
 // one step of a fused program; lhs / rhs / cond are value references (-1: unused)

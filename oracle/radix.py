@@ -25,6 +25,28 @@ def from_digits(d: list, width: int) -> int:
     return sum((int(v) & 3) << (2 * i) for i, v in enumerate(d)) & ((1 << width) - 1)
 
 
+def _run_layers_plain(prog: dict, blk: dict) -> None:
+    """Layers on clear blocks.  A table flagged in "lut_wraps" takes inputs up to 31: a blind rotation
+    returns minus the entry of x - 16 for an input x with the padding bit set, and the entries of such
+    a table are values modulo 32 (t >= 16 stands for t - 32), so its output may be negative until the
+    next linear operation adds its constant."""
+    wraps = prog.get("lut_wraps") or [0] * len(prog["luts"])
+    for layer in prog["layers"]:
+        for op in layer["lin"]:
+            v = op["cst"] + sum(c * blk[s] for c, s in op["terms"])
+            assert 0 <= v <= 31, f"block overflow {v}"
+            blk[op["out"]] = v
+        for i, o, l in layer["pbs"]:
+            x, tab = blk[i], prog["luts"][l]
+            if wraps[l]:
+                assert 0 <= x <= 31, f"bootstrap input {x}"
+                t = tab[x & 15] - 32 if tab[x & 15] >= 16 else tab[x & 15]
+                blk[o] = -t if x >= 16 else t
+            else:
+                assert 0 <= x <= 15, f"bootstrap input {x}"
+                blk[o] = tab[x]
+
+
 def run_plain(prog: dict, lhs: int, rhs: int | None = None, cond: int | None = None) -> int:
     w = prog["width"]
     blk = {}
@@ -36,14 +58,7 @@ def run_plain(prog: dict, lhs: int, rhs: int | None = None, cond: int | None = N
             blk[b] = v
     if prog["cond"]:
         blk[prog["cond"][0]] = cond & 1
-    for layer in prog["layers"]:
-        for op in layer["lin"]:
-            v = op["cst"] + sum(c * blk[s] for c, s in op["terms"])
-            assert 0 <= v <= 15, f"block overflow {v}"
-            blk[op["out"]] = v
-        for i, o, l in layer["pbs"]:
-            assert 0 <= blk[i] <= 15
-            blk[o] = prog["luts"][l][blk[i]]
+    _run_layers_plain(prog, blk)
     out = [blk[b] for b in prog["out"]]
     assert all(0 <= v <= 3 for v in out), "output not carry-free"
     return from_digits(out, prog["out_width"])
@@ -56,14 +71,7 @@ def run_plain_fused(prog: dict, inputs: list) -> list:
     for ids, w, v in zip(prog["ins"], prog["in_widths"], inputs):
         for b, d in zip(ids, digits(v, w)):
             blk[b] = d
-    for layer in prog["layers"]:
-        for op in layer["lin"]:
-            v = op["cst"] + sum(c * blk[s] for c, s in op["terms"])
-            assert 0 <= v <= 15, f"block overflow {v}"
-            blk[op["out"]] = v
-        for i, o, l in layer["pbs"]:
-            assert 0 <= blk[i] <= 15
-            blk[o] = prog["luts"][l][blk[i]]
+    _run_layers_plain(prog, blk)
     out = []
     for ids, w in zip(prog["outs"], prog["out_widths"]):
         d = [blk[b] for b in ids]
