@@ -262,7 +262,10 @@ int32_t lfhe_fused_dump(const lfhe_step* steps, uint32_t nsteps, uint32_t n_inpu
 /* The bootstrap schedule of an operator as JSON (layers of linear combinations and bootstraps over
  * block ids, the lookup tables, input/output block ids).  Needs no context and no GPU: it is the
  * host-side plan the executor replays, exposed for inspection and for checking the plan against a
- * plaintext model. */
+ * plaintext model.  "lut_wraps"[i] = 1 marks a table whose bootstraps take inputs up to 31 (the
+ * padding bit in use: the result for x >= 16 is minus the entry of x - 16); its entries are values
+ * modulo 32 (t >= 16 stands for t - 32), and the constant of the next linear combination brings the
+ * block back into [0, 16). */
 int32_t lfhe_program_dump(uint32_t op, uint32_t bit_width, int32_t lhs_noise, int32_t rhs_noise, int32_t cond_noise,
                           const uint8_t* scalar /* 32 bytes or NULL: clear shift amount / divisor */, char* out,
                           uint64_t* out_len);
@@ -286,7 +289,9 @@ int32_t lfhe_bsk_image_form(const lfhe_ctx* ctx, uint32_t* out);
 /* ---- the bootstrap path itself ------------------------------------------------------------------
  * Replaces: tfhe-rs keyswitch_programmable_bootstrap + generate_accumulator as the reference calls
  * them at ml/biometrics/notebooks/main.rs:68-71.  A ciphertext block is an LWE under the big key:
- * N + 1 = 2049 words.  A LUT is given as its table over [0, message_modulus*carry_modulus). */
+ * N + 1 = 2049 words.  A LUT is given as its table over [0, message_modulus*carry_modulus); entries
+ * are taken modulo twice that (an entry with the padding bit set is the negative value a negacyclic
+ * table returns for it). */
 int32_t lfhe_make_lut(lfhe_ctx* ctx, const uint64_t* table, uint64_t* lut_body /* [N] */);
 /* host buffers: count bootstraps, LUT bodies [nluts][N], lut_index [count] or NULL (all LUT 0) */
 int32_t lfhe_pbs_batch(lfhe_ctx* ctx, uint64_t count, const uint64_t* lwe_in, const uint64_t* lut_bodies,
