@@ -467,6 +467,34 @@ def test_grouped_key_pbs_full_parameters():
         ctx.close()
 
 
+def test_padding_bit_tables_full_parameters():
+    """Tables that use the padding bit (the operator schedules compose four carry states in one
+    bootstrap this way): inputs 0 .. 30, entries modulo 32; an input x >= 16 comes back as minus the
+    entry of x - 16.  Decrypted values as that rule says, every output bit-identical to the oracle."""
+    orc, keys, ctx = _mk_prime(918, seed=9, ms_zeros=1449, grouped=True)
+    try:
+        lwe_sk, glwe_sk, bskg, ksk = keys
+        pb = orc.prepare_bsk_qp_grouped(bskg)
+        r = Rng(seed_bytes(31))
+        # state - 1 of four composed states at position 3, the same resolved, and a table of mixed signs
+        f = [lambda x: 0 if x == 15 else -8, lambda x: -1, lambda x: (x % 7) - 3]
+        luts_o = [orc.make_lut(g) for g in f]
+        luts_g = np.stack([ctx.make_lut(g) for g in f])
+        assert all(np.array_equal(a[-ctx.N:], b) and not a[:-ctx.N].any() for a, b in zip(luts_o, luts_g))
+        msgs = [x for x in range(31)] * 3
+        idx = np.array([i // 31 for i in range(len(msgs))], dtype=np.uint32)
+        delta = orc.encode(1)
+        cts = np.stack([orc.lwe_encrypt(glwe_sk, m * delta, orc.p.glwe_noise_log2, r) for m in msgs])
+        out = ctx.pbs_batch(cts, luts_g, idx)
+        for i, m in enumerate(msgs):
+            want = f[idx[i]](m) if m < 16 else -f[idx[i]](m - 16)
+            e = (orc.lwe_phase(glwe_sk, out[i]) - want * delta) % (1 << 64)
+            assert min(e, (1 << 64) - e) < 1 << 53, (i, m, want)
+        assert np.array_equal(out, orc.pbs_batch_qp(ksk, pb, cts, np.stack(luts_o), idx, nthreads=16))
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("factored", [True, False], ids=["factored", "plain"])
 @pytest.mark.parametrize("n", [12, 13])
 def test_grouped_key_over_the_torus_bit_exact(n, factored):
