@@ -162,12 +162,64 @@ def test_fused_schedules():
         fused_program([("add", 16, 0, 5, None)], [16, 16], [2])         # dangling reference
 
 
+@pytest.mark.parametrize("w", [8, 16, 32, 64, 128, 256])
+def test_carry_and_sign_networks_on_chains_of_every_length(w):
+    """The carry network (a resolved prefix that grows by groups, states composed four at a time) and
+    the comparison tournament against operands built to stress them: a carry or borrow born at block
+    i that runs through a stretch of `propagate` blocks and dies at block j, for every (i, j) of a
+    sample, operands that differ in exactly one block, and random ones -- at every width, so that the
+    chains cross every group boundary of every level."""
+    rnd = random.Random(300 + w)
+    m = (1 << w) - 1
+    nb = w // 2
+    pairs = []
+    cuts = sorted(set(list(range(min(nb, 6))) + [nb - 1, nb - 2, nb // 2] + [rnd.randrange(nb) for _ in range(6)]))
+    for i in cuts:
+        for j in cuts:
+            if j < i:
+                continue
+            # blocks i .. j: a + b = 3 per block (propagate), a generate right below at block i - 1 or a
+            # carry born in block i itself; the rest random without carries (a | b disjoint)
+            a = b = 0
+            for k in range(nb):
+                if i <= k <= j:
+                    x = rnd.randrange(4)
+                    a |= x << (2 * k); b |= (3 - x) << (2 * k)
+                elif k == i - 1:
+                    a |= 3 << (2 * k); b |= (1 + rnd.randrange(3)) << (2 * k)
+                else:
+                    x = rnd.randrange(4)
+                    y = rnd.randrange(4 - x)
+                    a |= x << (2 * k); b |= y << (2 * k)
+            pairs += [(a, b), (a, (b + 1) & m), ((a + 1) & m, b)]
+    pairs += [(0, 0), (m, m), (m, 1), (1, m), (0, 1), (1 << (w - 1), 1 << (w - 1))]
+    pairs += [(rnd.randrange(m + 1), rnd.randrange(m + 1)) for _ in range(40)]
+    for k in cuts:        # equal but for one block (and equal): the tournament has to find that block
+        a = rnd.randrange(m + 1)
+        pairs += [(a, a ^ (1 << (2 * k))), (a, a ^ (2 << (2 * k))), (a, a)]
+    padd, psub, pneg = prog("add", w), prog("sub", w), prog("neg", w)
+    cmps = {op: prog(op, w) for op in ("lt", "le", "gt", "ge", "min", "max", "eq", "ne")}
+    for a, b in pairs:
+        assert radix.run_plain(padd, a, b) == (a + b) & m, (w, a, b)
+        assert radix.run_plain(psub, a, b) == (a - b) & m, (w, a, b)
+        assert radix.run_plain(psub, b, a) == (b - a) & m, (w, a, b)
+        assert radix.run_plain(pneg, a) == (-a) & m, (w, a)
+        for op, p in cmps.items():
+            assert radix.run_plain(p, a, b) == radix.clear_op(op, w, a, b), (op, w, a, b)
+    if w <= 64:
+        pmul = prog("mul", w)
+        for a, b in pairs[::3]:
+            assert radix.run_plain(pmul, a, b) == (a * b) & m, (w, a, b)
+
+
 def test_schedule_sizes_are_reported():
     """Bootstraps per operation (the scheduler's own count; the reference publishes none)."""
-    want_at_most = {("add", 64): 230, ("mul", 64): 2000, ("lt", 64): 63, ("eq", 64): 45, ("select", 64): 64}
-    for (op, w), cap in want_at_most.items():
+    want_at_most = {("add", 64): (150, 4), ("sub", 64): (150, 4), ("mul", 64): (1900, 9), ("lt", 64): (45, 4),
+                    ("eq", 64): (45, 4), ("select", 64): (64, 2), ("add", 256): (700, 5), ("lt", 256): (175, 5)}
+    for (op, w), (cap, depth) in want_at_most.items():
         p = prog(op, w)
         assert p["pbs"] == sum(len(l["pbs"]) for l in p["layers"]) <= cap, (op, w, p["pbs"])
+        assert len(p["layers"]) <= depth, (op, w, len(p["layers"]))
 
 
 def test_unsupported_operator_is_an_error():
