@@ -641,7 +641,7 @@ Blocks op_mul_clear(Builder& B, const Blocks& a, const Nat& c, size_t columns) {
 // Division of a W-bit integer by a clear d that is not a power of two, by multiplication with a
 // reciprocal (Granlund and Montgomery, "Division by invariant integers using multiplication",
 // unsigned case): l = ceil(log2 d), r = floor(2^W (2^l - d) / d) + 1, t = high half of r * a,
-// quotient = (t + ((a - t) >> 1)) >> (l - 1).  All intermediate values fit W bits.
+// quotient = (t + ((a - t) >> 1)) >> (l - 1) = (a + t) >> l.
 void op_divrem_clear(Builder& B, const Blocks& a0, const Nat& d, Blocks* quot, Blocks* rem) {
     const Blocks a = clean(B, a0);
     const size_t m = a.size(), W = 2 * m;
@@ -674,11 +674,13 @@ void op_divrem_clear(Builder& B, const Blocks& a0, const Nat& d, Blocks* quot, B
     for (size_t i = 0; i < r.size(); ++i)  // + 1
         if (++r[i]) break;
     const Blocks full = op_mul_clear(B, a, r, 2 * m);
-    const Blocks t(full.begin() + (long)m, full.end());
-    Blocks s = op_sub(B, a, t);
-    s = op_shift_clear(B, LFHE_OP_SHR, s, 1);
-    s = op_add(B, s, t);
-    const Blocks q = op_shift_clear(B, LFHE_OP_SHR, s, (long)l - 1);
+    // t + ((a - t) >> 1) = (a + t) >> 1 (the detour keeps the sum inside W bits); with one block more
+    // the sum itself fits, and the quotient is (a + t) >> l: one addition and one shift
+    std::vector<Expr> v;
+    for (size_t i = 0; i < m; ++i) v.push_back(Builder::add(B.E(a[i]), B.E(full[m + i])));
+    v.push_back(Builder::C(0));
+    Blocks q = op_shift_clear(B, LFHE_OP_SHR, propagate(B, v), (long)l);
+    q.pop_back();   // the quotient is below 2^W
     if (quot) *quot = q;
     if (rem) *rem = op_sub(B, a, op_mul_clear(B, clean(B, q), d, m));
 }
