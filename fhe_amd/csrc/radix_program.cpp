@@ -616,8 +616,10 @@ Nat nat_div(const Nat& num, const Nat& den) {
 }
 int nat_digit(const Nat& a, size_t i) { return nat_bit(a, 2 * i) | (nat_bit(a, 2 * i + 1) << 1); }
 
-// product of the blocks a (carry-free) with a clear natural c, `columns` base-4 digits of it
-Blocks op_mul_clear(Builder& B, const Blocks& a, const Nat& c, size_t columns) {
+// product of the blocks a (carry-free) with a clear natural c, `columns` base-4 digits of it; plus the
+// carry-free blocks `addend`, if given, from column `addend_col` on (they join the column sums)
+Blocks op_mul_clear(Builder& B, const Blocks& a, const Nat& c, size_t columns, const Blocks* addend = nullptr,
+                    size_t addend_col = 0) {
     const size_t m = a.size();
     std::vector<Blocks> cols(columns);
     for (size_t i = 0; i < m; ++i) {
@@ -635,13 +637,15 @@ Blocks op_mul_clear(Builder& B, const Blocks& a, const Nat& c, size_t columns) {
             if (d > 1 && i + j + 1 < columns) cols[i + j + 1].push_back(hi[d]);
         }
     }
+    if (addend)
+        for (size_t i = 0; i < addend->size() && addend_col + i < columns; ++i) cols[addend_col + i].push_back((*addend)[i]);
     return propagate(B, reduce_columns(B, cols));
 }
 
 // Division of a W-bit integer by a clear d that is not a power of two, by multiplication with a
 // reciprocal (Granlund and Montgomery, "Division by invariant integers using multiplication",
 // unsigned case): l = ceil(log2 d), r = floor(2^W (2^l - d) / d) + 1, t = high half of r * a,
-// quotient = (t + ((a - t) >> 1)) >> (l - 1) = (a + t) >> l.
+// quotient = (t + ((a - t) >> 1)) >> (l - 1) = (a + t) >> l = (a r + a 2^W) >> (W + l).
 void op_divrem_clear(Builder& B, const Blocks& a0, const Nat& d, Blocks* quot, Blocks* rem) {
     const Blocks a = clean(B, a0);
     const size_t m = a.size(), W = 2 * m;
@@ -673,16 +677,25 @@ void op_divrem_clear(Builder& B, const Blocks& a0, const Nat& d, Blocks* quot, B
     Nat r = nat_div(num, d);
     for (size_t i = 0; i < r.size(); ++i)  // + 1
         if (++r[i]) break;
-    const Blocks full = op_mul_clear(B, a, r, 2 * m);
     // t + ((a - t) >> 1) = (a + t) >> 1 (the detour keeps the sum inside W bits); with one block more
-    // the sum itself fits, and the quotient is (a + t) >> l: one addition and one shift
-    std::vector<Expr> v;
-    for (size_t i = 0; i < m; ++i) v.push_back(Builder::add(B.E(a[i]), B.E(full[m + i])));
-    v.push_back(Builder::C(0));
-    Blocks q = op_shift_clear(B, LFHE_OP_SHR, propagate(B, v), (long)l);
+    // the sum itself fits, and a + t is the upper part of a r + a 2^W: the blocks of a join the column
+    // sums of the product from column m on, and the quotient is one shift away
+    const Blocks full = op_mul_clear(B, a, r, 2 * m + 1, &a, m);
+    Blocks q = op_shift_clear(B, LFHE_OP_SHR, Blocks(full.begin() + (long)m, full.end()), (long)l);
     q.pop_back();   // the quotient is below 2^W
     if (quot) *quot = q;
-    if (rem) *rem = op_sub(B, a, op_mul_clear(B, clean(B, q), d, m));
+    if (rem) {
+        // a - q d = a + q (2^W - d) modulo 2^W: one product with a in its column sums saves the
+        // subtraction's layers, but 2^W - d has a non-zero digit wherever d runs out (every one of them
+        // costs a pair of bootstraps per block it meets): taken only when it is no longer than d
+        Nat neg_d((W + 63) / 64 + 1, 0);
+        neg_d[W / 64] |= 1ull << (W % 64);
+        nat_sub(neg_d, d);
+        size_t nz_d = 0, nz_neg = 0;
+        for (size_t j = 0; j < m; ++j) { nz_d += nat_digit(d, j) != 0; nz_neg += nat_digit(neg_d, j) != 0; }
+        if (nz_neg <= nz_d + 2) *rem = op_mul_clear(B, clean(B, q), neg_d, m, &a, 0);
+        else *rem = op_sub(B, a, op_mul_clear(B, clean(B, q), d, m));
+    }
 }
 
 }  // namespace
