@@ -230,10 +230,17 @@ void run_batch(lfhe_ctx* ctx, uint32_t op, uint32_t width, uint64_t n, const uin
     const int rn = (unary || rhs_scalar) ? 1 : check_operand(rhs, n, rhs_width);
     const int cn = op == LFHE_OP_SELECT ? check_operand(cond, n, 1) : 1;
     // a specialised program serves instances that share the clear operand: the caller groups them
-    const bool special = rhs_scalar && specialised_op(op);
+    bool special = rhs_scalar && specialised_op(op);
     if (special)
         for (uint64_t i = 1; i < n; ++i)
             if (std::memcmp(rhs, rhs + i * 32, 32)) throw std::logic_error("instances of one specialised run differ");
+    // a product with a clear factor has a schedule of its own (the factor's digits pick the partial
+    // products: about a third of the bootstraps) when every instance has the same factor; instances
+    // with different factors run the general schedule on constant blocks, in one batch
+    if (rhs_scalar && op == LFHE_OP_MUL && n) {
+        special = true;
+        for (uint64_t i = 1; i < n && special; ++i) special = !std::memcmp(rhs, rhs + i * 32, 32);
+    }
     Compiled& C = compiled_for(ctx, op, width, ln, rn, cn, special ? rhs : nullptr);
     const Program& P = C.prog;
     Engine& E = *ctx->eng;
@@ -906,7 +913,8 @@ int32_t lfhe_program_dump(uint32_t op, uint32_t bit_width, int32_t lhs_noise, in
     std::string js;
     try {
         if (!width_ok(bit_width)) return LFHE_ERR_ARG;
-        js = build_program(op, bit_width, lhs_noise, rhs_noise, cond_noise, specialised_op(op) ? scalar : nullptr).to_json();
+        js = build_program(op, bit_width, lhs_noise, rhs_noise, cond_noise,
+                           specialised_op(op) || op == LFHE_OP_MUL ? scalar : nullptr).to_json();
     } catch (const std::domain_error&) {
         return LFHE_ERR_ARG;
     } catch (const std::invalid_argument&) {

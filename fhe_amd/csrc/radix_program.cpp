@@ -639,6 +639,14 @@ Blocks op_mul_clear(Builder& B, const Blocks& a, const Nat& c, size_t columns, c
     }
     if (addend)
         for (size_t i = 0; i < addend->size() && addend_col + i < columns; ++i) cols[addend_col + i].push_back((*addend)[i]);
+    // at most one carry-free block per column (c = 0, 1, a power of four): nothing to add up
+    bool single = true;
+    for (const auto& col : cols) single = single && (col.empty() || (col.size() == 1 && B.hi(col[0]) <= 3));
+    if (single) {
+        Blocks r;
+        for (const auto& col : cols) r.push_back(col.empty() ? B.mat(Builder::C(0)) : col[0]);
+        return r;
+    }
     return propagate(B, reduce_columns(B, cols));
 }
 
@@ -702,7 +710,7 @@ void op_divrem_clear(Builder& B, const Blocks& a0, const Nat& d, Blocks* quot, B
 
 // One operator on blocks that already exist in the builder.  b: right operand blocks (encrypted, or
 // the constant blocks of a clear operand); scalar: the clear right operand, for the operators whose
-// schedule is specialised on it (shift / rotation amounts, divisors), else null.
+// schedule is specialised on it (shift / rotation amounts, divisors, clear factors), else null.
 static Blocks apply_op(Builder& B, uint32_t op, uint32_t width, const Blocks& a, const Blocks& b, uint32_t cond,
                        const uint8_t* scalar, uint32_t& out_width) {
     const int deg = width == 1 ? 1 : 3;
@@ -716,7 +724,13 @@ static Blocks apply_op(Builder& B, uint32_t op, uint32_t width, const Blocks& a,
         case LFHE_OP_ADD: return op_add(B, a, b);
         case LFHE_OP_SUB: return op_sub(B, a, b);
         case LFHE_OP_NEG: return op_neg(B, a);
-        case LFHE_OP_MUL: return op_mul(B, a, b);
+        case LFHE_OP_MUL:
+            if (scalar) {   // clear factor: its digits select the partial products, one bootstrap pair per block and digit value
+                Nat c(4);
+                for (int i = 0; i < 32; ++i) c[i / 8] |= (uint64_t)scalar[i] << (8 * (i % 8));
+                return op_mul_clear(B, clean(B, a), c, a.size());
+            }
+            return op_mul(B, a, b);
         case LFHE_OP_AND: case LFHE_OP_OR: case LFHE_OP_XOR: return op_bitwise(B, a, b, op);
         case LFHE_OP_NOT:
             for (uint32_t blk : a) out.push_back(B.mat(Builder::sub(Builder::C(deg), B.E(blk))));
@@ -748,7 +762,7 @@ static Blocks apply_op(Builder& B, uint32_t op, uint32_t width, const Blocks& a,
 
 static bool specialised_on_scalar(uint32_t op) {
     return op == LFHE_OP_SHL || op == LFHE_OP_SHR || op == LFHE_OP_ROTL || op == LFHE_OP_ROTR || op == LFHE_OP_DIV ||
-           op == LFHE_OP_REM;
+           op == LFHE_OP_REM || op == LFHE_OP_MUL;
 }
 
 Program build_program(uint32_t op, uint32_t width, int lhs_noise, int rhs_noise, int cond_noise, const uint8_t* scalar) {

@@ -133,6 +133,18 @@ def test_batch_matches_single_and_clear_model(ctx):
     out = ctx.evaluate_batch("add", 64, A, [y & 0xFFFF for y in ys])  # clear right operands
     assert [ctx.decrypt(o) for o in out] == [(x + (y & 0xFFFF)) & ((1 << 64) - 1) for x, y in zip(xs, ys)]
     assert ctx.evaluate_batch("add", 64, [], []) == []
+    # a clear factor shared by the whole batch runs the schedule built on the factor's digits (0, 1 and
+    # powers of four need no bootstrap at all); factors that differ run the general schedule on constants
+    m64 = (1 << 64) - 1
+    for c in (0, 1, 3, 16, 1000003, 0xF123456789ABCDEF):
+        n0 = ctx.pbs_count()
+        out = ctx.evaluate_batch("mul", 64, A[:8], [c] * 8)
+        assert [ctx.decrypt(o) for o in out] == [(x * c) & m64 for x in xs[:8]], c
+        assert ctx.pbs_count() - n0 <= 8 * 900, c
+    out = ctx.evaluate_batch("mul", 64, A[:8], ys[:8])
+    assert [ctx.decrypt(o) for o in out] == [(x * y) & m64 for x, y in zip(xs[:8], ys[:8])]
+    assert ctx.decrypt(ctx.evaluate("mul", 64, A[0], 12345)) == (xs[0] * 12345) & m64
+    assert ctx.decrypt(ctx.evaluate("add", 64, ctx.evaluate("mul", 64, A[1], 1), B[1])) == (xs[1] + ys[1]) & m64
     # clear amounts and divisors that differ between instances: grouped into specialised runs
     amounts = [(3 * i) % 5 + 60 * (i % 2) for i in range(n)]
     out = ctx.evaluate_batch("rotl", 64, A, amounts)
