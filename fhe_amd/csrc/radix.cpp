@@ -151,6 +151,8 @@ bool specialised_op(uint32_t op) {
     return op == LFHE_OP_SHL || op == LFHE_OP_SHR || op == LFHE_OP_ROTL || op == LFHE_OP_ROTR || op == LFHE_OP_DIV ||
            op == LFHE_OP_REM;
 }
+// operators whose schedule is specialised on a clear right operand only when the whole batch shares it
+bool shared_scalar_op(uint32_t op) { return op == LFHE_OP_MUL || op == LFHE_OP_AND || op == LFHE_OP_OR || op == LFHE_OP_XOR; }
 bool shift_op(uint32_t op) { return op == LFHE_OP_SHL || op == LFHE_OP_SHR || op == LFHE_OP_ROTL || op == LFHE_OP_ROTR; }
 
 Compiled& compiled_for(lfhe_ctx* ctx, uint32_t op, uint32_t width, int ln, int rn, int cn, const uint8_t* scalar) {
@@ -235,9 +237,10 @@ void run_batch(lfhe_ctx* ctx, uint32_t op, uint32_t width, uint64_t n, const uin
         for (uint64_t i = 1; i < n; ++i)
             if (std::memcmp(rhs, rhs + i * 32, 32)) throw std::logic_error("instances of one specialised run differ");
     // a product with a clear factor has a schedule of its own (the factor's digits pick the partial
-    // products: about a third of the bootstraps) when every instance has the same factor; instances
-    // with different factors run the general schedule on constant blocks, in one batch
-    if (rhs_scalar && op == LFHE_OP_MUL && n) {
+    // products: about a third of the bootstraps), and so have and / or / xor with a clear operand (no
+    // bootstrap where its digit is 0 or 3), when every instance has the same clear operand; instances
+    // with different ones run the general schedule on constant blocks, in one batch
+    if (rhs_scalar && shared_scalar_op(op) && n) {
         special = true;
         for (uint64_t i = 1; i < n && special; ++i) special = !std::memcmp(rhs, rhs + i * 32, 32);
     }
@@ -914,7 +917,7 @@ int32_t lfhe_program_dump(uint32_t op, uint32_t bit_width, int32_t lhs_noise, in
     try {
         if (!width_ok(bit_width)) return LFHE_ERR_ARG;
         js = build_program(op, bit_width, lhs_noise, rhs_noise, cond_noise,
-                           specialised_op(op) || op == LFHE_OP_MUL ? scalar : nullptr).to_json();
+                           specialised_op(op) || shared_scalar_op(op) ? scalar : nullptr).to_json();
     } catch (const std::domain_error&) {
         return LFHE_ERR_ARG;
     } catch (const std::invalid_argument&) {

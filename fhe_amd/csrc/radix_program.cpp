@@ -731,7 +731,23 @@ static Blocks apply_op(Builder& B, uint32_t op, uint32_t width, const Blocks& a,
                 return op_mul_clear(B, clean(B, a), c, a.size());
             }
             return op_mul(B, a, b);
-        case LFHE_OP_AND: case LFHE_OP_OR: case LFHE_OP_XOR: return op_bitwise(B, a, b, op);
+        case LFHE_OP_AND: case LFHE_OP_OR: case LFHE_OP_XOR:
+            if (scalar) {   // clear operand: a table of the block alone, and no bootstrap where the digit is 0 or 3
+                for (size_t i = 0; i < a.size(); ++i) {
+                    const int c = width == 1 ? (scalar[0] & 1) : ((scalar[(2 * i) >> 3] >> ((2 * i) & 7)) & 3);
+                    const bool keep = op == LFHE_OP_AND ? c == deg : c == 0;            // x & 3, x | 0, x ^ 0
+                    const bool fixed = op == LFHE_OP_AND ? c == 0 : (op == LFHE_OP_OR && c == deg);
+                    if (keep && B.hi(a[i]) <= deg) out.push_back(a[i]);
+                    else if (fixed) out.push_back(B.mat(Builder::C(op == LFHE_OP_AND ? 0 : deg)));
+                    else if (op == LFHE_OP_XOR && c == deg && B.hi(a[i]) <= deg) out.push_back(B.mat(Builder::sub(Builder::C(deg), B.E(a[i]))));
+                    else out.push_back(B.pbs(B.E(a[i]), [op, c, deg](int x) {
+                        const int p = x & deg;
+                        return op == LFHE_OP_AND ? (p & c) : op == LFHE_OP_OR ? (p | c) : (p ^ c);
+                    }));
+                }
+                return out;
+            }
+            return op_bitwise(B, a, b, op);
         case LFHE_OP_NOT:
             for (uint32_t blk : a) out.push_back(B.mat(Builder::sub(Builder::C(deg), B.E(blk))));
             return out;
@@ -762,7 +778,7 @@ static Blocks apply_op(Builder& B, uint32_t op, uint32_t width, const Blocks& a,
 
 static bool specialised_on_scalar(uint32_t op) {
     return op == LFHE_OP_SHL || op == LFHE_OP_SHR || op == LFHE_OP_ROTL || op == LFHE_OP_ROTR || op == LFHE_OP_DIV ||
-           op == LFHE_OP_REM || op == LFHE_OP_MUL;
+           op == LFHE_OP_REM || op == LFHE_OP_MUL || op == LFHE_OP_AND || op == LFHE_OP_OR || op == LFHE_OP_XOR;
 }
 
 Program build_program(uint32_t op, uint32_t width, int lhs_noise, int rhs_noise, int cond_noise, const uint8_t* scalar) {

@@ -145,6 +145,17 @@ def test_batch_matches_single_and_clear_model(ctx):
     assert [ctx.decrypt(o) for o in out] == [(x * y) & m64 for x, y in zip(xs[:8], ys[:8])]
     assert ctx.decrypt(ctx.evaluate("mul", 64, A[0], 12345)) == (xs[0] * 12345) & m64
     assert ctx.decrypt(ctx.evaluate("add", 64, ctx.evaluate("mul", 64, A[1], 1), B[1])) == (xs[1] + ys[1]) & m64
+    # and / or / xor with a clear operand shared by the batch: no bootstrap where its digit is 0 or 3
+    for op, f in (("and", lambda a, c: a & c), ("or", lambda a, c: a | c), ("xor", lambda a, c: a ^ c)):
+        for c in (0xFFFFFFFF, 0x5A5A5A5A12345678, m64):
+            out = ctx.evaluate_batch(op, 64, A[:6], [c] * 6)
+            assert [ctx.decrypt(o) for o in out] == [f(x, c) for x in xs[:6]], (op, c)
+        out = ctx.evaluate_batch(op, 64, A[:6], ys[:6])          # operands that differ: the general schedule
+        assert [ctx.decrypt(o) for o in out] == [f(x, y) for x, y in zip(xs[:6], ys[:6])], op
+    n0 = ctx.pbs_count()
+    masked = ctx.evaluate("and", 64, A[2], 0xFFFF)
+    assert ctx.pbs_count() == n0 and ctx.decrypt(masked) == xs[2] & 0xFFFF
+    assert ctx.decrypt(ctx.evaluate("add", 64, masked, B[2])) == ((xs[2] & 0xFFFF) + ys[2]) & m64
     # clear amounts and divisors that differ between instances: grouped into specialised runs
     amounts = [(3 * i) % 5 + 60 * (i % 2) for i in range(n)]
     out = ctx.evaluate_batch("rotl", 64, A, amounts)

@@ -237,6 +237,32 @@ def test_product_with_a_clear_factor():
     assert radix.run_plain(q, 0xFEDCBA9876543210) == (5 * 0xFEDCBA9876543210) & ((1 << 64) - 1)
 
 
+def test_bitwise_operators_with_a_clear_operand():
+    """and / or / xor specialised on a clear operand: a table of the block alone, no bootstrap where
+    the operand's digit is 0 or 3 (a byte mask costs none) -- reference vectors with a clear right
+    operand, masks and random operands at every width, ebool included."""
+    done = 0
+    for k in KATS:
+        op, w, ins, exp = radix.kat_case(k)
+        if op in ("and", "or", "xor") and not k["types"][1].startswith("e"):
+            assert radix.run_plain(prog(op, w, scalar=ins[1]), ins[0]) == exp, k
+            done += 1
+    assert done >= 30
+    rnd = random.Random(23)
+    for w in (1, 8, 16, 64, 256):
+        m = (1 << w) - 1
+        for c in [0, m, 1, m >> 1, 0xFF & m, 0xAA & m, 0x55 & m] + [rnd.randrange(m + 1) for _ in range(4)]:
+            for op, f in (("and", lambda a, c: a & c), ("or", lambda a, c: a | c), ("xor", lambda a, c: a ^ c)):
+                p = prog(op, w, scalar=c)
+                assert not p["rhs"]
+                for a in [0, m] + [rnd.randrange(m + 1) for _ in range(4)]:
+                    assert radix.run_plain(p, a) == f(a, c), (op, w, a, c)
+    assert prog("and", 64, scalar=0xFFFFFFFF)["pbs"] == 0 and prog("xor", 64, scalar=(1 << 64) - 1)["pbs"] == 0
+    assert prog("or", 64, scalar=0x5555555555555555)["pbs"] == 32
+    q = prog("and", 64, 2, scalar=0x0F0F)      # a noise-2 input passes through where it is kept
+    assert radix.run_plain(q, 0xFEDCBA9876543210) == 0xFEDCBA9876543210 & 0x0F0F
+
+
 def test_schedule_sizes_are_reported():
     """Bootstraps per operation (the scheduler's own count; the reference publishes none)."""
     want_at_most = {("add", 64): (150, 4), ("sub", 64): (150, 4), ("mul", 64): (1900, 9), ("lt", 64): (45, 4),
