@@ -150,7 +150,9 @@ def make_compact_public_key(pke_sk, seed: bytes, noise_log2: int = 17):
 # words.  The readers below therefore find the ciphertext words the same way the key readers find
 # the keys -- by walking the blob for length-prefixed runs of the right length whose content looks
 # like ciphertext words -- and ignore the framing around them.  Nothing here writes tfhe-rs
-# ciphertext blobs: a writer with guessed version tags would produce files tfhe-rs refuses.
+# ciphertext blobs: a writer with guessed version tags would produce files tfhe-rs refuses.  The way
+# out of this library into tfhe-rs objects is radix_ciphertext_raw_parts: the words and metadata
+# that tfhe-rs' own raw-parts constructors take.
 _LWE_WORDS = 2049
 
 
@@ -195,6 +197,25 @@ def parse_radix_ciphertext(blob: bytes, bit_width: int | None = None) -> bytes:
     for _, v in vecs:
         out += v.astype("<u8").tobytes()
     return bytes(out)
+
+
+def radix_ciphertext_raw_parts(ct: bytes) -> dict:
+    """This library's ciphertext blob taken apart into what tfhe-rs' raw-parts constructors take
+    (`LweCiphertext::from_container(words, CiphertextModulus::new_native())`,
+    `shortint::Ciphertext::new(lwe, Degree::new(degree), NoiseLevel, MessageModulus(4), CarryModulus(4), ..)`,
+    `RadixCiphertext::from(blocks)`): the route from a result of this library into tfhe-rs objects
+    that does not depend on the version tags of tfhe-rs' serialized ciphertext types, which no
+    fixture in the reference pins.  Blocks are little-endian in significance, 2049 words each (mask
+    of 2048 under the GLWE secret key, body last), native modulus 2^64, KeyswitchBootstrap order."""
+    if len(ct) < 16:
+        raise ValueError("short ciphertext blob")
+    magic, version, width, nb, noise, degree, _ = struct.unpack("<IHHIBBH", ct[:16])
+    if magic != 0x5443464C or version != 1 or len(ct) != 16 + nb * _LWE_WORDS * 8:
+        raise ValueError("not a ciphertext blob of this library")
+    words = np.frombuffer(ct, dtype="<u8", offset=16).reshape(nb, _LWE_WORDS)
+    return {"bit_width": width, "blocks": [w.copy() for w in words], "degree": degree, "noise_level": noise,
+            "message_modulus": 4, "carry_modulus": 4,     # an ebool is a block of the same space holding 0 or 1
+            "ciphertext_modulus_log2": 64, "lwe_dimension": _LWE_WORDS - 1, "pbs_order": "KeyswitchBootstrap"}
 
 
 def build_compact_list(pk_mask, pk_body, values: list, widths: list, seed: bytes, packed: bool = True,

@@ -263,3 +263,26 @@ def test_compact_input_list_is_expanded_cast_and_computed_on(packed):
             ctx.expand_compact_list(c0, bodies[:-1], widths, packed=packed)       # length does not match the types
     finally:
         ctx.close()
+
+
+def test_ciphertext_blob_as_raw_parts_for_tfhers_constructors():
+    """The blocks and metadata tfhe-rs' raw-parts constructors take, from a blob of this library;
+    the same blocks wrapped as length-prefixed word vectors (how bincode writes them inside a
+    tfhe-rs container) are found again by the container reader."""
+    import struct
+    import numpy as np
+    from fhe_amd import tfhers_wire as tw
+    rng = np.random.default_rng(5)
+    words = rng.integers(0, 1 << 64, size=(4, 2049), dtype=np.uint64)
+    blob = struct.pack("<IHHIBBH", 0x5443464C, 1, 8, 4, 2, 3, 0) + words.astype("<u8").tobytes()
+    parts = tw.radix_ciphertext_raw_parts(blob)
+    assert parts["bit_width"] == 8 and parts["degree"] == 3 and parts["noise_level"] == 2
+    assert parts["message_modulus"] == parts["carry_modulus"] == 4 and parts["lwe_dimension"] == 2048
+    assert all(np.array_equal(b, w) for b, w in zip(parts["blocks"], words))
+    container = b"\x07" * 40 + b"".join(struct.pack("<Q", 2049) + b.astype("<u8").tobytes() + b"\x00" * 60
+                                         for b in parts["blocks"])
+    back = tw.parse_radix_ciphertext(container, 8)
+    assert back[16:] == blob[16:]
+    import pytest
+    with pytest.raises(ValueError):
+        tw.radix_ciphertext_raw_parts(blob[:-8])
