@@ -263,7 +263,6 @@ private:
 // = the sum reaches 2), so q in [F, F + w) never need a resolved carry of their own.  Two prefix
 // levels serve 32 blocks, three serve 128, and none of them waits for the others to finish: blocks
 // whose sums arrive early (the low columns of a product) resolve early.
-namespace {
 // prefix levels still needed when q < F are resolved and states span w; bit: the carry into F can be
 // handed out as a bit.  *R: the number of groups to resolve at this level.
 int prefix_levels(size_t F, size_t w, bool bit, size_t nq, int* R) {
@@ -277,7 +276,6 @@ int prefix_levels(size_t F, size_t w, bool bit, size_t nq, int* R) {
     }
     return best;
 }
-}  // namespace
 
 Blocks propagate(Builder& B, const std::vector<Expr>& v) {
     const size_t m = v.size();
