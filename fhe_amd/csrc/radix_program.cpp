@@ -547,14 +547,20 @@ Blocks op_shift_encrypted(Builder& B, uint32_t op, const Blocks& x0, const Block
     int log2w = 0;
     while ((1L << log2w) < W) ++log2w;
     if ((1L << log2w) != W) throw std::invalid_argument("operator not supported");  // width not a power of two
-    const Blocks amount = clean(B, amount0);
     const int ndigits = (log2w + 1) / 2;
     Blocks x = x0;
     for (int j = 0; j < ndigits; ++j) {
-        x = clean(B, x);
         const long unit = 1L << (2 * j);
         const int vmask = (j == ndigits - 1 && (log2w & 1)) ? 1 : 3;
-        const uint32_t s = amount[j];
+        // A stage looks up 4 s + x[u] (s: this stage's digit of the amount).  Its outputs are sums of up
+        // to four bootstrap outputs (noise level up to 4), so the next stage cannot scale anything by
+        // four: it takes 4 s ready-made from a table of the amount block (noise level 1; these tables
+        // run beside the first stage and cost no layer) and adds x[u] as it is.  The first stage scales
+        // the amount block itself when both operands are fresh.
+        int xnoise = 0;
+        for (uint32_t blk : x) xnoise = std::max(xnoise, B.noise(blk));
+        const bool direct = j == 0 && B.hi(amount0[j]) <= 3 && 4 * B.noise(amount0[j]) + xnoise <= MAX_NOISE;
+        const Expr s4 = direct ? Builder::scale(B.E(amount0[j]), 4) : B.E(B.pbs(B.E(amount0[j]), [](int v) { return 4 * lo2(v); }));
         Blocks nx;
         for (long i = 0; i < m; ++i) {
             std::vector<long> srcs;
@@ -565,7 +571,7 @@ Blocks op_shift_encrypted(Builder& B, uint32_t op, const Blocks& x0, const Block
                 }
             Expr sum;
             for (long u : srcs)
-                sum = Builder::add(sum, B.E(B.pbs(pack(B, s, x[u]), [=](int in) {
+                sum = Builder::add(sum, B.E(B.pbs(Builder::add(s4, B.E(x[u])), [=](int in) {
                     return shifted_part(op, W, i, u, (hi2(in) & vmask) * unit, lo2(in));
                 })));
             nx.push_back(B.mat(sum, 3));
