@@ -357,37 +357,118 @@ Blocks op_bitwise(Builder& B, const Blocks& a0, const Blocks& b0, uint32_t op) {
     return r;
 }
 
-// column sums of a schoolbook product: groups of up to five blocks are replaced by their digit (same
-// column) and carry (next column) until every column holds at most two blocks; columns beyond the
-// last are dropped (arithmetic modulo 4^columns)
-std::vector<Expr> reduce_columns(Builder& B, std::vector<Blocks> cols) {
-    const size_t m = cols.size();
-    for (;;) {
-        size_t longest = 0;
-        for (const auto& c : cols) longest = std::max(longest, c.size());
-        if (longest <= 2) break;
-        std::vector<Blocks> nx(m);
+// Column sums of a schoolbook product.  A group of up to five blocks of one column (sum at most 15)
+// is replaced by its digit (same column) and its carry (next column): g blocks become one here and
+// one there.  The heights come down in rounds to the targets 2 < 5 < 11 < 26 < 65 < ... (a column of
+// height T + 3 floor(T / 2) can be brought to T when its neighbour sends it floor(T / 2) carries),
+// as in Dadda's reduction: a round looks at the columns from the least significant one up, counts
+// the carries the column below sends in this very round, and forms only the groups the target asks
+// for.  Counting them in the same round is what keeps a column of two blocks that receives a carry
+// from pushing the problem one column up per round.  At the end every column holds at most two
+// blocks; columns beyond the last are dropped (arithmetic modulo 4^columns).
+// (the digits of the sum: the reduction and one carry propagation)
+Blocks sum_columns(Builder& B, const std::vector<Blocks>& cols0) {
+    const size_t m = cols0.size();
+    // one round on heights alone: the sizes of the groups each column forms
+    auto plan_round = [m](std::vector<size_t>& h, size_t target, std::vector<std::vector<size_t>>& groups) {
+        std::vector<size_t> nh(m, 0);
+        groups.assign(m, {});
         for (size_t c = 0; c < m; ++c) {
-            const Blocks& t = cols[c];
-            if (t.size() <= 2) { nx[c].insert(nx[c].end(), t.begin(), t.end()); continue; }
-            for (size_t k = 0; k < t.size(); k += 5) {
-                const size_t g = std::min<size_t>(5, t.size() - k);
-                if (g == 1) { nx[c].push_back(t[k]); continue; }
-                Expr s;
-                for (size_t u = 0; u < g; ++u) s = Builder::add(s, B.E(t[k + u]));
-                nx[c].push_back(B.pbs(s, lo2));
-                if (c + 1 < m) nx[c + 1].push_back(B.pbs(s, hi2));
+            const size_t own = h[c], tall = own + nh[c];   // nh[c] holds the carries of column c - 1 by now
+            size_t need = tall > target ? tall - target : 0, used = 0;
+            while (need > 0 && own - used >= 2) {
+                const size_t g = std::min<size_t>({5, own - used, need + 1});
+                groups[c].push_back(g);
+                used += g;
+                need -= g - 1;
+                nh[c] += 1;
+                if (c + 1 < m) nh[c + 1] += 1;
             }
+            nh[c] += own - used;
         }
-        cols.swap(nx);
-    }
-    std::vector<Expr> v;
-    for (size_t c = 0; c < m; ++c) {
+        h.swap(nh);
+    };
+    auto tallest = [](const std::vector<size_t>& h) { return h.empty() ? (size_t)0 : *std::max_element(h.begin(), h.end()); };
+    auto group = [m](Builder& T, const std::vector<Blocks>& cols, std::vector<Blocks>& nx, size_t c, size_t k, size_t g) {
         Expr s;
-        for (uint32_t blk : cols[c]) s = Builder::add(s, B.E(blk));
-        v.push_back(s);
+        for (size_t u = 0; u < g; ++u) s = Builder::add(s, T.E(cols[c][k + u]));
+        nx[c].push_back(T.pbs(s, lo2));
+        if (c + 1 < m) nx[c + 1].push_back(T.pbs(s, hi2));
+    };
+    // the whole reduction under one list of targets
+    auto reduce_with = [&](Builder& T, const std::vector<size_t>& targets, std::vector<Blocks>& cols) {
+        std::vector<size_t> h(m);
+        for (size_t c = 0; c < m; ++c) h[c] = cols[c].size();
+        size_t ti = 0;
+        for (size_t rounds = 0; tallest(h) > 2; ++rounds) {
+            if (rounds > 4 * m + 16) return false;
+            while (ti + 1 < targets.size() && tallest(h) <= targets[ti]) ++ti;
+            std::vector<std::vector<size_t>> groups;
+            plan_round(h, tallest(h) > targets[ti] ? targets[ti] : 2, groups);
+            std::vector<Blocks> nx(m);
+            for (size_t c = 0; c < m; ++c) {
+                size_t k = 0;
+                for (size_t g : groups[c]) { group(T, cols, nx, c, k, g); k += g; }
+                nx[c].insert(nx[c].end(), cols[c].begin() + (long)k, cols[c].end());
+            }
+            cols.swap(nx);
+        }
+        return true;
+    };
+    // every column of more than two blocks grouped whole, five at a time, round after round (carries
+    // of a round are not counted in that round: columns of two that receive one ripple)
+    auto reduce_whole = [&](Builder& T, std::vector<Blocks>& cols) {
+        for (size_t rounds = 0;; ++rounds) {
+            size_t longest = 0;
+            for (const auto& c : cols) longest = std::max(longest, c.size());
+            if (longest <= 2) return true;
+            if (rounds > 4 * m + 16) return false;
+            std::vector<Blocks> nx(m);
+            for (size_t c = 0; c < m; ++c) {
+                const Blocks& t = cols[c];
+                if (t.size() <= 2) { nx[c].insert(nx[c].end(), t.begin(), t.end()); continue; }
+                for (size_t k = 0; k < t.size(); k += 5) {
+                    const size_t g = std::min<size_t>(5, t.size() - k);
+                    if (g == 1) nx[c].push_back(t[k]);
+                    else group(T, cols, nx, c, k, g);
+                }
+            }
+            cols.swap(nx);
+        }
+    };
+    // The targets that fit uniform columns are not always the best for a triangle of columns whose
+    // low end is ready early, and what counts is the depth after the carry propagation: every tail
+    // of the sequence (down to "as far as possible in every round") and the whole-column grouping are
+    // built on copies of the builder, carry propagation included; the shallowest result wins, then
+    // the one with the fewest bootstraps.
+    size_t top = 0;
+    for (const auto& c : cols0) top = std::max(top, c.size());
+    std::vector<size_t> seq{2};
+    while (seq.back() < top) seq.push_back(seq.back() + 3 * (seq.back() / 2));
+    bool have = false;
+    Builder best_builder;
+    Blocks best;
+    std::array<uint64_t, 2> best_cost{};
+    for (size_t len = 0; len <= seq.size(); ++len) {
+        Builder trial = B;
+        std::vector<Blocks> cols = cols0;
+        if (len == 0 ? !reduce_whole(trial, cols)
+                     : !reduce_with(trial, std::vector<size_t>(seq.rend() - (long)len, seq.rend()), cols)) continue;
+        std::vector<Expr> v;
+        for (size_t c = 0; c < m; ++c) {
+            Expr e;
+            for (uint32_t blk : cols[c]) e = Builder::add(e, trial.E(blk));
+            v.push_back(e);
+        }
+        Blocks r = propagate(trial, v);
+        uint64_t deepest = 0;
+        for (uint32_t blk : r) deepest = std::max<uint64_t>(deepest, (uint64_t)trial.level(blk));
+        const std::array<uint64_t, 2> cost{deepest, trial.P.pbs_per_instance()};
+        if (!have || cost < best_cost) { have = true; best_cost = cost; best_builder = std::move(trial); best = std::move(r); }
     }
-    return v;
+    if (!have) throw std::logic_error("column reduction did not converge");
+    B = std::move(best_builder);
+    return best;
 }
 
 // schoolbook product: low and high digit of every block pair, column sums of up to five terms
@@ -402,7 +483,7 @@ Blocks op_mul(Builder& B, const Blocks& a0, const Blocks& b0) {
             cols[i + j].push_back(B.pbs(in, [](int x) { return (hi2(x) * lo2(x)) & 3; }));
             if (i + j + 1 < m) cols[i + j + 1].push_back(B.pbs(in, [](int x) { return (hi2(x) * lo2(x)) >> 2; }));
         }
-    return propagate(B, reduce_columns(B, cols));
+    return sum_columns(B, cols);
 }
 
 // equality: per-block equality bits, AND-reduced five at a time
@@ -651,7 +732,7 @@ Blocks op_mul_clear(Builder& B, const Blocks& a, const Nat& c, size_t columns, c
         for (const auto& col : cols) r.push_back(col.empty() ? B.mat(Builder::C(0)) : col[0]);
         return r;
     }
-    return propagate(B, reduce_columns(B, cols));
+    return sum_columns(B, cols);
 }
 
 // Division of a W-bit integer by a clear d that is not a power of two, by multiplication with a

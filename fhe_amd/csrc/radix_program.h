@@ -101,6 +101,7 @@ public:
     uint32_t mat(const Expr& e, int hi_known = -1, int lo_known = -1, int limit = BLOCK_MAX);
     int hi(uint32_t b) const { return info_[b].hi; }
     int noise(uint32_t b) const { return info_[b].noise; }
+    int level(uint32_t b) const { return info_[b].level; }   // the layer whose bootstraps may read the block
     void finish();
 
 private:
