@@ -366,8 +366,10 @@ Blocks op_bitwise(Builder& B, const Blocks& a0, const Blocks& b0, uint32_t op) {
 // for.  Counting them in the same round is what keeps a column of two blocks that receives a carry
 // from pushing the problem one column up per round.  At the end every column holds at most two
 // blocks; columns beyond the last are dropped (arithmetic modulo 4^columns).
-// (the digits of the sum: the reduction and one carry propagation)
-Blocks sum_columns(Builder& B, const std::vector<Blocks>& cols0) {
+// (the digits of the sum: the reduction and one carry propagation; `minuend`, if given, turns the
+// result into minuend - sum: see subtract_columns)
+Blocks subtract_columns(Builder& B, const Blocks& minuend, const std::vector<Blocks>& cols);
+Blocks sum_columns(Builder& B, const std::vector<Blocks>& cols0, const Blocks* minuend = nullptr) {
     const size_t m = cols0.size();
     // one round on heights alone: the sizes of the groups each column forms
     auto plan_round = [m](std::vector<size_t>& h, size_t target, std::vector<std::vector<size_t>>& groups) {
@@ -454,13 +456,18 @@ Blocks sum_columns(Builder& B, const std::vector<Blocks>& cols0) {
         std::vector<Blocks> cols = cols0;
         if (len == 0 ? !reduce_whole(trial, cols)
                      : !reduce_with(trial, std::vector<size_t>(seq.rend() - (long)len, seq.rend()), cols)) continue;
-        std::vector<Expr> v;
-        for (size_t c = 0; c < m; ++c) {
-            Expr e;
-            for (uint32_t blk : cols[c]) e = Builder::add(e, trial.E(blk));
-            v.push_back(e);
+        Blocks r;
+        if (minuend) {
+            r = subtract_columns(trial, *minuend, cols);
+        } else {
+            std::vector<Expr> v;
+            for (size_t c = 0; c < m; ++c) {
+                Expr e;
+                for (uint32_t blk : cols[c]) e = Builder::add(e, trial.E(blk));
+                v.push_back(e);
+            }
+            r = propagate(trial, v);
         }
-        Blocks r = propagate(trial, v);
         uint64_t deepest = 0;
         for (uint32_t blk : r) deepest = std::max<uint64_t>(deepest, (uint64_t)trial.level(blk));
         const std::array<uint64_t, 2> cost{deepest, trial.P.pbs_per_instance()};
@@ -469,6 +476,23 @@ Blocks sum_columns(Builder& B, const std::vector<Blocks>& cols0) {
     if (!have) throw std::logic_error("column reduction did not converge");
     B = std::move(best_builder);
     return best;
+}
+
+// a - P modulo 4^m, where P is given as columns of at most two carry-free blocks (the state a column
+// reduction ends in) and a as carry-free blocks: with t_c the sum of column c (at most 6),
+//   a - P = sum 4^c (a_c + 6 - t_c) - 6 (4^m - 1) / 3 = sum 4^c (a_c + 6 - t_c) + 2   (mod 4^m),
+// so one round of digit + carry over x_c = a_c + 6 - t_c (+ 2 in column 0; at most 11) leaves columns of
+// two blocks again, and ONE carry propagation finishes: P never has to be propagated on its own.
+Blocks subtract_columns(Builder& B, const Blocks& a, const std::vector<Blocks>& cols) {
+    const size_t m = cols.size();
+    std::vector<Expr> v(m);
+    for (size_t c = 0; c < m; ++c) {
+        Expr x = Builder::add(B.E(a[c]), Builder::C(c == 0 ? 8 : 6));
+        for (uint32_t blk : cols[c]) x = Builder::sub(x, B.E(blk));
+        v[c] = Builder::add(v[c], B.E(B.pbs(x, lo2)));
+        if (c + 1 < m) v[c + 1] = Builder::add(v[c + 1], B.E(B.pbs(x, hi2)));
+    }
+    return propagate(B, v);
 }
 
 // schoolbook product: low and high digit of every block pair, column sums of up to five terms
@@ -704,7 +728,7 @@ int nat_digit(const Nat& a, size_t i) { return nat_bit(a, 2 * i) | (nat_bit(a, 2
 // product of the blocks a (carry-free) with a clear natural c, `columns` base-4 digits of it; plus the
 // carry-free blocks `addend`, if given, from column `addend_col` on (they join the column sums)
 Blocks op_mul_clear(Builder& B, const Blocks& a, const Nat& c, size_t columns, const Blocks* addend = nullptr,
-                    size_t addend_col = 0) {
+                    size_t addend_col = 0, const Blocks* minuend = nullptr) {
     const size_t m = a.size();
     std::vector<Blocks> cols(columns);
     for (size_t i = 0; i < m; ++i) {
@@ -725,6 +749,7 @@ Blocks op_mul_clear(Builder& B, const Blocks& a, const Nat& c, size_t columns, c
     if (addend)
         for (size_t i = 0; i < addend->size() && addend_col + i < columns; ++i) cols[addend_col + i].push_back((*addend)[i]);
     // at most one carry-free block per column (c = 0, 1, a power of four): nothing to add up
+    if (minuend) return sum_columns(B, cols, minuend);   // minuend - a c
     bool single = true;
     for (const auto& col : cols) single = single && (col.empty() || (col.size() == 1 && B.hi(col[0]) <= 3));
     if (single) {
@@ -787,7 +812,7 @@ void op_divrem_clear(Builder& B, const Blocks& a0, const Nat& d, Blocks* quot, B
         size_t nz_d = 0, nz_neg = 0;
         for (size_t j = 0; j < m; ++j) { nz_d += nat_digit(d, j) != 0; nz_neg += nat_digit(neg_d, j) != 0; }
         if (nz_neg <= nz_d + 2) *rem = op_mul_clear(B, clean(B, q), neg_d, m, &a, 0);
-        else *rem = op_sub(B, a, op_mul_clear(B, clean(B, q), d, m));
+        else *rem = op_mul_clear(B, clean(B, q), d, m, nullptr, 0, &a);
     }
 }
 
