@@ -103,7 +103,37 @@ uint32_t Builder::pbs(const Expr& e, const std::function<int(int)>& f) {
     return out;
 }
 
+// Operations nothing reads are dropped: an operator may ask for more than its result needs (the low
+// digits of a product whose upper half is the result, the carry states of blocks a shift discards).
+// Block ids stay as they are.
+void Builder::prune() {
+    std::vector<char> live(P.nblocks, 0);
+    for (uint32_t b : P.out) live[b] = 1;
+    for (const auto& o : P.outs)
+        for (uint32_t b : o) live[b] = 1;
+    for (size_t l = P.layers.size(); l-- > 0;) {
+        Layer& L = P.layers[l];
+        std::vector<PbsOp> pbs;
+        for (const PbsOp& q : L.pbs)
+            if (live[q.out]) { pbs.push_back(q); live[q.in] = 1; }
+        L.pbs.swap(pbs);
+        // a linear operation of this layer may read another one of this layer only through the
+        // combination it was flattened to, so one backward pass over the list is enough
+        std::vector<LinOp> lin;
+        for (size_t i = L.lin.size(); i-- > 0;) {
+            const LinOp& q = L.lin[i];
+            if (!live[q.out]) continue;
+            for (uint32_t k = 0; k < q.n; ++k) live[q.src[k]] = 1;
+            lin.push_back(q);
+        }
+        std::reverse(lin.begin(), lin.end());
+        L.lin.swap(lin);
+    }
+    while (!P.layers.empty() && P.layers.back().pbs.empty() && P.layers.back().lin.empty()) P.layers.pop_back();
+}
+
 void Builder::finish() {
+    prune();
     int noise = 0, deg = 0;
     for (uint32_t b : P.out) { noise = std::max(noise, info_[b].noise); deg = std::max(deg, info_[b].hi); }
     P.out_noise = (uint8_t)std::max(noise, 1);
@@ -981,6 +1011,7 @@ Program build_fused(const std::vector<FusedStep>& steps, const std::vector<uint3
         B.P.out_noises.push_back((uint8_t)std::max(noise, 1));
         B.P.out_degrees.push_back((uint8_t)deg);
     }
+    B.prune();
     return B.P;
 }
 

@@ -103,6 +103,7 @@ public:
     int noise(uint32_t b) const { return info_[b].noise; }
     int level(uint32_t b) const { return info_[b].level; }   // the layer whose bootstraps may read the block
     void finish();
+    void prune();   // drops the operations no output depends on
 
 private:
     struct Info { int level, lo, hi, noise; };
