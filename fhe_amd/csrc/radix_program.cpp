@@ -100,7 +100,15 @@ uint32_t Builder::pbs(const Expr& e, const std::function<int(int)>& f) {
     for (int x = i.lo; x <= i.hi; ++x) { lo = std::min(lo, f(x)); hi = std::max(hi, f(x)); }
     const uint32_t out = new_block(i.level + 1, lo, hi, 1);
     layer(i.level).pbs.push_back({in, out, lut_id(f)});
+    made_by_[out] = {in, f};
     return out;
+}
+
+uint32_t Builder::pbs_of(uint32_t b, const std::function<int(int)>& g) {
+    auto it = made_by_.find(b);
+    if (it == made_by_.end()) return pbs(E(b), g);
+    const auto f = it->second.second;
+    return pbs(E(it->second.first), [f, g](int x) { return g(f(x)); });
 }
 
 // Operations nothing reads are dropped: an operator may ask for more than its result needs (the low
@@ -204,6 +212,15 @@ Blocks clean(Builder& B, const Blocks& v) {
     for (uint32_t b : v) r.push_back((B.noise(b) > 1 || B.hi(b) > 3) ? B.pbs(B.E(b), lo2) : b);
     return r;
 }
+
+// only the blocks that hold carries are bootstrapped (for operators that take the difference of two
+// blocks: a - b + 3 costs the sum of the noise levels, nothing is scaled)
+Blocks carry_free(Builder& B, const Blocks& v) {
+    Blocks r;
+    for (uint32_t b : v) r.push_back(B.hi(b) > 3 ? B.pbs(B.E(b), lo2) : b);
+    return r;
+}
+Expr diff3(Builder& B, uint32_t a, uint32_t b) { return Builder::add(Builder::sub(B.E(a), B.E(b)), Builder::C(3)); }
 
 Expr pack(Builder& B, uint32_t hi_blk, uint32_t lo_blk) { return Builder::add(Builder::scale(B.E(hi_blk), 4), B.E(lo_blk)); }
 
@@ -540,14 +557,15 @@ Blocks op_mul(Builder& B, const Blocks& a0, const Blocks& b0) {
     return sum_columns(B, cols);
 }
 
-// equality: per-block equality bits, AND-reduced five at a time
+// equality: per-block equality bits (of the difference of the blocks), AND-reduced five at a time
 uint32_t op_eq(Builder& B, const Blocks& a0, const Blocks& b0, bool negate) {
-    const Blocks a = clean(B, a0), b = clean(B, b0);
+    // per block a table of a - b + 3: operands at noise level 2 (results of a select) need no clean-up
+    const Blocks a = carry_free(B, a0), b = carry_free(B, b0);
     const size_t m = a.size();
     Blocks cur;
     for (size_t i = 0; i < m; ++i)
-        cur.push_back(B.pbs(pack(B, a[i], b[i]), [=](int x) {
-            const int e = hi2(x) == lo2(x);
+        cur.push_back(B.pbs(diff3(B, a[i], b[i]), [=](int x) {
+            const int e = x == 3;
             return (m == 1 && negate) ? 1 - e : e;
         }));
     while (cur.size() > 1) {
@@ -568,10 +586,11 @@ uint32_t op_eq(Builder& B, const Blocks& a0, const Blocks& b0, bool negate) {
     return cur[0];
 }
 
-// order: per-block sign (0 less, 1 equal, 2 greater), most significant non-equal block wins; the
-// signs compose four at a time (States)
+// order: per-block sign (0 less, 1 equal, 2 greater) read off a - b + 3 (no scaling: operands at noise
+// level 2 are taken as they are), most significant non-equal block wins; the signs compose four at
+// a time (States)
 uint32_t op_cmp(Builder& B, const Blocks& a0, const Blocks& b0, uint32_t op) {
-    const Blocks a = clean(B, a0), b = clean(B, b0);
+    const Blocks a = carry_free(B, a0), b = carry_free(B, b0);
     const size_t m = a.size();
     auto verdict = [op](int s) {
         switch (op) {
@@ -584,7 +603,7 @@ uint32_t op_cmp(Builder& B, const Blocks& a0, const Blocks& b0, uint32_t op) {
     States S(B);
     std::vector<int> cur;  // most significant first
     for (size_t i = m; i-- > 0;)
-        cur.push_back(S.leaf(pack(B, a[i], b[i]), [](int x) { return hi2(x) > lo2(x) ? 2 : (hi2(x) < lo2(x) ? 0 : 1); }));
+        cur.push_back(S.leaf(diff3(B, a[i], b[i]), [](int x) { return x > 3 ? 2 : (x < 3 ? 0 : 1); }));   // sign of a - b
     // four at a time (wrapped nodes) or three; the last node must not be wrapped (its verdict is a
     // table of the state itself), so the last round composes at most three
     std::function<int(size_t)> rounds = [&](size_t n) -> int {
@@ -610,9 +629,26 @@ uint32_t op_cmp(Builder& B, const Blocks& a0, const Blocks& b0, uint32_t op) {
 // costs exactly the noise budget (2 + 2 + 1); the table returns a - b + 3 when the low bit is set
 // and 3 otherwise, and b + table - 3 is the selected digit.
 Blocks op_select(Builder& B, uint32_t c0, const Blocks& a0, const Blocks& b0) {
-    const uint32_t c = clean(B, {c0})[0];
-    const Blocks a = clean(B, a0), b = clean(B, b0);
+    bool fresh = true;
+    for (uint32_t blk : a0) fresh = fresh && B.noise(blk) <= 1 && B.hi(blk) <= 3;
+    for (uint32_t blk : b0) fresh = fresh && B.noise(blk) <= 1 && B.hi(blk) <= 3;
     Blocks r;
+    if (!fresh) {
+        // Operands above noise level 1 (results of an earlier select) cannot be scaled by two.  Two
+        // bootstraps per block instead of a clean-up of both operands and one: the condition comes
+        // ready-scaled as 4 c from the table that made it (or from a table of its block), a + 4 c is looked up through "a if c else
+        // 0", b + 4 c through "0 if c else b", and the sum of the two is the selected digit.
+        const Blocks a = carry_free(B, a0), b = carry_free(B, b0);
+        const Expr c4 = B.E(B.pbs_of(c0, [](int x) { return 4 * (x & 1); }));
+        for (size_t i = 0; i < a.size(); ++i) {
+            const uint32_t u = B.pbs(Builder::add(B.E(a[i]), c4), [](int x) { return (x & 4) ? (x & 3) : 0; });
+            const uint32_t w = B.pbs(Builder::add(B.E(b[i]), c4), [](int x) { return (x & 4) ? 0 : (x & 3); });
+            r.push_back(B.mat(Builder::add(B.E(u), B.E(w)), std::max(B.hi(a[i]), B.hi(b[i])), 0));
+        }
+        return r;
+    }
+    const uint32_t c = clean(B, {c0})[0];
+    const Blocks &a = a0, &b = b0;
     for (size_t i = 0; i < a.size(); ++i) {
         Expr in = Builder::add(Builder::scale(Builder::sub(B.E(a[i]), B.E(b[i])), 2), Builder::add(B.E(c), Builder::C(6)));
         const uint32_t t = B.pbs(in, [](int x) { return (x & 1) ? (x >> 1) : 3; });

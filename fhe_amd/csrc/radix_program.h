@@ -93,6 +93,9 @@ public:
 
     // bootstrap of e through the table f : [0,16) -> [0,16)
     uint32_t pbs(const Expr& e, const std::function<int(int)>& f);
+    // g of the value of block b in one bootstrap: when b is itself the output of a bootstrap, a second
+    // bootstrap of that one's input through g o f (same layer as b, no layer added); else of b
+    uint32_t pbs_of(uint32_t b, const std::function<int(int)>& g);
     // bootstrap of an input in [0,32) through f : [0,16) -> (-16,16), continued as f(x + 16) = -f(x)
     uint32_t pbs_wrapped(const Expr& e, const std::function<int(int)>& f);
     // e as a block (a linear op unless e already is a plain block); hi_known / lo_known >= 0
@@ -110,6 +113,7 @@ private:
     std::vector<Info> info_;
     std::map<std::pair<std::array<uint64_t, 16>, bool>, uint32_t> lut_ids_;
     std::map<uint32_t, Expr> lin_expr_;  // blocks defined by a linear operation
+    std::map<uint32_t, std::pair<uint32_t, std::function<int(int)>>> made_by_;  // bootstrap outputs: input block, table
     uint32_t new_block(int level, int lo, int hi, int noise) {
         info_.push_back({level, lo, hi, noise});
         return P.nblocks++;

@@ -263,6 +263,37 @@ def test_bitwise_operators_with_a_clear_operand():
     assert radix.run_plain(q, 0xFEDCBA9876543210) == 0xFEDCBA9876543210 & 0x0F0F
 
 
+def test_operands_at_noise_level_two_need_no_clean_up_for_comparisons_and_selects():
+    """Results of a select leave at noise level 2.  Comparisons and equality read a - b + 3 (nothing is
+    scaled), a select takes two bootstraps per block with the condition ready-scaled from the table
+    that made it: the round of an argmax tournament on such operands costs 71 bootstraps, not 126."""
+    from fhe_amd.native import fused_program
+    rnd = random.Random(31)
+    for w in (8, 64):
+        m = (1 << w) - 1
+        vals = [(0, 0), (m, m), (m, 0), (5, 6)] + [(rnd.randrange(m + 1), rnd.randrange(m + 1)) for _ in range(20)]
+        for op in ("lt", "le", "gt", "ge", "eq", "ne", "min", "max"):
+            p = prog(op, w, 2, 2)
+            assert p["pbs"] <= prog(op, w)["pbs"] + w // 2 + 2, op          # no clean-up of 2 x w/2 blocks
+            for a, b in vals:
+                assert radix.run_plain(p, a, b) == radix.clear_op(op, w, a, b), (op, w, a, b)
+        p = prog("select", w, 2, 2, 2)
+        assert p["out_noise"] == 2 and p["pbs"] == 2 * (w // 2) + 1
+        for a, b in vals:
+            for c in (0, 1):
+                assert radix.run_plain(p, a, b, c) == (a if c else b), (w, a, b, c)
+    steps = [("gt", 32, 0, 1, None), ("select", 32, 0, 1, 4), ("select", 16, 2, 3, 4)]
+    fresh = fused_program(steps, [32, 32, 16, 16], [5, 6])
+    later = fused_program(steps, [32, 32, 16, 16], [5, 6], [2, 2, 2, 2])
+    assert fresh["pbs"] == 46 and later["pbs"] <= 72 and len(later["layers"]) <= len(fresh["layers"])
+    for _ in range(30):
+        a, b = rnd.randrange(1 << 32), rnd.randrange(1 << 32)
+        ia, ib = rnd.randrange(1 << 16), rnd.randrange(1 << 16)
+        want = [a, ia] if a > b else [b, ib]
+        assert radix.run_plain_fused(fresh, [a, b, ia, ib]) == want
+        assert radix.run_plain_fused(later, [a, b, ia, ib]) == want
+
+
 def test_schedule_sizes_are_reported():
     """Bootstraps per operation (the scheduler's own count; the reference publishes none)."""
     want_at_most = {("add", 64): (150, 4), ("sub", 64): (150, 4), ("mul", 64): (1900, 9), ("lt", 64): (45, 4),
