@@ -56,6 +56,18 @@ def main():
             got = [ctx.decrypt(o) for o in out]
             wrong += sum(g != (x if c else y) for g, x, y, c in zip(got, xs, ys, conds))
             done += batch
+            # operands at noise level 2 (results of a select) into the operators that take them as they are
+            sel = ctx.evaluate_batch("select", w, A, B, Cn)
+            sv = [x if c else y for x, y, c in zip(xs, ys, conds)]
+            for op in ("lt", "ge", "eq", "min", "max", "add", "sub"):
+                out = ctx.evaluate_batch(op, w, sel, B)
+                got = [ctx.decrypt(o) for o in out]
+                wrong += sum(g != radix.clear_op(op, w, v, y) for g, v, y in zip(got, sv, ys))
+                done += batch
+            out = ctx.evaluate_batch("select", w, sel, ctx.evaluate_batch("select", w, B, A, Cn), Cn)
+            got = [ctx.decrypt(o) for o in out]
+            wrong += sum(g != v for g, v in zip(got, sv))      # c ? (c ? a : b) : (c ? b : a) = c ? a : b
+            done += batch
         print(f"round {it + 1} of {rounds}: {done} evaluations, {wrong} wrong", file=sys.stderr, flush=True)
     print(json.dumps({"params_id": pid, "evaluations": done, "wrong": wrong, "bootstraps": ctx.pbs_count() - p0,
                       "seconds": round(time.time() - t0, 1)}), flush=True)
