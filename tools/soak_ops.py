@@ -66,7 +66,7 @@ def main():
                 done += batch
             out = ctx.evaluate_batch("select", w, sel, ctx.evaluate_batch("select", w, B, A, Cn), Cn)
             got = [ctx.decrypt(o) for o in out]
-            wrong += sum(g != v for g, v in zip(got, sv))      # c ? (c ? a : b) : (c ? b : a) = c ? a : b
+            wrong += sum(g != x for g, x in zip(got, xs))      # c ? (c ? a : b) : (c ? b : a) = a
             done += batch
         print(f"round {it + 1} of {rounds}: {done} evaluations, {wrong} wrong", file=sys.stderr, flush=True)
     print(json.dumps({"params_id": pid, "evaluations": done, "wrong": wrong, "bootstraps": ctx.pbs_count() - p0,
