@@ -10,7 +10,10 @@
 //
 // The builder tracks, for every block, the range of values it can hold and its noise level in
 // units of one bootstrap output (the parameter set allows 5), and refuses to build a program that
-// would overflow the 4-bit block or exceed the noise budget.
+// would overflow the 4-bit block or exceed the noise budget.  A few bootstraps take sums that run
+// into the padding bit on purpose (inputs up to 31, tables flagged in lut_wraps: pbs_wrapped); the
+// block a consumer sees is back in [0,16) after the constant of its linear combination.
+// Finished programs are pruned of operations no output depends on.
 #pragma once
 #include <stdint.h>
 
