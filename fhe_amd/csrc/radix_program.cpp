@@ -92,16 +92,6 @@ uint32_t Builder::pbs_wrapped(const Expr& e, const std::function<int(int)>& f) {
 }
 
 uint32_t Builder::pbs(const Expr& e, const std::function<int(int)>& f) {
-    // a table of a block that is itself the plain output of a bootstrap is a table of that bootstrap's
-    // input: one bootstrap, one layer earlier (the first one is pruned if nothing else reads it)
-    if (e.t.size() == 1 && e.t[0].first == 1 && e.cst == 0) {
-        auto it = made_by_.find(e.t[0].second);
-        if (it != made_by_.end()) {
-            const uint32_t in = it->second.first;
-            const auto f0 = it->second.second;
-            return pbs(E(in), [f0, f](int x) { return f(f0(x)); });
-        }
-    }
     const Info i = eval(e);
     if (i.lo < 0 || i.hi > BLOCK_MAX) throw std::logic_error("bootstrap input range overflows the carry space");
     if (i.noise > MAX_NOISE) throw std::logic_error("bootstrap input noise above the parameter set's budget");
@@ -114,7 +104,17 @@ uint32_t Builder::pbs(const Expr& e, const std::function<int(int)>& f) {
     return out;
 }
 
-uint32_t Builder::pbs_of(uint32_t b, const std::function<int(int)>& g) { return pbs(E(b), g); }
+// A table of a block that is itself the plain output of a bootstrap is a table of that bootstrap's
+// input: one bootstrap, one layer earlier (the first one is pruned if nothing else reads it).  Not
+// done behind the caller's back in pbs(): moving a bootstrap one layer up can push a layer over the
+// number of ciphertexts the GPU holds at once (1024), which costs more than the layer saved.
+uint32_t Builder::pbs_of(uint32_t b, const std::function<int(int)>& g) {
+    auto it = made_by_.find(b);
+    if (it == made_by_.end()) return pbs(E(b), g);
+    const uint32_t in = it->second.first;
+    const auto f = it->second.second;
+    return pbs(E(in), [f, g](int x) { return g(f(x)); });
+}
 
 // Operations nothing reads are dropped: an operator may ask for more than its result needs (the low
 // digits of a product whose upper half is the result, the carry states of blocks a shift discards).
@@ -809,8 +809,8 @@ Blocks op_mul_clear(Builder& B, const Blocks& a, const Nat& c, size_t columns, c
             const int d = nat_digit(c, j);
             if (!d) continue;
             if (!have[d]) {
-                lo[d] = B.pbs(B.E(a[i]), [d](int x) { return ((x & 3) * d) & 3; });
-                hi[d] = B.pbs(B.E(a[i]), [d](int x) { return ((x & 3) * d) >> 2; });
+                lo[d] = B.pbs_of(a[i], [d](int x) { return ((x & 3) * d) & 3; });
+                hi[d] = B.pbs_of(a[i], [d](int x) { return ((x & 3) * d) >> 2; });
                 have[d] = true;
             }
             cols[i + j].push_back(lo[d]);

@@ -96,8 +96,8 @@ public:
 
     // bootstrap of e through the table f : [0,16) -> [0,16)
     uint32_t pbs(const Expr& e, const std::function<int(int)>& f);
-    // g of the value of block b in one bootstrap (pbs of a plain block: when b is itself the output
-    // of a bootstrap, this is a second bootstrap of that one's input through g o f, in b's own layer)
+    // g of the value of block b in one bootstrap: when b is itself the plain output of a bootstrap, a
+    // second bootstrap of that one's input through g o f (in b's own layer, no layer added); else of b
     uint32_t pbs_of(uint32_t b, const std::function<int(int)>& g);
     // bootstrap of an input in [0,32) through f : [0,16) -> (-16,16), continued as f(x + 16) = -f(x)
     uint32_t pbs_wrapped(const Expr& e, const std::function<int(int)>& f);

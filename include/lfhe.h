@@ -226,7 +226,7 @@ int32_t lfhe_op_from_name(const char* name); /* "add", "sub", "lt", ... ; -1 if 
  * clear amount; division and remainder take a clear divisor (zero is LFHE_ERR_ARG).  Operators
  * with a clear amount or divisor run a schedule specialised on that value, and so does a product
  * with a clear factor (the factor's digits pick the partial products: a 64-bit product costs
- * 200 .. 900 bootstraps instead of 1813, none for 0, 1 and powers of four) and and / or / xor with a
+ * 200 .. 900 bootstraps instead of 1814, none for 0, 1 and powers of four) and and / or / xor with a
  * clear operand (no bootstrap where its digit is 0 or 3); in a batch, when every instance has the
  * same clear operand. */
 int32_t lfhe_evaluate(lfhe_ctx* ctx, uint32_t op, uint32_t bit_width, const uint8_t* lhs, uint64_t lhs_len,
