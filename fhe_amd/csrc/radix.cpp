@@ -75,6 +75,7 @@ struct DevBuf {
 // a Program with its descriptors and tables resident on the device
 struct Compiled {
     Program prog;
+    uint64_t last_use = 0;                 // for the bound on programs specialised on a clear operand
     std::vector<LinOp*> d_lin;            // per layer (null when empty)
     std::vector<u32*> d_in, d_out, d_lut;  // per layer
     u64* d_luts = nullptr;                 // [nluts][N]
@@ -92,6 +93,8 @@ struct Compiled {
 typedef std::array<uint8_t, 32> Scalar;
 struct lfhe_radix {
     std::map<std::tuple<uint32_t, uint32_t, int, int, int, bool, Scalar>, std::unique_ptr<Compiled>> cache;
+    uint64_t clock = 0;          // use counter
+    size_t specialised = 0;      // entries whose key holds a clear operand
     std::map<std::string, std::unique_ptr<Compiled>> fused;   // key: the bytes of the request's shape
 };
 
@@ -155,18 +158,47 @@ bool specialised_op(uint32_t op) {
 bool shared_scalar_op(uint32_t op) { return op == LFHE_OP_MUL || op == LFHE_OP_AND || op == LFHE_OP_OR || op == LFHE_OP_XOR; }
 bool shift_op(uint32_t op) { return op == LFHE_OP_SHL || op == LFHE_OP_SHR || op == LFHE_OP_ROTL || op == LFHE_OP_ROTR; }
 
+size_t program_cache_limit() {
+    static const size_t limit = [] {
+        const char* e = std::getenv("LFHE_PROGRAM_CACHE");
+        const long v = e ? std::atol(e) : 0;
+        return (size_t)(v > 0 ? v : 256);
+    }();
+    return limit;
+}
+
 Compiled& compiled_for(lfhe_ctx* ctx, uint32_t op, uint32_t width, int ln, int rn, int cn, const uint8_t* scalar) {
     if (!ctx->radix) ctx->radix.reset(new lfhe_radix());
     Scalar sc{};
     if (scalar) std::memcpy(sc.data(), scalar, 32);
     auto key = std::make_tuple(op, width, ln, rn, cn, scalar != nullptr, sc);
-    auto it = ctx->radix->cache.find(key);
-    if (it != ctx->radix->cache.end()) return *it->second;
+    lfhe_radix& R = *ctx->radix;
+    auto it = R.cache.find(key);
+    if (it != R.cache.end()) {
+        it->second->last_use = ++R.clock;
+        return *it->second;
+    }
+    // Programs built for a clear operand are kept per value (shift amounts, divisors, factors, masks):
+    // a service that sees ever new values must not grow without bound, so the least recently used
+    // one goes when there are more than program_cache_limit() of them.
+    if (scalar && R.specialised >= program_cache_limit()) {
+        auto oldest = R.cache.end();
+        for (auto e = R.cache.begin(); e != R.cache.end(); ++e)
+            if (std::get<5>(e->first) && (oldest == R.cache.end() || e->second->last_use < oldest->second->last_use)) oldest = e;
+        if (oldest != R.cache.end()) {
+            HC(hipSetDevice(ctx->eng->device()));
+            HC(hipStreamSynchronize(ctx->eng->stream()));   // nothing in flight reads its tables
+            R.cache.erase(oldest);
+            --R.specialised;
+        }
+    }
     std::unique_ptr<Compiled> c(new Compiled());
     c->prog = build_program(op, width, ln, rn, cn, scalar);
     upload_program(ctx, *c);
+    c->last_use = ++R.clock;
     Compiled& ref = *c;
-    ctx->radix->cache[key] = std::move(c);
+    R.cache[key] = std::move(c);
+    if (scalar) ++R.specialised;
     return ref;
 }
 
@@ -339,11 +371,23 @@ void run_fused(lfhe_ctx* ctx, const lfhe_step* steps, uint32_t nsteps, uint32_t 
             std::memcpy(fs[k].scalar, steps[k].scalar, 32);
             if (!width_ok(fs[k].width)) throw std::invalid_argument("unsupported bit width");
         }
+        // fused schedules are kept per request shape (clear operands included): bounded like the
+        // programs specialised on a clear operand, least recently used first
+        lfhe_radix& R = *ctx->radix;
+        if (R.fused.size() >= program_cache_limit()) {
+            auto oldest = R.fused.begin();
+            for (auto e = R.fused.begin(); e != R.fused.end(); ++e)
+                if (e->second->last_use < oldest->second->last_use) oldest = e;
+            HC(hipSetDevice(ctx->eng->device()));
+            HC(hipStreamSynchronize(ctx->eng->stream()));
+            R.fused.erase(oldest);
+        }
         std::unique_ptr<Compiled> c(new Compiled());
         c->prog = build_fused(fs, widths, noises, std::vector<int32_t>(outputs, outputs + n_outputs));
         upload_program(ctx, *c);
-        it = ctx->radix->fused.emplace(key, std::move(c)).first;
+        it = R.fused.emplace(key, std::move(c)).first;
     }
+    it->second->last_use = ++ctx->radix->clock;
     Compiled& C = *it->second;
     const Program& P = C.prog;
     Engine& E = *ctx->eng;

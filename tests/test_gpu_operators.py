@@ -345,3 +345,36 @@ def test_error_paths(ctx):
         ctx.evaluate("div", 8, a8, a8)             # encrypted divisor
     with pytest.raises(LfheError):
         ctx.evaluate("shl", 16, a16, a16)          # the amount must be a euint8
+
+
+def test_programs_built_for_clear_operands_are_bounded_and_evicted():
+    """Programs specialised on a clear operand are kept per value, the least recently used one goes
+    beyond a limit (256; 2 here, in a process of its own because the limit is read once): results
+    stay right while programs are evicted and rebuilt."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys\n"
+        "sys.path.insert(0, os.getcwd())\n"
+        "from fhe_amd.native import Context\n"
+        "ctx = Context(seed=bytes(range(32)), params_id=3)\n"
+        "ctx.keygen()\n"
+        "m = (1 << 32) - 1\n"
+        "a = ctx.encrypt(0xDEADBEEF, 32)\n"
+        "for rep in range(2):\n"
+        "    for c in (3, 5, 7, 11, 13):\n"
+        "        assert ctx.decrypt(ctx.evaluate('mul', 32, a, c)) == (0xDEADBEEF * c) & m, c\n"
+        "        assert ctx.decrypt(ctx.evaluate('shl', 32, a, c)) == (0xDEADBEEF << c) & m, c\n"
+        "        assert ctx.decrypt(ctx.evaluate('and', 32, a, c * 0x01010101)) == 0xDEADBEEF & (c * 0x01010101), c\n"
+        "for rep in range(2):\n"
+        "    for c in (3, 5, 7):\n"
+        "        out = ctx.evaluate_fused([('mul', 32, 0, ('clear', c), None), ('add', 32, 1, 0, None)], [32], [[a]], [2], [32])\n"
+        "        assert ctx.decrypt(out[0][0]) == (0xDEADBEEF * (c + 1)) & m, c\n"
+        "outs = ctx.evaluate_batch('rem', 32, [a] * 6, [3, 5, 7, 11, 13, 3])\n"
+        "assert [ctx.decrypt(o) for o in outs] == [0xDEADBEEF % d for d in (3, 5, 7, 11, 13, 3)]\n"
+        "ctx.close()\n"
+        "print('evictions ok')\n")
+    env = dict(os.environ, LFHE_PROGRAM_CACHE="2")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "evictions ok" in r.stdout, r.stdout + r.stderr
