@@ -1,6 +1,8 @@
 #include "radix_program.h"
 
 #include <algorithm>
+#include <climits>
+#include <cstdlib>
 #include <functional>
 #include <sstream>
 
@@ -145,8 +147,192 @@ void Builder::prune() {
     while (!P.layers.empty() && P.layers.back().pbs.empty() && P.layers.back().lin.empty()) P.layers.pop_back();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Layer balancing.  The builder places every bootstrap in the earliest layer its inputs allow.  For
+// ONE instance of an operator a layer costs by the number of ciphertexts the fullest compute unit
+// gets: up to `cap` (one per unit) a layer costs the same whatever it holds, and the cost rises in
+// steps at every further multiple.  Many bootstraps of a large early layer are not needed by the
+// next layer at all (the partial products of the low columns of a multiplication, the groups of a
+// column sum that only the last rounds read): every bootstrap gets a deadline -- the last layer
+// that still lets its consumers meet theirs, the operator's depth staying what it is -- and a list
+// scheduler fills each layer with what is due, rounded up to a multiple of `cap`, most urgent first.
+// Two fillings are tried (the first layer as built, or cut like the others); the cheaper one under
+// the step model replaces the program if it beats it, and only if the rebuilt program passes a
+// dependency check.  The bootstraps and their tables are untouched: for large batches, where a
+// layer's cost is proportional to its size, nothing changes.
+// ------------------------------------------------------------------------------------------------
+void Builder::balance(size_t cap) {
+    if (!cap || P.layers.size() < 3) return;
+    const size_t L = P.layers.size();
+    struct Pb { PbsOp op; uint32_t layer; };
+    struct Ln { LinOp op; uint32_t layer; };
+    std::vector<Pb> pbs;
+    std::vector<Ln> lin;
+    std::vector<int> made(P.nblocks, -1);   // -1 input, 2 i: bootstrap i, 2 i + 1: linear operation i
+    for (size_t l = 0; l < L; ++l) {
+        for (const LinOp& q : P.layers[l].lin) { made[q.out] = 2 * (int)lin.size() + 1; lin.push_back({q, (uint32_t)l}); }
+        for (const PbsOp& q : P.layers[l].pbs) { made[q.out] = 2 * (int)pbs.size(); pbs.push_back({q, (uint32_t)l}); }
+    }
+    const size_t n = pbs.size();
+    if (!n) return;
+    // the bootstraps a block's value depends on directly (through linear operations)
+    std::vector<std::vector<uint32_t>> block_preds(P.nblocks);
+    std::vector<char> known(P.nblocks, 0);
+    std::function<const std::vector<uint32_t>&(uint32_t)> preds_of = [&](uint32_t b) -> const std::vector<uint32_t>& {
+        if (known[b]) return block_preds[b];
+        known[b] = 1;
+        const int m = made[b];
+        if (m >= 0 && !(m & 1)) block_preds[b] = {(uint32_t)(m / 2)};
+        else if (m >= 0) {
+            std::vector<uint32_t> acc;
+            const LinOp& q = lin[(size_t)(m / 2)].op;
+            for (uint32_t k = 0; k < q.n; ++k) { const auto& r = preds_of(q.src[k]); acc.insert(acc.end(), r.begin(), r.end()); }
+            std::sort(acc.begin(), acc.end());
+            acc.erase(std::unique(acc.begin(), acc.end()), acc.end());
+            block_preds[b] = std::move(acc);
+        }
+        return block_preds[b];
+    };
+    std::vector<std::vector<uint32_t>> preds(n), succ(n);
+    for (size_t i = 0; i < n; ++i) {
+        preds[i] = preds_of(pbs[i].op.in);
+        for (uint32_t j : preds[i]) succ[j].push_back((uint32_t)i);
+    }
+    const uint32_t never = 1u << 30;
+    std::vector<uint32_t> due(n, never);
+    auto final_block = [&](uint32_t b) { for (uint32_t j : preds_of(b)) due[j] = (uint32_t)L - 1; };
+    for (uint32_t b : P.out) final_block(b);
+    for (const auto& o : P.outs) for (uint32_t b : o) final_block(b);
+    for (size_t i = n; i-- > 0;) {   // consumers sit in later layers, hence later in the list
+        for (uint32_t s : succ[i]) due[i] = std::min(due[i], due[s] - 1);
+        if (due[i] == never) due[i] = (uint32_t)L - 1;
+        if (due[i] < pbs[i].layer) return;   // cannot be: the program as built meets its own depth
+    }
+    auto cost = [cap](size_t x) {
+        const double c = (double)cap;
+        if (!x) return 0.0;
+        if (x <= cap) return 1.0;
+        if (x <= 2 * cap) return 1.9;
+        if (x <= 3 * cap) return 2.85;
+        if (x <= 4 * cap) return 3.35;
+        return 3.35 * (double)x / (4 * c);
+    };
+    auto total = [&](const std::vector<uint32_t>& where) {
+        std::vector<size_t> sizes(L, 0);
+        for (uint32_t l : where) sizes[l] += 1;
+        double t = 0;
+        for (size_t x : sizes) t += cost(x);
+        return t;
+    };
+    auto schedule = [&](bool first_as_built, std::vector<uint32_t>& where) {
+        where.assign(n, never);
+        std::vector<uint32_t> waiting(n);
+        for (size_t i = 0; i < n; ++i) waiting[i] = (uint32_t)preds[i].size();
+        std::vector<uint32_t> ready, next;
+        for (size_t i = 0; i < n; ++i) if (!waiting[i]) ready.push_back((uint32_t)i);
+        size_t placed = 0;
+        for (uint32_t l = 0; l < L && placed < n; ++l) {
+            std::sort(ready.begin(), ready.end(), [&](uint32_t a, uint32_t b) {
+                return due[a] != due[b] ? due[a] < due[b] : (pbs[a].layer != pbs[b].layer ? pbs[a].layer < pbs[b].layer : a < b);
+            });
+            size_t must = 0;
+            while (must < ready.size() && due[ready[must]] <= l) ++must;
+            size_t take = std::max(cap, (must + cap - 1) / cap * cap);
+            if (l == 0 && first_as_built) take = ready.size();
+            take = std::min(take, ready.size());
+            next.assign(ready.begin() + (long)take, ready.end());
+            for (size_t k = 0; k < take; ++k) {
+                const uint32_t i = ready[k];
+                where[i] = l;
+                ++placed;
+            }
+            for (size_t k = 0; k < take; ++k)
+                for (uint32_t s : succ[ready[k]])
+                    if (--waiting[s] == 0) next.push_back(s);
+            ready.swap(next);
+        }
+        return placed == n;
+    };
+    std::vector<uint32_t> as_built(n), best, trial;
+    for (size_t i = 0; i < n; ++i) as_built[i] = pbs[i].layer;
+    double best_cost = total(as_built);
+    for (int variant = 0; variant < 2; ++variant)
+        if (schedule(variant == 1, trial) && total(trial) < best_cost - 1e-9) { best_cost = total(trial); best = trial; }
+    if (best.empty()) return;
+
+    // rebuild: linear operations move to the first layer that has all their sources; one that now
+    // shares its layer with a linear operation it reads takes that one's combination in its place
+    std::vector<uint32_t> lin_layer(lin.size(), 0);
+    std::vector<std::vector<std::pair<int64_t, uint32_t>>> terms(lin.size());
+    std::vector<int64_t> consts(lin.size());
+    for (size_t a = 0; a < lin.size(); ++a) {
+        const LinOp& q = lin[a].op;
+        uint32_t at = 0;
+        for (uint32_t k = 0; k < q.n; ++k) {
+            const int m = made[q.src[k]];
+            if (m >= 0 && !(m & 1)) at = std::max(at, best[(size_t)(m / 2)] + 1);
+            else if (m >= 0) { if ((size_t)(m / 2) >= a) return; at = std::max(at, lin_layer[(size_t)(m / 2)]); }
+        }
+        std::map<uint32_t, int64_t> acc;
+        int64_t c = q.cst;
+        for (uint32_t k = 0; k < q.n; ++k) {
+            const int m = made[q.src[k]];
+            if (m >= 0 && (m & 1) && lin_layer[(size_t)(m / 2)] == at) {
+                const size_t b = (size_t)(m / 2);
+                for (const auto& t : terms[b]) acc[t.second] += (int64_t)q.coef[k] * t.first;
+                c += (int64_t)q.coef[k] * consts[b];
+            } else {
+                acc[q.src[k]] += q.coef[k];
+            }
+        }
+        for (const auto& t : acc) if (t.second) terms[a].push_back({t.second, t.first});
+        if (terms[a].size() > (size_t)LIN_MAX_TERMS) return;
+        consts[a] = c;
+        lin_layer[a] = at;
+    }
+    uint32_t depth = 0;
+    for (size_t i = 0; i < n; ++i) depth = std::max(depth, best[i] + 1);
+    for (size_t a = 0; a < lin.size(); ++a) depth = std::max(depth, lin_layer[a] + 1);
+    if (depth > L) return;
+    // dependency check of what is about to be written
+    for (size_t i = 0; i < n; ++i) {
+        const int m = made[pbs[i].op.in];
+        if (m >= 0 && !(m & 1) && best[(size_t)(m / 2)] + 1 > best[i]) return;
+        if (m >= 0 && (m & 1) && lin_layer[(size_t)(m / 2)] > best[i]) return;
+    }
+    for (size_t a = 0; a < lin.size(); ++a)
+        for (const auto& t : terms[a]) {
+            const int m = made[t.second];
+            if (m >= 0 && !(m & 1) && best[(size_t)(m / 2)] + 1 > lin_layer[a]) return;
+            if (m >= 0 && (m & 1) && lin_layer[(size_t)(m / 2)] >= lin_layer[a]) return;
+            if (t.first > INT32_MAX || t.first < INT32_MIN) return;
+        }
+    std::vector<Layer> layers(L);
+    for (size_t a = 0; a < lin.size(); ++a) {
+        LinOp q{};
+        q.out = lin[a].op.out;
+        q.n = (uint32_t)terms[a].size();
+        for (size_t k = 0; k < terms[a].size(); ++k) { q.coef[k] = (int32_t)terms[a][k].first; q.src[k] = terms[a][k].second; }
+        if (consts[a] > INT32_MAX || consts[a] < INT32_MIN) return;
+        q.cst = (int32_t)consts[a];
+        layers[lin_layer[a]].lin.push_back(q);
+    }
+    for (size_t i = 0; i < n; ++i) layers[best[i]].pbs.push_back(pbs[i].op);
+    P.layers.swap(layers);
+    prune();   // linear operations whose combination was taken over may have no reader left
+}
+
+static size_t layer_cap() {
+    static const size_t cap = [] {
+        const char* e = std::getenv("LFHE_LAYER_CAP");   // 0: programs stay as built
+        return e ? (size_t)std::atol(e) : (size_t)256;   // one ciphertext per compute unit of an MI355X
+    }();
+    return cap;
+}
+
 void Builder::finish() {
     prune();
+    balance(layer_cap());
     int noise = 0, deg = 0;
     for (uint32_t b : P.out) { noise = std::max(noise, info_[b].noise); deg = std::max(deg, info_[b].hi); }
     P.out_noise = (uint8_t)std::max(noise, 1);
@@ -1053,6 +1239,7 @@ Program build_fused(const std::vector<FusedStep>& steps, const std::vector<uint3
         B.P.out_degrees.push_back((uint8_t)deg);
     }
     B.prune();
+    B.balance(layer_cap());
     return B.P;
 }
 

@@ -110,6 +110,9 @@ public:
     int level(uint32_t b) const { return info_[b].level; }   // the layer whose bootstraps may read the block
     void finish();
     void prune();   // drops the operations no output depends on
+    // Moves bootstraps that have slack out of layers larger than `cap` ciphertexts into later ones,
+    // without adding a layer (radix_program.cpp).  cap 0: leaves the program as built.
+    void balance(size_t cap);
 
 private:
     struct Info { int level, lo, hi, noise; };

@@ -32,6 +32,9 @@ def _run_layers_plain(prog: dict, blk: dict) -> None:
     next linear operation adds its constant."""
     wraps = prog.get("lut_wraps") or [0] * len(prog["luts"])
     for layer in prog["layers"]:
+        # the linear operations of a layer run side by side on the GPU: none may read another's output
+        written = {op["out"] for op in layer["lin"]}
+        assert not any(s in written for op in layer["lin"] for _, s in op["terms"]), "linear operations of one layer depend on each other"
         for op in layer["lin"]:
             v = op["cst"] + sum(c * blk[s] for c, s in op["terms"])
             assert 0 <= v <= 31, f"block overflow {v}"
