@@ -294,6 +294,51 @@ def test_operands_at_noise_level_two_need_no_clean_up_for_comparisons_and_select
         assert radix.run_plain_fused(later, [a, b, ia, ib]) == want
 
 
+def test_random_chains_of_operators_as_one_schedule():
+    """Random chains (results of selects feeding products, shifts, divisions, comparisons feeding
+    selects, clear operands) built as ONE fused schedule and interpreted on clear blocks against the
+    clear model: noise-level handling, pruning, layer balancing and the specialised forms meet here."""
+    from fhe_amd.native import fused_program
+    rnd = random.Random(91)
+    binary = ["add", "sub", "mul", "and", "or", "xor", "min", "max"]
+    compare = ["lt", "le", "gt", "ge", "eq", "ne"]
+    for trial in range(60):
+        w = rnd.choice([8, 16, 32, 64])
+        m = (1 << w) - 1
+        n_in = rnd.randrange(2, 4)
+        widths = [w] * n_in
+        steps, vw = [], list(widths)          # vw: width of every value so far
+        for _ in range(rnd.randrange(3, 7)):
+            ints = [i for i, x in enumerate(vw) if x == w]
+            bools = [i for i, x in enumerate(vw) if x == 1]
+            kind = rnd.random()
+            if kind < 0.15 and bools:
+                steps.append(("select", w, rnd.choice(ints), rnd.choice(ints), rnd.choice(bools))); vw.append(w)
+            elif kind < 0.35:
+                steps.append((rnd.choice(compare), w, rnd.choice(ints), rnd.choice(ints), None)); vw.append(1)
+            elif kind < 0.5:
+                op = rnd.choice(["shl", "shr", "rotl", "rotr", "div", "rem", "mul", "and"])
+                c = rnd.randrange(1, m + 1) if op in ("div", "rem", "mul", "and") else rnd.randrange(w)
+                steps.append((op, w, rnd.choice(ints), ("clear", c), None)); vw.append(w)
+            elif kind < 0.6:
+                steps.append((rnd.choice(["neg", "not"]), w, rnd.choice(ints), None, None)); vw.append(w)
+            else:
+                steps.append((rnd.choice(binary), w, rnd.choice(ints), rnd.choice(ints), None)); vw.append(w)
+        outs = [i for i in range(n_in, len(vw))][-2:]
+        p = fused_program(steps, widths, outs)
+        for _ in range(6):
+            vals = [rnd.choice([0, 1, m, rnd.randrange(m + 1)]) for _ in range(n_in)]
+            model = list(vals)
+            for op, _, a, b, c in steps:
+                if op == "select":
+                    model.append(model[a] if model[c] else model[b])
+                elif op in ("neg", "not"):
+                    model.append(radix.clear_op(op, w, model[a]))
+                else:
+                    model.append(radix.clear_op(op, w, model[a], b[1] if isinstance(b, tuple) else model[b]))
+            assert radix.run_plain_fused(p, vals) == [model[o] for o in outs], (trial, steps, vals)
+
+
 def test_schedule_sizes_are_reported():
     """Bootstraps per operation (the scheduler's own count; the reference publishes none)."""
     want_at_most = {("add", 64): (150, 4), ("sub", 64): (150, 4), ("mul", 64): (1900, 9), ("lt", 64): (45, 4),
