@@ -200,7 +200,11 @@ void Builder::balance(size_t cap) {
     }
     const uint32_t never = 1u << 30;
     std::vector<uint32_t> due(n, never);
-    auto final_block = [&](uint32_t b) { for (uint32_t j : preds_of(b)) due[j] = (uint32_t)L - 1; };
+    // an output made by a linear operation needs its bootstraps one layer before the last
+    auto final_block = [&](uint32_t b) {
+        const uint32_t last = (made[b] >= 0 && (made[b] & 1)) ? (uint32_t)L - 2 : (uint32_t)L - 1;
+        for (uint32_t j : preds_of(b)) due[j] = std::min(due[j], last);
+    };
     for (uint32_t b : P.out) final_block(b);
     for (const auto& o : P.outs) for (uint32_t b : o) final_block(b);
     for (size_t i = n; i-- > 0;) {   // consumers sit in later layers, hence later in the list
