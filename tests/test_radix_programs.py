@@ -339,6 +339,30 @@ def test_random_chains_of_operators_as_one_schedule():
             assert radix.run_plain_fused(p, vals) == [model[o] for o in outs], (trial, steps, vals)
 
 
+def test_layer_balancing_moves_bootstraps_and_nothing_else():
+    """Balanced and as-built program of a euint64 multiplication (LFHE_LAYER_CAP=0 in a process of its
+    own: the setting is read once): the same bootstraps on the same blocks through the same tables,
+    the same depth, no layer after the first above one ciphertext per compute unit."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import json, sys; sys.path.insert(0, %r); from fhe_amd.native import program; "
+            "print(json.dumps(program('mul', 64)))" % root)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LFHE_LAYER_CAP="0"), capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    built, balanced = json.loads(r.stdout.strip().splitlines()[-1]), prog("mul", 64)
+    ops = lambda p: sorted(tuple(q) for l in p["layers"] for q in l["pbs"])
+    assert ops(built) == ops(balanced) and built["luts"] == balanced["luts"]
+    assert len(built["layers"]) == len(balanced["layers"]) == 9
+    assert [len(l["pbs"]) for l in built["layers"]][:3] == [1024, 387, 140]
+    assert all(len(l["pbs"]) <= 256 for l in balanced["layers"][1:])
+    rnd = random.Random(7)
+    for _ in range(20):
+        a, b = rnd.randrange(1 << 64), rnd.randrange(1 << 64)
+        assert radix.run_plain(built, a, b) == radix.run_plain(balanced, a, b) == (a * b) & ((1 << 64) - 1)
+
+
 def test_schedule_sizes_are_reported():
     """Bootstraps per operation (the scheduler's own count; the reference publishes none)."""
     want_at_most = {("add", 64): (150, 4), ("sub", 64): (150, 4), ("mul", 64): (1900, 9), ("lt", 64): (45, 4),
