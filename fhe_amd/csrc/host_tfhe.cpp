@@ -48,13 +48,17 @@ uint64_t ChaCha::next() {
     return lo | (hi << 32);
 }
 
+// TUniform(b) as tfhe-rs defines it: the integers of [-2^b, 2^b], the two end points with probability
+// 2^-(b+2) each, every inner value with 2^-(b+1): b + 2 random bits v give floor((v + 1) / 2) - 2^b.
 uint64_t ChaCha::tuniform(uint32_t b) {
-    const uint64_t span = (1ull << (b + 1)) + 1, mask = (1ull << (b + 2)) - 1;
-    for (;;) {
-        uint64_t v = next() & mask;
-        if (v < span) return v - (1ull << b);
-    }
+    const uint64_t v = next() & ((1ull << (b + 2)) - 1);
+    return ((v + 1) >> 1) - (1ull << b);
 }
+
+// The same shape for a bound that is not a power of two: offset in [0, 2 bound] of a value of
+// [-bound, bound] whose end points have half the weight of the inner values (4 bound <= 2^20, so the
+// bias of the modulo is below 2^-44).
+uint64_t ChaCha::tuniform_bound(uint64_t bound) { return ((next() % (4 * bound)) + 1) >> 1; }
 
 void gen_binary_key(ChaCha& r, uint64_t* key, size_t len) {
     for (size_t i = 0; i < len; i += 64) {
@@ -132,8 +136,10 @@ void gen_bsk(const EngineParams& p, const uint64_t* lwe_sk, const uint64_t* glwe
     });
 }
 
-// the same key over the ring modulus q': residues in [0, q'), noise uniform in [-E, E] with
-// E = round(2^glwe_noise_log2 q' / 2^64), gadget round(q' / 2^base_log)
+// the same key over the ring modulus q': residues in [0, q'), noise of the set's own shape scaled to
+// q' -- the integers of [-E, E] with the end points at half weight, E = round(2^glwe_noise_log2 q' /
+// 2^64) (variance 8.5 for E = 5, where the set's TUniform(17) scaled by q' / 2^64 has 8.31) --, gadget
+// round(q' / 2^base_log)
 void gen_bsk_qp(const EngineParams& p, const uint64_t* lwe_sk, const uint64_t* glwe_sk, const uint8_t seed[32],
                 uint64_t* bsk, int threads) {
     const uint64_t Q = QP_U;
@@ -147,7 +153,7 @@ void gen_bsk_qp(const EngineParams& p, const uint64_t* lwe_sk, const uint64_t* g
         uint64_t* body = mask + N;
         for (int j = 0; j < N; ++j) mask[j] = (uint64_t)(((unsigned __int128)r.next() * Q) >> 64);
         for (int j = 0; j < N; ++j) {
-            const uint64_t e = r.next() % (2 * E + 1);
+            const uint64_t e = r.tuniform_bound(E);
             body[j] = e >= E ? e - E : e + Q - E;
         }
         // body += mask (*) s over Z_q' for the binary key s: sum of negacyclic rotations, kept below 2^63

@@ -16,8 +16,10 @@ public:
     ChaCha(const uint8_t seed[32], uint64_t stream) { init(seed, stream); }
     void init(const uint8_t seed[32], uint64_t stream);
     uint64_t next();
-    // uniform integer in [-2^b, 2^b] as a torus element
+    // TUniform(b): integer of [-2^b, 2^b] (end points at half weight) as a torus element
     uint64_t tuniform(uint32_t b);
+    // the same shape on [-bound, bound], returned as an offset in [0, 2 bound]
+    uint64_t tuniform_bound(uint64_t bound);
 
 private:
     void refill();

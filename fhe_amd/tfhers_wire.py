@@ -69,6 +69,7 @@ def parse_client_key(blob: bytes) -> dict:
         "lwe_noise_log2": u32(72), "glwe_noise_log2": u32(88),
         "pbs_base_log": u64(96), "pbs_level": u64(108), "ks_base_log": u64(120), "ks_level": u64(132),
         "message_modulus": u64(144), "carry_modulus": u64(156), "max_noise_level": u64(168),
+        "log2_p_fail": f64(176),
         "ms_zeros_count": u32(229), "ms_bound": f64(241), "ms_r_sigma_factor": f64(253),
         "ms_input_variance": f64(265),
     }

@@ -43,8 +43,9 @@ extern "C" {
  * step multiplies the accumulator by G0 + X^a G1 + X^a' G2 + X^(a+a') G3 -- one external product
  * for two mask elements (the multi-bit blind rotation of tfhe-rs with grouping factor 2).
  * Ciphertexts, secret keys, key switch, encodings and every interface are those of the named set;
- * only the server's bootstrapping key differs (twice the words, 1.4 times the blind-rotation
- * noise variance). */
+ * only the server's bootstrapping key differs (twice the words; 1.38 times the variance of a
+ * bootstrap's output, which leaves log2 p_fail at noise level 5 at -129.2 or below -- measured and
+ * computed, tools/noise_probe.py and tools/pfail.py -- where the set's own fixture states -129.15). */
 #define LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK_GROUPED 3u
 /* the named set itself -- every modulus 2^64, as published -- with the key bits taken two at a time:
  * four GGSWs over 2^64 per pair of bits, half the transforms of set 1 (two-prime transform and lift

@@ -65,16 +65,21 @@ uint64_t orc_rng_u64(orc_rng* r) {
     return lo | (hi << 32);
 }
 
-/* TUniform(b): uniform over the 2^(b+1)+1 integers of [-2^b, 2^b] (rejection sampling on b+2
- * bits).  tfhe-rs weights the two end points by one half instead; the support is the same and no
- * reference fixture depends on the sampler. */
+/* TUniform(b) as tfhe-rs defines it: the integers of [-2^b, 2^b], the two end points with
+ * probability 2^-(b+2) each, every inner value with 2^-(b+1).  b + 2 random bits v give
+ * floor((v + 1) / 2) - 2^b: v = 0 and v = 2^(b+2) - 1 are the end points, every other value is hit
+ * by two v.  Variance (2^(2b+1) + 1) / 6. */
 uint64_t orc_rng_tuniform(orc_rng* r, uint32_t b) {
-    const u64 span = ((u64)1 << (b + 1)) + 1;
-    const u64 mask = ((u64)1 << (b + 2)) - 1;
-    for (;;) {
-        u64 v = orc_rng_u64(r) & mask;
-        if (v < span) return v - ((u64)1 << b);
-    }
+    const u64 v = orc_rng_u64(r) & (((u64)1 << (b + 2)) - 1);
+    return ((v + 1) >> 1) - ((u64)1 << b);
+}
+
+/* The same shape for a bound E that is not a power of two (keys over the prime ring modulus, whose
+ * noise bound is 2^b scaled to that modulus): integers of [-E, E], end points at half weight.
+ * Returned as an offset in [0, 2E]. */
+uint64_t orc_rng_tuniform_bound(orc_rng* r, uint64_t E) {
+    const u64 v = orc_rng_u64(r) % (4 * E);   /* 4E <= 2^20: the modulo bias is below 2^-44 */
+    return (v + 1) >> 1;
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -901,7 +906,7 @@ static void gen_ggsw_qp(const orc_ctx* c, u64 msg, const u64* glwe_sk, orc_rng* 
     for (u32 rr = 0; rr <= k; ++rr, row += (size_t)(k + 1) * N) {
         u64* body = row + (size_t)k * N;
         for (u32 j = 0; j < N; ++j) {
-            const u64 e = orc_rng_u64(r) % (2 * E + 1);          /* uniform in [-E, E] */
+            const u64 e = orc_rng_tuniform_bound(r, E);          /* [-E, E], end points at half weight */
             body[j] = e >= E ? e - E : e + ORC_QP - E;
         }
         for (u32 q = 0; q < k; ++q) {

@@ -65,6 +65,7 @@ void orc_rng_init(orc_rng* r, const uint8_t seed[32], uint64_t stream);
 uint64_t orc_rng_u64(orc_rng* r);
 /* uniform integer in [-2^log2_bound, 2^log2_bound], returned as a torus element (mod 2^64) */
 uint64_t orc_rng_tuniform(orc_rng* r, uint32_t log2_bound);
+uint64_t orc_rng_tuniform_bound(orc_rng* r, uint64_t bound);   /* offset in [0, 2 bound] */
 
 /* ---- context: parameters + NTT tables for the two oracle primes ---- */
 typedef struct orc_ctx orc_ctx;
@@ -181,7 +182,7 @@ void orc_pbs_batch_prepared(const orc_ctx* c, const uint64_t* ksk, const orc_pre
  * its modulus everything keeps the parameter set's proportions:
  *   gadget   G  = round(q' / 2^pbs_base_log)                    (83886080 = 5*2^24 for base 2^23)
  *   digit    d  = rint(c * fl(1/G)) in IEEE double, c the centred residue in (-q'/2, q'/2)
- *   noise    e  uniform in [-E, E], E = round(2^glwe_noise_log2 * q' / 2^64)          (5 for 2^17)
+ *   noise    e  in [-E, E], end points at half weight (the set's TUniform shape), E = round(2^glwe_noise_log2 * q' / 2^64)   (5 for 2^17)
  *   LUT      round(v * q' / 2^64) of the 2^64-scale accumulator body
  *   output   round(r * 2^64 / q') of every word of the sample-extracted ciphertext
  * pbs_level must be 1.  PARITY UNPINNED against the reference (no engine in the tree). */

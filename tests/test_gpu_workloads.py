@@ -79,3 +79,63 @@ def test_batched_transfers_against_the_clear_ledger(ctx):
     assert [ctx.decrypt(bytes(c)) for c in nf] == [f - v for f, v in zip(frm, moved)]
     assert [ctx.decrypt(bytes(c)) for c in nt] == [(t + v) & ((1 << 64) - 1) for t, v in zip(to, moved)]
     assert any(moved) and not all(moved)
+
+
+# the four euint64 multiplication vectors and the greater-than vectors of the reference's suite
+# (tests/fhevm-suite/e2e/test/fhevmOperations/fhevmOperations6.ts:647-705 and :1067), read from the
+# extracted fixture so that the literals stay the reference's own
+def _kat_pairs(op):
+    import json
+    import os
+    rows = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fhevm_operator_kats.json")))
+    return [(int(r["inputs"][0]), int(r["inputs"][1]), r["expected"]) for r in rows["kats"]
+            if r["op"] == op and r["types"] == ["euint64", "euint64"]]
+
+
+def test_config3_full_size_mul_and_compare():
+    """BASELINE configuration 3 at full size: 256 random euint64 pairs plus the reference's own
+    vectors, one evaluate_batch per operator, against the clear model."""
+    from fhe_amd.native import Context
+    ctx = Context(seed=bytes(range(32)), params_id=3)
+    try:
+        ctx.keygen()
+        rnd = random.Random(33)
+        m64 = (1 << 64) - 1
+        for op, model in (("mul", lambda a, b: (a * b) & m64), ("gt", lambda a, b: int(a > b))):
+            kats = _kat_pairs(op)
+            assert len(kats) == 4, f"expected the four reference vectors of {op}, found {len(kats)}"
+            pairs = [(a, b) for a, b, _ in kats] + [(rnd.randrange(1 << 64), rnd.randrange(1 << 64)) for _ in range(256)]
+            for (a, b, want) in kats:
+                assert model(a, b) == (int(want == "true") if want in ("true", "false") else int(want))
+            n0 = ctx.pbs_count()
+            out = ctx.evaluate_batch(op, 64, _column(ctx, [p[0] for p in pairs], 64), _column(ctx, [p[1] for p in pairs], 64))
+            got = [ctx.decrypt(bytes(c)) for c in out]
+            assert got == [model(a, b) for a, b in pairs], op
+            print(f"{op}: {len(pairs)} instances, {ctx.pbs_count() - n0} bootstraps")
+    finally:
+        ctx.close()
+
+
+def test_config4_full_per_gpu_share_of_transfers():
+    """BASELINE configuration 4 at the size one GPU of eight takes: 1250 of the 10 000 independent
+    transfers through the fused schedule, about half with an amount above the balance, against the
+    clear ledger (tests/fhevm-suite/e2e/contracts/EncryptedERC20.sol:87-93, 208-220)."""
+    from fhe_amd import workloads
+    from fhe_amd.native import Context
+    ctx = Context(seed=bytes(range(32)), params_id=3)
+    try:
+        ctx.keygen()
+        rnd = random.Random(44)
+        n = 1250
+        m64 = (1 << 64) - 1
+        frm = [rnd.randrange(1 << 64) for _ in range(n)]
+        amt = [rnd.randrange(f + 1) if rnd.random() < 0.5 else min(m64, f + 1 + rnd.randrange(1 << 40)) for f in frm]
+        to = [rnd.randrange(1 << 64) for _ in range(n)]
+        nf, nt = workloads.transfers(ctx, _column(ctx, frm, 64), _column(ctx, to, 64), _column(ctx, amt, 64),
+                                     ctx.encrypt(0, 64, trivial=True))
+        moved = [a if a <= f else 0 for a, f in zip(amt, frm)]
+        assert [ctx.decrypt(bytes(c)) for c in nf] == [f - v for f, v in zip(frm, moved)]
+        assert [ctx.decrypt(bytes(c)) for c in nt] == [(t + v) & m64 for t, v in zip(to, moved)]
+        assert 0.35 * n < sum(1 for v in moved if v) < 0.65 * n
+    finally:
+        ctx.close()
