@@ -40,22 +40,23 @@ PEAK_GBFLY_PER_PRIME = 4748.0
 # (tools/pmc_passes.sh + tools/pmc_summary.py: separate rocprofv3 --pmc passes, (2 * FETCH_SIZE +
 # WRITE_SIZE) * 1024, Infinity-Cache hits included).  The summary is stamped with a hash of the kernel
 # sources; a build from other sources reports null instead of a stale number.
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02", "traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03", "traffic.json")
 
 
-def measured_traffic(flavour: str, batch: int):
-    """(bytes per launch or None, where it comes from)."""
+def measured_counters(flavour: str, batch: int) -> dict:
+    """The tracked counter summary of this build's blind-rotation kernel ({} when there is none or it
+    was taken on other kernel sources): bytes_per_launch_4096, clock_ghz, issue_frac, source, ..."""
     if batch != BATCH or not os.path.exists(TRAFFIC_FILE):
-        return None, None
+        return {}
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     try:
         from pmc_summary import kernel_source_hash
         rec = json.load(open(TRAFFIC_FILE)).get(flavour)
         if not rec or rec.get("kernel_sources") != kernel_source_hash():
-            return None, None
-        return rec["bytes_per_launch_4096"], rec.get("source")
+            return {}
+        return rec
     except (OSError, ValueError, KeyError, ImportError):
-        return None, None
+        return {}
 
 
 # algorithmic bytes of one batch launch: both keys once + one ciphertext in and out per bootstrap
@@ -279,7 +280,19 @@ def main(argv=None, backend=None):
         achieved = B * modmul / br_s / 1e9
         peak = PEAK_GBFLY_PER_PRIME / 2 if flavour in ("q64", "q64_grouped") else PEAK_GBFLY_PER_PRIME
         algo_bytes = BSK_BYTES + KSK_BYTES + 2 * CT_BYTES * B
-        traffic, traffic_source = measured_traffic(flavour, B)
+        pmc = measured_counters(flavour, B)
+        traffic, traffic_source = pmc.get("bytes_per_launch_4096"), pmc.get("source")
+        classic = B * MODMUL_PER_PBS / br_s / 1e9 / peak
+        unit_note = (f"achieved = {B} bootstraps x modmul_per_pbs / blind-rotation launch time; modmul_per_pbs counts the modular "
+                     "products this kernel's algorithm executes")
+        if flavour in ("grouped", "q64_grouped"):
+            unit_note += (f": {MODMUL_PER_PBS_GROUPED_FACTORED if factored else MODMUL_PER_PBS_GROUPED} = 459 steps x (4 transforms x "
+                          f"11264 butterflies + {12 if factored else 16} products x 2048 points) with the key bits in pairs, where the "
+                          f"classic one-bit-per-step count (918 x 4 transforms + 918 x 4 x 2048 products = {MODMUL_PER_PBS}) would "
+                          f"read frac = {classic:.3f}")
+        unit_note += (f"; peak = {PEAK_GBFLY_PER_PRIME:.0f} G exact f64 butterflies/s per prime, calibrated register-resident at "
+                      "2.39 GHz (profiles/r01/valu_rates_8wg_per_cu.txt)" + (", halved: two primes per product over 2^64"
+                                                                              if flavour in ("q64", "q64_grouped") else ""))
         res = {
             "metric": "programmable bootstraps/sec (node)",
             "value": value,
@@ -301,7 +314,12 @@ def main(argv=None, backend=None):
             "kernel_ms": {"keyswitch_and_ms_noise_reduction": ks_ms, "blind_rotate": br_ms},
             "roofline": {"bound": "valu", "kernel": FLAVOURS[flavour][2], "achieved": achieved, "peak": peak,
                          "unit": "Gmodmul/s", "frac": achieved / peak, "modmul_per_pbs": modmul,
+                         "unit_note": unit_note, "frac_with_classic_unit": classic,
+                         # from the tracked rocprofv3 --pmc summary of this build (null: none for these sources)
                          "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_ratio": traffic / algo_bytes if traffic else None,
+                         "issue_frac": pmc.get("issue_frac"), "clock_ghz": pmc.get("clock_ghz"),
+                         "valu_wave_insts_per_launch": pmc.get("valu_wave_insts_per_launch"),
                          "hbm": {"achieved": algo_bytes / ((ks_ms + br_ms) * 1e-3) / 1e9, "peak": 8000.0,
                                  "unit": "GB/s", "algorithmic_bytes": algo_bytes},
                          # key words the workgroups request per launch (served by L2): every ciphertext
@@ -325,6 +343,11 @@ def main(argv=None, backend=None):
             res["value_q64_key"] = value
         if flavour == "q64_grouped":
             res["value_q64_grouped_key"] = value
+        # `value` is on this library's fastest server key (config.bsk_modulus says which); the same workload with
+        # every modulus exactly as the parameter set is published:
+        res["value_param_set_as_published"] = {
+            "one_bit_key_any_2^64_engine_can_load": res.get("value_q64_key"),
+            "own_key_with_the_key_bits_in_pairs": res.get("value_q64_grouped_key"), "unit": "PBS/s"}
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(flavour=flavour)
         print(json.dumps(res), flush=True)

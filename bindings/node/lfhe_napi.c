@@ -509,6 +509,7 @@ static napi_value js_expand_compact_list(napi_env env, napi_callback_info info) 
                                             (uint32_t)(tl / 4), NULL, &on);
     if (rc != LFHE_OK) return fail(env, c, rc, "lfhe_expand_compact_list");
     uint8_t* tmp = (uint8_t*)malloc(on ? on : 1);
+    if (!tmp) return throw_msg(env, "out of memory");
     rc = p_lfhe_expand_compact_list(c, w64, w64 + 2048, n_lwe, packed ? 1 : 0, (const uint32_t*)widths, (uint32_t)(tl / 4),
                                     tmp, &on);
     napi_value out = rc == LFHE_OK ? make_buffer(env, tmp, on) : fail(env, c, rc, "lfhe_expand_compact_list");

@@ -1,6 +1,8 @@
 """Builds liblfhe.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree next to this file."""
 from __future__ import annotations
 
+import fcntl
+import hashlib
 import os
 import subprocess
 import sys
@@ -28,31 +30,49 @@ def build(force: bool = False, verbose: bool = False, out: str = OUT, defines: t
     change to one source recompiles that source, a change to a header everything), then one link."""
     if out == OUT and not force and not _stale():
         return OUT
-    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-pthread", "-Wall", "-Wno-unused-function"]
     flags += [f"-D{d}" for d in defines]
-    tag = "" if out == OUT else "." + str(abs(hash((out,) + tuple(defines))) % 10 ** 8)
+    # objects of a non-default build (other defines, other output) get a tag that is the same in every process
+    tag = "" if out == OUT else "." + hashlib.sha1("\0".join((out,) + tuple(defines)).encode()).hexdigest()[:10]
     os.makedirs(OBJ_DIR, exist_ok=True)
     newest_header = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    # one builder at a time (ranks, a test run beside a benchmark): the others wait and then find fresh objects
+    lock = open(os.path.join(OBJ_DIR, ".lock"), "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        return _build_locked(force, verbose, out, flags, tag, newest_header, hipcc)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(force, verbose, out, flags, tag, newest_header, hipcc) -> str:
+    from concurrent.futures import ThreadPoolExecutor
+    if out == OUT and not force and not _stale():
+        return OUT      # built by whoever held the lock before us
 
     def compile_one(src: str) -> str:
         obj = os.path.join(OBJ_DIR, src + tag + ".o")
         path = os.path.join(CSRC, src)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), newest_header):
             return obj
-        cmd = [hipcc] + flags + ["-x", "hip", "-c", path, "-o", obj]
+        tmp = f"{obj}.{os.getpid()}.tmp"
+        cmd = [hipcc] + flags + ["-x", "hip", "-c", path, "-o", tmp]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+        os.replace(tmp, obj)      # a reader never sees a half-written object
         return obj
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), int(os.environ.get("MAX_JOBS", "8")))) as pool:
         objs = list(pool.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-pthread"] + objs + ["-o", out]
+    tmp = f"{out}.{os.getpid()}.tmp"
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-pthread"] + objs + ["-o", tmp]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    os.replace(tmp, out)
     return out
 
 

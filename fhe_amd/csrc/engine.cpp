@@ -35,7 +35,6 @@ Engine::Engine(int device, const EngineParams& p) : device_(device), prm_(p) {
     if (ndev <= 0) throw std::runtime_error("no HIP device: the HIP path is the only path");
     if (device < 0 || device >= ndev) throw std::runtime_error("device index out of range");
     HC(hipSetDevice(device_));
-    noalloc_setup(device_);
     blind_rotate_setup(device_);
     HC(hipSetDevice(device_));
     HC(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
@@ -86,6 +85,7 @@ Engine::Engine(int device, const EngineParams& p) : device_(device), prm_(p) {
 Engine::~Engine() {
     (void)hipSetDevice(device_);
     if (stream_) (void)hipStreamSynchronize(stream_);
+    noalloc_release(device_, stream_);
     if (own_keys_) { (void)hipFree(d_bsk_); (void)hipFree(d_ksk_); }
     (void)hipFree(d_cast_ksk_);
     (void)hipFree(d_tw_);

@@ -251,6 +251,7 @@ void hip_check(hipError_t e, const char* what);
 // once per device, with any device current: resolves the device address of the scratch array behind
 // lfhe_pbs_batch_device_noalloc (noalloc.hip)
 void noalloc_setup(int device);
+void noalloc_release(int device, hipStream_t st);
 // once per device: the 512-thread blind-rotation kernels ask for more than 64 KiB of dynamic LDS
 void blind_rotate_setup(int device);
 

@@ -1569,17 +1569,21 @@ void blind_rotate_setup(int dev) {
     static std::atomic<uint64_t> lds_asked{0};
     if (dev < 0 || dev >= 64) throw std::runtime_error("device index out of range");
     if (lds_asked.load(std::memory_order_acquire) >> dev & 1) return;
-    const bool ok = hipSetDevice(dev) == hipSuccess &&
-                    ask_lds(k_blind_rotate_q2_pair<true, false>, G2P_LDS_BYTES) &&
-                    ask_lds(k_blind_rotate_q2_pair<false, false>, G2P_LDS_BYTES) &&
-                    ask_lds(k_blind_rotate_q2_pair<true, true>, G2P_LDS_BYTES) &&
-                    ask_lds(k_blind_rotate_q2_pair<false, true>, G2P_LDS_BYTES) &&
-                    ask_lds(k_blind_rotate_g64_pair<false, 2>, g64_lds_bytes(2)) &&
-                    ask_lds(k_blind_rotate_g64_pair<true, 2>, g64_lds_bytes(2)) &&
-                    ask_lds(k_blind_rotate_q2_wide<false>, WIDE2_LDS_BYTES) &&
-                    ask_lds(k_blind_rotate_q2_wide<true>, WIDE2_LDS_BYTES) &&
-                    ask_lds(k_blind_rotate_q_wide, WIDE_LDS_BYTES);
-    if (!ok) throw std::runtime_error("the 512-thread blind rotation needs 136 KiB of LDS per workgroup");
+    if (hipSetDevice(dev) != hipSuccess) throw std::runtime_error("hipSetDevice failed");
+    auto need = [](bool ok, const char* kernel, size_t bytes) {
+        if (!ok)
+            throw std::runtime_error(std::string(kernel) + " needs " + std::to_string(bytes) +
+                                     " bytes of LDS per workgroup and the device refused the request");
+    };
+    need(ask_lds(k_blind_rotate_q2_pair<true, false>, G2P_LDS_BYTES), "k_blind_rotate_q2_pair", G2P_LDS_BYTES);
+    need(ask_lds(k_blind_rotate_q2_pair<false, false>, G2P_LDS_BYTES), "k_blind_rotate_q2_pair", G2P_LDS_BYTES);
+    need(ask_lds(k_blind_rotate_q2_pair<true, true>, G2P_LDS_BYTES), "k_blind_rotate_q2_pair", G2P_LDS_BYTES);
+    need(ask_lds(k_blind_rotate_q2_pair<false, true>, G2P_LDS_BYTES), "k_blind_rotate_q2_pair", G2P_LDS_BYTES);
+    need(ask_lds(k_blind_rotate_g64_pair<false, 2>, g64_lds_bytes(2)), "k_blind_rotate_g64_pair", g64_lds_bytes(2));
+    need(ask_lds(k_blind_rotate_g64_pair<true, 2>, g64_lds_bytes(2)), "k_blind_rotate_g64_pair", g64_lds_bytes(2));
+    need(ask_lds(k_blind_rotate_q2_wide<false>, WIDE2_LDS_BYTES), "k_blind_rotate_q2_wide", WIDE2_LDS_BYTES);
+    need(ask_lds(k_blind_rotate_q2_wide<true>, WIDE2_LDS_BYTES), "k_blind_rotate_q2_wide", WIDE2_LDS_BYTES);
+    need(ask_lds(k_blind_rotate_q_wide, WIDE_LDS_BYTES), "k_blind_rotate_q_wide", WIDE_LDS_BYTES);
     lds_asked.fetch_or(1ull << dev, std::memory_order_release);
 }
 

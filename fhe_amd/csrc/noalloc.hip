@@ -7,9 +7,14 @@
 // The array exists once per GPU the library runs on (about 25 MiB each, held until the process
 // ends).  In host code its NAME is only a stand-in: the device address is asked for once per device
 // with hipGetSymbolAddress and everything below uses that pointer.  Every call on a GPU uses that
-// GPU's one array: calls that overlap on one GPU (two contexts, two host threads) race.  Nothing
-// in it has to start at zero: the digit kernels write every word of the rows they hand on
-// (padding rows included) and the split key switch clears its output itself.
+// GPU's one array.  Calls from different contexts are ordered on the device by the library: the
+// entry point remembers the stream that used the array last and, when another stream comes, makes
+// it wait for an event recorded behind the last user's work (one event per device, made at set-up;
+// nothing is allocated per call); host threads are serialised by a mutex for the length of the
+// enqueue.  What still races is a call that overlaps, on the device, with work the CALLER queued
+// on the same buffers -- the usual rule for in/out pointers.  Nothing in the array has to start at
+// zero: the digit kernels write every word of the rows they hand on (padding rows included) and the
+// split key switch clears its output itself.
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -39,6 +44,10 @@ static __device__ __align__(256) unsigned char scratch[NA_TOTAL];
 static unsigned char* g_scratch_ptr[64];
 static std::atomic<uint64_t> g_scratch_known{0};
 static std::mutex g_scratch_mutex;
+// who used the array last on each device, and the event that orders the next user behind it
+static hipStream_t g_last_stream[64];
+static hipEvent_t g_order_event[64];
+static std::mutex g_use_mutex[64];
 
 void noalloc_setup(int device) {
     if (device < 0 || device >= 64) throw std::runtime_error("device index out of range for the scratch table");
@@ -51,8 +60,17 @@ void noalloc_setup(int device) {
     size_t bytes = 0;
     hip_check(hipGetSymbolSize(&bytes, HIP_SYMBOL(scratch)), "hipGetSymbolSize(scratch)");
     if (!p || bytes != NA_TOTAL) throw std::runtime_error("scratch symbol not resolved");
+    hip_check(hipEventCreateWithFlags(&g_order_event[device], hipEventDisableTiming), "hipEventCreateWithFlags");
     g_scratch_ptr[device] = static_cast<unsigned char*>(p);
     g_scratch_known.fetch_or(1ull << device, std::memory_order_release);
+}
+
+// An engine that goes away takes its stream with it: forget it as the array's last user (the engine has
+// waited for the stream by then, so nothing is left to order against).
+void noalloc_release(int device, hipStream_t st) {
+    if (device < 0 || device >= 64) return;
+    std::lock_guard<std::mutex> lock(g_use_mutex[device]);
+    if (g_last_stream[device] == st) g_last_stream[device] = nullptr;
 }
 
 static PbsScratch noalloc_regions(int device) {
@@ -86,7 +104,18 @@ extern "C" int32_t lfhe_pbs_batch_device_noalloc(lfhe_ctx* ctx, uint64_t count, 
             throw std::invalid_argument("lfhe_pbs_batch_device_noalloc: parameter set beyond the scratch array "
                                         "(LWE dimension <= 1024, key-switch levels <= 4)");
         if (!ctx->eng->has_keys()) throw std::logic_error("server keys not loaded: call lfhe_keygen or an import first");
-        const PbsScratch s = noalloc_regions(ctx->eng->device());
+        const int dev = ctx->eng->device();
+        noalloc_setup(dev);   // first call on this device: resolves the symbol, makes the event; later calls: one atomic load
+        const PbsScratch s = noalloc_regions(dev);
+        std::lock_guard<std::mutex> use(g_use_mutex[dev]);
+        const hipStream_t st = ctx->eng->stream(), prev = g_last_stream[dev];
+        if (prev && prev != st) {
+            // another context's stream used the array last: everything queued there so far comes first
+            hip_check(hipSetDevice(dev), "hipSetDevice");
+            hip_check(hipEventRecord(g_order_event[dev], prev), "hipEventRecord");
+            hip_check(hipStreamWaitEvent(st, g_order_event[dev], 0), "hipStreamWaitEvent");
+        }
+        g_last_stream[dev] = st;
         ctx->eng->pbs_batch_on(s, static_cast<const u64*>(d_lwe_in), static_cast<const u64*>(d_lut_bodies),
                                static_cast<const u32*>(d_lut_index), static_cast<u64*>(d_lwe_out), count);
         ctx->pbs_count += count;

@@ -79,6 +79,14 @@ def replicated_context(dist, rank: int, world: int, device, seed: bytes, params_
         blob = ctx.export_keys(KEY_CLIENT)
     if world > 1 or (always_broadcast and dist is not None):
         images = key_image_tensors(ctx, device, owner=rank == 0)
+        # The images were written on the library's own non-blocking stream, which no torch stream is
+        # ordered against.  Every key load ends in a host-side wait on that stream, so they are complete
+        # here; the two waits below make that ordering explicit at the hand-over instead of leaving it to
+        # the loaders (torch's side too: the receive buffers' allocation and any pending work on them).
+        if hasattr(ctx, "sync"):
+            ctx.sync()
+        if device.type == "cuda":
+            torch.cuda.synchronize()
         replicate(dist, images)
         if device.type == "cuda":
             torch.cuda.synchronize()

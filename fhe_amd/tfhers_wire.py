@@ -15,6 +15,7 @@ reproduces the fixtures byte for byte (tests/test_reference_keys.py).
 from __future__ import annotations
 
 import base64
+import os
 import struct
 
 import numpy as np
@@ -125,15 +126,39 @@ def emit_compact_public_key(mask, body) -> bytes:
     return base64.b64decode(COMPACT_PUBLIC_KEY_FRAMING[0]) + v.tobytes() + base64.b64decode(COMPACT_PUBLIC_KEY_FRAMING[1])
 
 
-def make_compact_public_key(pke_sk, seed: bytes, noise_log2: int = 17):
+class _Draws:
+    """Where the builders below take their randomness from.  seed = None: the operating system's
+    generator (os.urandom), which is what anything that protects real data must use.  A seed: numpy's
+    PCG64, reproducible and NOT cryptographic -- for known-answer vectors and tests only."""
+
+    def __init__(self, seed: bytes | None):
+        self._rng = None if seed is None else np.random.default_rng(list(seed))
+
+    def words(self, n: int) -> np.ndarray:
+        if self._rng is None:
+            return np.frombuffer(os.urandom(8 * n), dtype="<u8").astype(np.uint64)
+        return self._rng.integers(0, 1 << 64, size=n, dtype=np.uint64)
+
+    def bits(self, n: int) -> np.ndarray:
+        return self.words(n) & np.uint64(1)
+
+    def tuniform(self, n: int, log2_bound: int) -> np.ndarray:
+        """TUniform(b) as tfhe-rs defines it: [-2^b, 2^b], the end points at half weight."""
+        v = self.words(n) & np.uint64((1 << (log2_bound + 2)) - 1)
+        with np.errstate(over="ignore"):
+            return ((v + np.uint64(1)) >> np.uint64(1)) - np.uint64(1 << log2_bound)
+
+
+def make_compact_public_key(pke_sk, seed: bytes | None = None, noise_log2: int = 17):
     """(mask, body) of a fresh compact public key under the binary secret `pke_sk` in the convention of
-    tfhe-rs: body = mask (*) rev(s) + e over Z_2^64[X]/(X^N+1), rev(s)_i = s_{N-1-i}, e uniform in
-    [-2^noise_log2, 2^noise_log2]."""
+    tfhe-rs: body = mask (*) rev(s) + e over Z_2^64[X]/(X^N+1), rev(s)_i = s_{N-1-i}, e from
+    TUniform(noise_log2).  seed: None draws from the operating system; a seed gives reproducible,
+    non-cryptographic randomness (known-answer vectors only)."""
     s = np.ascontiguousarray(pke_sk, dtype=np.uint64)
     n = len(s)
-    rng = np.random.default_rng(list(seed))
-    mask = rng.integers(0, 1 << 64, size=n, dtype=np.uint64)
-    e = rng.integers(-(1 << noise_log2), (1 << noise_log2) + 1, size=n, dtype=np.int64).astype(np.uint64)
+    rng = _Draws(seed)
+    mask = rng.words(n)
+    e = rng.tuniform(n, noise_log2)
     body = e.copy()
     rev = s[::-1]
     with np.errstate(over="ignore"):
@@ -219,12 +244,15 @@ def radix_ciphertext_raw_parts(ct: bytes) -> dict:
             "ciphertext_modulus_log2": 64, "lwe_dimension": _LWE_WORDS - 1, "pbs_order": "KeyswitchBootstrap"}
 
 
-def build_compact_list(pk_mask, pk_body, values: list, widths: list, seed: bytes, packed: bool = True,
+def build_compact_list(pk_mask, pk_body, values: list, widths: list, seed: bytes | None = None, packed: bool = True,
                        noise_log2: int = 17):
     """What a client's input builder does (sdk/relayer/src/sdk/encrypt.ts:54-196, without the proof):
     all values' radix blocks in order, two per ciphertext when packed (low + 4 * high), encrypted
     as ONE compact list under the compact public key (tfhe-rs convention: key body = mask (*) rev(s)
-    + e): u binary, c0 = a (*) u + e1, c1 = b (*) u + e2 + M.  Returns (mask c0[2048], bodies[n])."""
+    + e): u binary, c0 = a (*) u + e1, c1 = b (*) u + e2 + M.  Returns (mask c0[2048], bodies[n]).
+    seed: None draws u and the noise from the operating system; a seed gives reproducible,
+    non-cryptographic randomness (known-answer vectors only).  Parity unpinned: the reference holds
+    no ciphertext fixture; the convention follows from its key fixtures."""
     n = 2048
     blocks = []
     for v, w in zip(values, widths):
@@ -236,9 +264,9 @@ def build_compact_list(pk_mask, pk_body, values: list, widths: list, seed: bytes
         blocks = [blocks[i] + 4 * (blocks[i + 1] if i + 1 < len(blocks) else 0) for i in range(0, len(blocks), 2)]
     if not 0 < len(blocks) <= n:
         raise ValueError("a compact list holds 1 .. 2048 ciphertexts")
-    rng = np.random.default_rng(list(seed))
-    u = rng.integers(0, 2, size=n, dtype=np.uint64)
-    tu = lambda: rng.integers(-(1 << noise_log2), (1 << noise_log2) + 1, size=n, dtype=np.int64).astype(np.uint64)
+    rng = _Draws(seed)
+    u = rng.bits(n)
+    tu = lambda: rng.tuniform(n, noise_log2)
     a, b = np.ascontiguousarray(pk_mask, dtype=np.uint64), np.ascontiguousarray(pk_body, dtype=np.uint64)
     c0, c1 = tu(), tu()
     with np.errstate(over="ignore"):

@@ -311,8 +311,11 @@ int32_t lfhe_sync(lfhe_ctx* ctx);
  * static device array of the library (about 25 MiB per GPU, held until the process ends) instead of
  * the context's grow-only buffers, and the call makes no hipMalloc / hipFree.  At most
  * LFHE_NOALLOC_MAX_COUNT ciphertexts per call (more is LFHE_ERR_ARG; so is a custom parameter set
- * with an LWE dimension above 1024).  All calls on one GPU share that GPU's array: calls that
- * overlap on one GPU -- from two contexts or two threads -- race; serialise them. */
+ * with an LWE dimension above 1024).  All calls on one GPU share that GPU's array; the library
+ * orders them on the device (a call from another context waits for the previous user's work through
+ * an event made at set-up, host threads are serialised for the length of the enqueue), so contexts
+ * may call back to back without a wait in between.  The first call on a GPU is the set-up (array
+ * address, event): make it outside a graph capture, e.g. with count = 0. */
 #define LFHE_NOALLOC_MAX_COUNT 1024u
 int32_t lfhe_pbs_batch_device_noalloc(lfhe_ctx* ctx, uint64_t count, const void* d_lwe_in, const void* d_lut_bodies,
                                       const void* d_lut_index, void* d_lwe_out);

@@ -17,8 +17,12 @@ def _two_rank_worker(rank, world, port, q):
     staging stands in for RCCL (two ranks cannot share a device under RCCL), everything else is the
     bench's path: library-owned device memory seen as a torch tensor, one broadcast per key image,
     attach."""
+    import faulthandler
     import os
     import sys
+    # a rank that stalls names the frame it sits in (all threads) and exits, instead of leaving the
+    # parent to guess from a silent queue
+    faulthandler.dump_traceback_later(240, exit=True)
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import numpy as np
     import torch
@@ -59,6 +63,7 @@ def _two_rank_worker(rank, world, port, q):
     finally:
         ctx.close()
         dist.destroy_process_group()
+        faulthandler.cancel_dump_traceback_later()
 
 
 def test_two_ranks_replicate_keys_through_torch_distributed(capsys):

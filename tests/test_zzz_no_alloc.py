@@ -29,6 +29,9 @@ def test_no_alloc_entry_point_matches_the_allocating_one(params_id):
         f = [(lambda x, j=j: ((2 * j + 1) * x + j) % 16) for j in range(16)]
         luts = np.stack([ctx.make_lut(g) for g in f])
         d_luts = torch.from_numpy(luts.view(np.int64)).to(dev)
+        # the first call on a device is the set-up (it asks for the array's address and makes the ordering
+        # event): an empty batch does it, so that every call measured below is an ordinary one
+        ctx.pbs_batch_device_noalloc(0, 0, 0, None, 0)
         # first call at the largest size the entry point takes, then smaller ones on the same (now dirty) array
         for call, count in enumerate((1024, 300, 100, 1, 700)):
             blocks = _blocks(ctx, count, call)
@@ -75,3 +78,40 @@ def test_no_alloc_entry_point_needs_keys():
         assert e.value.code == -2
     finally:
         ctx.close()
+
+
+def test_two_contexts_back_to_back_share_the_array_in_order():
+    """Two contexts (two streams) call the entry point one right after the other with no wait in
+    between: the second call's key switch would overwrite the small ciphertexts the first call's
+    blind rotation is still reading, were the calls not ordered on the device by the library."""
+    import torch
+    from fhe_amd.native import Context
+    dev = torch.device("cuda", 0)
+    a = Context(seed=bytes(range(32)), params_id=3)
+    b = Context(seed=bytes(range(1, 33)), params_id=3)
+    try:
+        a.keygen()
+        b.keygen()
+        work = []
+        for k, ctx in enumerate((a, b)):
+            luts = np.stack([ctx.make_lut(lambda x, j=j: (3 * x + j) % 16) for j in range(4)])
+            blocks = _blocks(ctx, 1024, 50 + k)
+            idx = ((np.arange(1024) + k) % 4).astype(np.uint32)
+            d = {"in": torch.from_numpy(blocks.view(np.int64)).to(dev), "luts": torch.from_numpy(luts.view(np.int64)).to(dev),
+                 "idx": torch.from_numpy(idx.view(np.int32)).to(dev)}
+            d["want"], d["got"] = torch.zeros_like(d["in"]), torch.zeros_like(d["in"])
+            ctx.pbs_batch_device(1024, d["in"].data_ptr(), d["luts"].data_ptr(), d["idx"].data_ptr(), d["want"].data_ptr())
+            ctx.sync()
+            work.append(d)
+        torch.cuda.synchronize()
+        for rounds in range(3):          # a, b, a, b, a, b with nothing in between
+            for ctx, d in zip((a, b), work):
+                ctx.pbs_batch_device_noalloc(1024, d["in"].data_ptr(), d["luts"].data_ptr(), d["idx"].data_ptr(),
+                                             d["got"].data_ptr())
+        a.sync()
+        b.sync()
+        for d in work:
+            assert torch.equal(d["got"], d["want"])
+    finally:
+        a.close()
+        b.close()

@@ -26,6 +26,7 @@ def kernel_source_hash() -> str:
 def main():
     src, dst = sys.argv[1], sys.argv[2]
     per = {}      # kernel -> counter -> (sum, dispatches)
+    span = {}     # kernel -> [sum of dispatch durations (ns), dispatches] of the pass that holds GRBM_GUI_ACTIVE
     for path in sorted(glob.glob(os.path.join(src, "*", "*counter_collection.csv")) +
                        glob.glob(os.path.join(src, "*", "*", "*counter_collection.csv"))):
         seen = set()
@@ -36,6 +37,10 @@ def main():
             if (k, c, row["Dispatch_Id"]) not in seen:
                 seen.add((k, c, row["Dispatch_Id"]))
                 d[1] += 1
+                if c == "GRBM_GUI_ACTIVE" and os.sep + "sq" + os.sep in path:
+                    sp = span.setdefault(k, [0, 0])
+                    sp[0] += int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+                    sp[1] += 1
     if not per:
         raise SystemExit(f"no counter CSVs under {src}")
     main_k = max(per, key=lambda k: per[k].get("SQ_WAVE_CYCLES", [0, 0])[0])
@@ -46,6 +51,22 @@ def main():
     for name in sorted(c):
         s, n = c[name]
         lines.append(f"  {name:42s} {s:20.1f}   dispatches {n}   per launch {s / max(n, 1):18.1f}")
+    # clock and issue rate of the pass that counted instructions (`sq`): busy cycles per XCD over the
+    # dispatch's own duration, and vector-ALU wave-instructions x 4 cycles over the 1024 SIMDs' cycles
+    extra = {}
+    if main_k in span and "SQ_INSTS_VALU" in c and os.path.exists(os.path.join(src, "sq")):
+        sq = {}
+        for path in glob.glob(os.path.join(src, "sq", "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(path)):
+                if row["Kernel_Name"] == main_k:
+                    sq[row["Counter_Name"]] = sq.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+        ns, n = span[main_k]
+        cycles = sq["GRBM_GUI_ACTIVE"] / 8 / n                 # per XCD and launch
+        extra = {"clock_ghz": sq["GRBM_GUI_ACTIVE"] / 8 / ns, "cycles_per_launch": cycles,
+                 "valu_wave_insts_per_launch": sq["SQ_INSTS_VALU"] / n,
+                 "issue_frac": sq["SQ_INSTS_VALU"] / n * 4 / 1024 / cycles, "launch_ms_under_counters": ns / n / 1e6}
+        lines += ["", f"  clock {extra['clock_ghz']:.3f} GHz ({cycles / 1e6:.1f} M cycles per launch of {ns / n / 1e6:.2f} ms); vector-ALU issue "
+                      f"{extra['issue_frac']:.3f} of the cycles (SQ_INSTS_VALU x 4 / 1024 SIMDs / cycles)"]
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         f = c["FETCH_SIZE"][0] / max(c["FETCH_SIZE"][1], 1)
         w = c["WRITE_SIZE"][0] / max(c["WRITE_SIZE"][1], 1)
@@ -55,7 +76,7 @@ def main():
             tj, flavour = sys.argv[3], sys.argv[4]
             doc = json.load(open(tj)) if os.path.exists(tj) else {}
             doc[flavour] = {"bytes_per_launch_4096": traffic, "kernel": main_k, "kernel_sources": kernel_source_hash(),
-                            "source": os.path.relpath(dst, ROOT)}
+                            "source": os.path.relpath(dst, ROOT), **extra}
             json.dump(doc, open(tj, "w"), indent=1, sort_keys=True)
     others = sorted(k for k in per if k != main_k)
     lines += ["", "other kernels of the run: " + ", ".join(o.split("(")[0] for o in others)]
