@@ -64,14 +64,51 @@ def _clear(v) -> int:
     return v if isinstance(v, int) else int.from_bytes(v, "big")
 
 
+class _DeviceStore:
+    """The backend's own store of ciphertexts in device memory, with the mapping interface the worker
+    uses: writing uploads, reading downloads, operator results are entered by the backend itself
+    (`mark`).  Ciphertexts cross PCIe when they enter (inputs) and when somebody asks for them
+    (decryption requests), not between events."""
+
+    def __init__(self, backend):
+        self.b = backend
+        self.known: set = set()
+
+    def __contains__(self, h) -> bool:
+        return bytes(h) in self.known
+
+    def __getitem__(self, h) -> bytes:
+        if bytes(h) not in self.known:
+            raise KeyError(bytes(h).hex())
+        return self.b.store_get(bytes(h))
+
+    def __setitem__(self, h, ct: bytes):
+        self.b.store_put(bytes(h), ct)
+        self.known.add(bytes(h))
+
+    def update(self, d: dict):
+        for k, v in d.items():
+            self[k] = v
+
+    def mark(self, h):
+        self.known.add(bytes(h))
+
+    def __len__(self) -> int:
+        return len(self.known)
+
+
 class Coprocessor:
     """backend: an object with evaluate_batch(op, width, lhs[], rhs[]|None, cond[]|None),
     evaluate(op, width, lhs, rhs, cond), encrypt(value, width, trivial=True) and
-    rand(width, seed16, random_bits) -- fhe_amd.native.Context is one."""
+    rand(width, seed16, random_bits) -- fhe_amd.native.Context is one.
+    resident: keep the ciphertexts in the backend's device store and run the events on handles
+    (store_put / store_get / evaluate_batch_handles / evaluate_fused_handles); the default when the
+    backend has such a store.  Results are bit-identical to the host-buffer route."""
 
-    def __init__(self, backend, fuse: bool = True):
+    def __init__(self, backend, fuse: bool = True, resident: bool | None = None):
         self.backend = backend
-        self.store: dict = {}
+        self.resident = hasattr(backend, "evaluate_batch_handles") if resident is None else resident
+        self.store = _DeviceStore(backend) if self.resident else {}
         self.launches = 0          # evaluate_batch / evaluate_fused / single calls issued
         self.executed = 0
         self.fuse = fuse and hasattr(backend, "evaluate_fused")
@@ -141,8 +178,19 @@ class Coprocessor:
             shapes.setdefault((steps, widths), []).append((members, inputs))
         fused_ids = set()
         for (steps, widths), insts in shapes.items():
-            cols = [[self.store[inp[k]] for _, inp in insts] for k in range(len(widths))]
             outs = list(range(len(widths), len(widths) + len(steps)))
+            if self.resident:
+                cols = [[inp[k] for _, inp in insts] for k in range(len(widths))]
+                out_h = [[bytes(ops[members[sidx]].args["result"]) for members, _ in insts] for sidx in range(len(steps))]
+                self.backend.evaluate_fused_handles(list(steps), list(widths), cols, outs, out_h)
+                self.launches += 1
+                for members, _ in insts:
+                    for i in members:
+                        self.store.mark(ops[i].args["result"])
+                        fused_ids.add(id(ops[i]))
+                self.executed += sum(len(m) for m, _ in insts)
+                continue
+            cols = [[self.store[inp[k]] for _, inp in insts] for k in range(len(widths))]
             out_w = [1 if op in ("eq", "ne", "ge", "gt", "le", "lt") else w for op, w, _, _, _ in steps]
             res = self.backend.evaluate_fused(list(steps), list(widths), cols, outs, out_w)
             self.launches += 1
@@ -200,7 +248,37 @@ class Coprocessor:
             return ("sel", handle_width(a["ifTrue"]))
         return (e.name, id(e))     # executed one by one
 
+    def _run_group_resident(self, key, evs) -> dict:
+        """The same on handles: operands and results stay in the backend's device store."""
+        B = self.backend
+        kind = key[0]
+        res_h = [bytes(e.args["result"]) for e in evs]
+        if kind == "bin":
+            _, op, width, scalar = key
+            if not scalar and op in ("shl", "shr", "rotl", "rotr"):
+                for e in evs:
+                    if handle_width(e.args["rhs"]) != 8:
+                        raise ValueError("shift and rotation amounts are euint8")
+            rhs = [_clear(e.args["rhs"]) if scalar else bytes(e.args["rhs"]) for e in evs]
+            B.evaluate_batch_handles(op, width, [bytes(e.args["lhs"]) for e in evs], rhs, None, res_h)
+        elif kind == "un":
+            _, op, width = key
+            B.evaluate_batch_handles(op, width, [bytes(e.args["ct"]) for e in evs], None, None, res_h)
+        elif kind == "sel":
+            B.evaluate_batch_handles("select", key[1], [bytes(e.args["ifTrue"]) for e in evs],
+                                     [bytes(e.args["ifFalse"]) for e in evs], [bytes(e.args["control"]) for e in evs], res_h)
+        else:
+            (e,) = evs
+            self.launches += 1
+            return {res_h[0]: self._run_single(e)}     # made on the host (trivial encryption, cast, random): uploaded by the caller
+        self.launches += 1
+        for h in res_h:
+            self.store.mark(h)
+        return {}
+
     def _run_group(self, key, evs) -> dict:
+        if self.resident:
+            return self._run_group_resident(key, evs)
         B = self.backend
         out = {}
         kind = key[0]

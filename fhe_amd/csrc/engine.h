@@ -66,6 +66,8 @@ void launch_lin_batch(u64* arena, const LinOp* ops, int nops, size_t instances, 
                       hipStream_t st);
 void launch_blocks_move(u64* arena, size_t instances, size_t inst_stride_blocks, const u32* idx, u32 first, u32 nblocks,
                         u64* flat, size_t ct_words, u32 header_words, bool to_arena, hipStream_t st);
+void launch_blocks_move_ptrs(u64* arena, size_t instances, size_t inst_stride_blocks, const u32* idx, u32 first,
+                             u32 nblocks, u64* const* ptrs, bool to_arena, hipStream_t st);
 void launch_ksk_colsum(const u64* ksk, int rows, int cols, int half_base, u64* colsum, hipStream_t st);
 // dig_scratch: keyswitch_scratch_words(count, big) 32-bit words of device memory
 void launch_keyswitch(const u64* ksk, const u64* colsum, const u64* in, u32* dig_scratch, u64* out, size_t count,

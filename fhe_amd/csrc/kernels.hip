@@ -1895,6 +1895,26 @@ void launch_blocks_move(u64* arena, size_t instances, size_t inst_stride_blocks,
                        first, flat, ct_words, header_words, to_arena ? 1 : 0);
 }
 
+// The same between the arena and ciphertexts that live one by one in device memory (the context's
+// ciphertext store): ptrs[inst] is the first block of ciphertext `inst`, its blocks back to back.
+__global__ void __launch_bounds__(256) k_blocks_move_ptrs(u64* __restrict__ arena, size_t inst_stride_blocks,
+                                                          const u32* __restrict__ idx, u32 first,
+                                                          u64* const* __restrict__ ptrs, int to_arena) {
+    const u32 j = blockIdx.x;
+    const size_t inst = blockIdx.y;
+    u64* a = arena + (inst * inst_stride_blocks + (idx ? idx[j] : first + j)) * (size_t)(N + 1);
+    u64* f = ptrs[inst] + (size_t)j * (N + 1);
+    if (to_arena) { for (int w = threadIdx.x; w <= N; w += blockDim.x) a[w] = f[w]; }
+    else { for (int w = threadIdx.x; w <= N; w += blockDim.x) f[w] = a[w]; }
+}
+
+void launch_blocks_move_ptrs(u64* arena, size_t instances, size_t inst_stride_blocks, const u32* idx, u32 first,
+                             u32 nblocks, u64* const* ptrs, bool to_arena, hipStream_t st) {
+    if (!instances || !nblocks) return;
+    hipLaunchKernelGGL(k_blocks_move_ptrs, dim3(nblocks, (unsigned)instances), dim3(256), 0, st, arena, inst_stride_blocks,
+                       idx, first, ptrs, to_arena ? 1 : 0);
+}
+
 void launch_lin_batch(u64* arena, const LinOp* ops, int nops, size_t instances, size_t inst_stride_blocks, u64 delta,
                       hipStream_t st) {
     hipLaunchKernelGGL(k_lin_batch, dim3((unsigned)(instances * nops)), dim3(256), 0, st, arena, ops, nops,

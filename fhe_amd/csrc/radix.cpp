@@ -10,6 +10,7 @@
 #include <string>
 #include <thread>
 #include <tuple>
+#include <unordered_map>
 
 #include "ctx.h"
 #include "radix_program.h"
@@ -91,7 +92,56 @@ struct Compiled {
 }  // namespace
 
 typedef std::array<uint8_t, 32> Scalar;
+
+// ---- the context's ciphertext store: ciphertexts resident in device memory under 32-byte handles.
+// Memory comes in slabs per ciphertext size (one hipMalloc serves many entries) and goes back to a
+// free list when an entry is dropped or replaced; the slabs stay with the context.
+typedef std::array<uint8_t, 32> Handle;
+struct HandleHash {
+    size_t operator()(const Handle& h) const {
+        uint64_t a, b;
+        std::memcpy(&a, h.data(), 8);
+        std::memcpy(&b, h.data() + 13, 8);
+        return (size_t)(a ^ (b * 0x9E3779B97F4A7C15ull));
+    }
+};
+struct StoreEntry {
+    u64* dev = nullptr;       // nblocks blocks of N + 1 words
+    uint16_t width = 0;
+    uint32_t nblocks = 0;
+    uint8_t noise = 1, degree = 3;
+};
+struct lfhe_store {
+    std::unordered_map<Handle, StoreEntry, HandleHash> map;
+    std::map<uint32_t, std::vector<u64*>> free_list;   // by block count
+    std::vector<u64*> slabs;
+    uint64_t reserved = 0;                              // bytes of device memory held by the slabs
+    u64* alloc(uint32_t nblocks) {
+        auto& fl = free_list[nblocks];
+        if (fl.empty()) {
+            const size_t words = (size_t)nblocks * BLK_WORDS;
+            const size_t per = std::max<size_t>(1, std::min<size_t>(256, ((size_t)64 << 20) / (words * 8)));
+            u64* slab = nullptr;
+            HC(hipMalloc(&slab, per * words * 8));
+            slabs.push_back(slab);
+            reserved += per * words * 8;
+            for (size_t k = per; k-- > 0;) fl.push_back(slab + k * words);
+        }
+        u64* p = fl.back();
+        fl.pop_back();
+        return p;
+    }
+    void release(const StoreEntry& e) { if (e.dev) free_list[e.nblocks].push_back(e.dev); }
+    ~lfhe_store() { for (u64* s : slabs) (void)hipFree(s); }
+};
+static Handle handle_at(const uint8_t* handles, uint64_t i) {
+    Handle h;
+    std::memcpy(h.data(), handles + i * 32, 32);
+    return h;
+}
+
 struct lfhe_radix {
+    lfhe_store store;
     std::map<std::tuple<uint32_t, uint32_t, int, int, int, bool, Scalar>, std::unique_ptr<Compiled>> cache;
     uint64_t clock = 0;          // use counter
     size_t specialised = 0;      // entries whose key holds a clear operand
@@ -202,11 +252,38 @@ Compiled& compiled_for(lfhe_ctx* ctx, uint32_t op, uint32_t width, int ln, int r
     return ref;
 }
 
-// ciphertext i of an operand array of stride `stride` bytes: header check, returns noise level
-int check_operand(const uint8_t* base, uint64_t n, uint32_t width) {
+// An operand array of n ciphertexts: the caller's host array (per ciphertext a header and its blocks), or n
+// handles of 32 bytes into the context's device store.  Results likewise.
+struct Src {
+    const uint8_t* host = nullptr;
+    const uint8_t* handles = nullptr;
+    explicit operator bool() const { return host || handles; }
+    Src at(uint64_t off, uint64_t stride) const { return Src{host ? host + off * stride : nullptr, handles ? handles + off * 32 : nullptr}; }
+};
+struct Dst {
+    uint8_t* host = nullptr;
+    const uint8_t* handles = nullptr;
+    explicit operator bool() const { return host || handles; }
+    Dst at(uint64_t off, uint64_t stride) const { return Dst{host ? host + off * stride : nullptr, handles ? handles + off * 32 : nullptr}; }
+};
+
+const StoreEntry& stored(lfhe_ctx* ctx, const uint8_t* handles, uint64_t i, uint32_t width) {
+    if (!ctx->radix) throw std::invalid_argument("unknown handle: the store is empty");
+    const auto it = ctx->radix->store.map.find(handle_at(handles, i));
+    if (it == ctx->radix->store.map.end()) throw std::invalid_argument("unknown handle");
+    if (it->second.width != width) throw std::invalid_argument("stored ciphertext has another width than the operation");
+    return it->second;
+}
+
+// header (or store entry) check of every ciphertext of an operand array; returns the largest noise level
+int check_operand(lfhe_ctx* ctx, const Src& a, uint64_t n, uint32_t width) {
     int noise = 1;
+    if (a.handles) {
+        for (uint64_t i = 0; i < n; ++i) noise = std::max<int>(noise, stored(ctx, a.handles, i, width).noise);
+        return noise;
+    }
     const uint64_t stride = ct_bytes(width);
-    for (uint64_t i = 0; i < n; ++i) noise = std::max<int>(noise, parse_header(base + i * stride, width).noise_level);
+    for (uint64_t i = 0; i < n; ++i) noise = std::max<int>(noise, parse_header(a.host + i * stride, width).noise_level);
     return noise;
 }
 
@@ -250,19 +327,82 @@ void download_array(Engine& E, u64* staging, u64* arena, uint32_t nblocks_inst, 
     HC(hipMemcpyAsync(dst, staging, n * ct_stride, hipMemcpyDeviceToHost, E.stream()));
 }
 
-void run_batch(lfhe_ctx* ctx, uint32_t op, uint32_t width, uint64_t n, const uint8_t* lhs, const uint8_t* rhs,
-               bool rhs_scalar, const uint8_t* cond, uint8_t* out) {
+// device tables of per-instance pointers, alive until the call has synchronised
+typedef std::vector<DevBuf<u64*>> PtrTables;
+
+// an operand array into arena blocks first .. first + nb - 1 of every instance
+void load_operand(lfhe_ctx* ctx, u64* staging, u64* arena, uint32_t nblocks_inst, const Src& a, uint32_t width,
+                  uint32_t first, uint64_t n, PtrTables& keep) {
+    Engine& E = *ctx->eng;
+    const uint32_t nb = blocks_of(width);
+    if (!a.handles) {
+        upload_array(E, staging, arena, nblocks_inst, a.host, ct_bytes(width), first, nb, n);
+        return;
+    }
+    std::vector<u64*> ptrs(n);
+    for (uint64_t i = 0; i < n; ++i) ptrs[i] = stored(ctx, a.handles, i, width).dev;
+    keep.emplace_back(n);
+    HC(hipMemcpy(keep.back().p, ptrs.data(), n * sizeof(u64*), hipMemcpyHostToDevice));
+    launch_blocks_move_ptrs(arena, n, nblocks_inst, nullptr, first, nb, keep.back().p, true, E.stream());
+    HC(hipGetLastError());
+}
+
+// Result entries of a call that writes into the store: allocated up front, entered under their handles
+// once the call has finished (an entry that already has the handle is replaced), given back if it fails.
+struct FreshEntries {
+    lfhe_store& S;
+    std::vector<std::pair<Handle, StoreEntry>> items;
+    bool committed = false;
+    explicit FreshEntries(lfhe_store& s) : S(s) {}
+    ~FreshEntries() { if (!committed) for (auto& it : items) S.release(it.second); }
+    void commit() {
+        for (auto& it : items) {
+            auto f = S.map.find(it.first);
+            if (f != S.map.end()) { S.release(f->second); f->second = it.second; }
+            else S.map.emplace(it.first, it.second);
+        }
+        committed = true;
+    }
+};
+
+// arena blocks `blocks` (device list of nb block numbers) of every instance out to a result array
+void store_result(lfhe_ctx* ctx, u64* staging, u64* arena, uint32_t nblocks_inst, const u32* blocks, uint32_t nb,
+                  const Dst& out, const CtHeader& h, uint64_t n, PtrTables& keep, FreshEntries& fresh) {
+    Engine& E = *ctx->eng;
+    if (!out.handles) {
+        download_array(E, staging, arena, nblocks_inst, blocks, nb, out.host, ct_bytes(h.bit_width), n);
+        return;
+    }
+    std::vector<u64*> ptrs(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        StoreEntry e;
+        e.dev = fresh.S.alloc(nb);
+        e.width = h.bit_width; e.nblocks = nb; e.noise = h.noise_level; e.degree = h.degree;
+        fresh.items.emplace_back(handle_at(out.handles, i), e);
+        ptrs[i] = e.dev;
+    }
+    keep.emplace_back(n);
+    HC(hipMemcpy(keep.back().p, ptrs.data(), n * sizeof(u64*), hipMemcpyHostToDevice));
+    launch_blocks_move_ptrs(arena, n, nblocks_inst, blocks, 0, nb, keep.back().p, false, E.stream());
+    HC(hipGetLastError());
+}
+
+void run_batch(lfhe_ctx* ctx, uint32_t op, uint32_t width, uint64_t n, const Src& lhs, const Src& rhs_src,
+               bool rhs_scalar, const Src& cond, const Dst& out) {
+    const uint8_t* rhs = rhs_src.host;    // clear operands are always the caller's (32 bytes each)
+    if (rhs_scalar && rhs_src.handles) throw std::invalid_argument("a clear operand is not a handle");
     if (!width_ok(width)) throw std::invalid_argument("unsupported bit width");
     if (!n) return;
     if (!lhs || !out) throw std::invalid_argument("null operand");
     if (!ctx->eng->has_keys()) throw std::logic_error("server keys not loaded");
     const bool unary = op == LFHE_OP_NOT || op == LFHE_OP_NEG;
-    if (!unary && !rhs) throw std::invalid_argument("missing right operand");
+    if (!unary && !rhs_src) throw std::invalid_argument("missing right operand");
     if (op == LFHE_OP_SELECT && !cond) throw std::invalid_argument("select needs a condition");
-    const int ln = check_operand(lhs, n, width);
+    if (!ctx->radix) ctx->radix.reset(new lfhe_radix());
+    const int ln = check_operand(ctx, lhs, n, width);
     const uint32_t rhs_width = shift_op(op) ? 8 : width;  // shift amounts are euint8
-    const int rn = (unary || rhs_scalar) ? 1 : check_operand(rhs, n, rhs_width);
-    const int cn = op == LFHE_OP_SELECT ? check_operand(cond, n, 1) : 1;
+    const int rn = (unary || rhs_scalar) ? 1 : check_operand(ctx, rhs_src, n, rhs_width);
+    const int cn = op == LFHE_OP_SELECT ? check_operand(ctx, cond, n, 1) : 1;
     // a specialised program serves instances that share the clear operand: the caller groups them
     bool special = rhs_scalar && specialised_op(op);
     if (special)
@@ -287,17 +427,19 @@ void run_batch(lfhe_ctx* ctx, uint32_t op, uint32_t width, uint64_t n, const uin
     if (const uint64_t cap = arena_capacity(inst_bytes); n > cap) {   // too many instances for one arena
         const uint64_t rs = rhs_scalar ? 32 : ct_bytes(rhs_width), os = ct_bytes(P.out_width);
         for (uint64_t off = 0; off < n; off += cap)
-            run_batch(ctx, op, width, std::min(cap, n - off), lhs + off * in_stride, rhs ? rhs + off * rs : nullptr,
-                      rhs_scalar, cond ? cond + off * ct_bytes(1) : nullptr, out + off * os);
+            run_batch(ctx, op, width, std::min(cap, n - off), lhs.at(off, in_stride), rhs_src.at(off, rs),
+                      rhs_scalar, cond.at(off, ct_bytes(1)), out.at(off, os));
         return;
     }
     DevBuf<u64> arena(n * (size_t)P.nblocks * BLK_WORDS);
     const uint64_t out_stride = ct_bytes(P.out_width);
     DevBuf<u64> staging(n * std::max<uint64_t>({in_stride, ct_bytes(rhs_width), out_stride}) / 8);
-    auto upload = [&](const uint8_t* src, uint64_t sstride, uint32_t first, uint32_t nb) {
-        upload_array(E, staging.p, arena.p, P.nblocks, src, sstride, first, nb, n);
+    PtrTables tables;
+    FreshEntries fresh(ctx->radix->store);
+    auto upload = [&](const Src& src, uint32_t w, uint32_t first) {
+        load_operand(ctx, staging.p, arena.p, P.nblocks, src, w, first, n, tables);
     };
-    upload(lhs, in_stride, P.lhs[0], m);
+    upload(lhs, width, P.lhs[0]);
     DevBuf<u64> scal;
     if (!unary && !special) {
         if (rhs_scalar) {
@@ -315,18 +457,20 @@ void run_batch(lfhe_ctx* ctx, uint32_t op, uint32_t width, uint64_t n, const uin
             launch_fill_trivial(arena.p, n, P.nblocks, P.rhs[0], m, scal.p, st);
             HC(hipGetLastError());
         } else {
-            upload(rhs, ct_bytes(rhs_width), P.rhs[0], blocks_of(rhs_width));
+            upload(rhs_src, rhs_width, P.rhs[0]);
         }
     }
-    if (op == LFHE_OP_SELECT) upload(cond, ct_bytes(1), P.cond[0], 1);
+    if (op == LFHE_OP_SELECT) upload(cond, 1, P.cond[0]);
 
     replay(ctx, C, arena.p, n);
     DevBuf<u32> out_blocks(P.out.size());
     HC(hipMemcpyAsync(out_blocks.p, P.out.data(), P.out.size() * sizeof(u32), hipMemcpyHostToDevice, st));
-    download_array(E, staging.p, arena.p, P.nblocks, out_blocks.p, (uint32_t)P.out.size(), out, out_stride, n);
+    const CtHeader h{CT_MAGIC, 1, (uint16_t)P.out_width, (uint32_t)P.out.size(), P.out_noise, P.out_degree, 0};
+    store_result(ctx, staging.p, arena.p, P.nblocks, out_blocks.p, (uint32_t)P.out.size(), out, h, n, tables, fresh);
     E.sync();
-    CtHeader h{CT_MAGIC, 1, (uint16_t)P.out_width, (uint32_t)P.out.size(), P.out_noise, P.out_degree, 0};
-    for (uint64_t i = 0; i < n; ++i) std::memcpy(out + i * out_stride, &h, sizeof h);
+    fresh.commit();
+    if (out.host)
+        for (uint64_t i = 0; i < n; ++i) std::memcpy(out.host + i * out_stride, &h, sizeof h);
 }
 
 // replay of a compiled program over an arena holding `n` instances
@@ -344,17 +488,17 @@ void replay(lfhe_ctx* ctx, Compiled& C, u64* arena, uint64_t n) {
 }
 
 void run_fused(lfhe_ctx* ctx, const lfhe_step* steps, uint32_t nsteps, uint32_t n_inputs, const uint32_t* in_widths,
-               uint64_t n, const uint8_t* const* inputs, const int32_t* outputs, uint32_t n_outputs,
-               uint8_t* const* outs) {
+               uint64_t n, const Src* inputs, const int32_t* outputs, uint32_t n_outputs, const Dst* outs) {
     if (!steps || !nsteps || !in_widths || !inputs || !outputs || !n_outputs || !outs)
         throw std::invalid_argument("null or empty argument");
+    if (!ctx->radix) ctx->radix.reset(new lfhe_radix());
     if (!n) return;
     if (!ctx->eng->has_keys()) throw std::logic_error("server keys not loaded");
     std::vector<uint32_t> widths(in_widths, in_widths + n_inputs);
     std::vector<int> noises(n_inputs);
     for (uint32_t i = 0; i < n_inputs; ++i) {
         if (!width_ok(widths[i]) || !inputs[i]) throw std::invalid_argument("bad input");
-        noises[i] = check_operand(inputs[i], n, widths[i]);
+        noises[i] = check_operand(ctx, inputs[i], n, widths[i]);
     }
     std::string key((const char*)steps, nsteps * sizeof(lfhe_step));
     key.append((const char*)widths.data(), widths.size() * 4);
@@ -395,11 +539,11 @@ void run_fused(lfhe_ctx* ctx, const lfhe_step* steps, uint32_t nsteps, uint32_t 
     hipStream_t st = E.stream();
     const size_t inst_bytes = (size_t)P.nblocks * BLK_BYTES;
     if (const uint64_t cap = arena_capacity(inst_bytes); n > cap) {   // too many instances for one arena
-        std::vector<const uint8_t*> in_c(n_inputs);
-        std::vector<uint8_t*> out_c(n_outputs);
+        std::vector<Src> in_c(n_inputs);
+        std::vector<Dst> out_c(n_outputs);
         for (uint64_t off = 0; off < n; off += cap) {
-            for (uint32_t i = 0; i < n_inputs; ++i) in_c[i] = inputs[i] + off * ct_bytes(widths[i]);
-            for (uint32_t o = 0; o < n_outputs; ++o) out_c[o] = outs[o] + off * ct_bytes(P.out_widths[o]);
+            for (uint32_t i = 0; i < n_inputs; ++i) in_c[i] = inputs[i].at(off, ct_bytes(widths[i]));
+            for (uint32_t o = 0; o < n_outputs; ++o) out_c[o] = outs[o].at(off, ct_bytes(P.out_widths[o]));
             run_fused(ctx, steps, nsteps, n_inputs, in_widths, std::min(cap, n - off), in_c.data(), outputs, n_outputs,
                       out_c.data());
         }
@@ -410,22 +554,29 @@ void run_fused(lfhe_ctx* ctx, const lfhe_step* steps, uint32_t nsteps, uint32_t 
     for (uint32_t i = 0; i < n_inputs; ++i) widest = std::max(widest, ct_bytes(widths[i]));
     for (uint32_t o = 0; o < n_outputs; ++o) widest = std::max(widest, ct_bytes(P.out_widths[o]));
     DevBuf<u64> staging(n * widest / 8);
+    PtrTables tables;
+    FreshEntries fresh(ctx->radix->store);
     for (uint32_t i = 0; i < n_inputs; ++i)
-        upload_array(E, staging.p, arena.p, P.nblocks, inputs[i], ct_bytes(widths[i]), P.ins[i][0], blocks_of(widths[i]), n);
+        load_operand(ctx, staging.p, arena.p, P.nblocks, inputs[i], widths[i], P.ins[i][0], n, tables);
     replay(ctx, C, arena.p, n);
     std::vector<DevBuf<u32>> out_blocks;
+    auto header = [&](uint32_t o) {
+        return CtHeader{CT_MAGIC, 1, (uint16_t)P.out_widths[o], (uint32_t)P.outs[o].size(), P.out_noises[o], P.out_degrees[o], 0};
+    };
     for (uint32_t o = 0; o < n_outputs; ++o) {
         if (!outs[o]) throw std::invalid_argument("null output");
         out_blocks.emplace_back(P.outs[o].size());
         HC(hipMemcpyAsync(out_blocks.back().p, P.outs[o].data(), P.outs[o].size() * sizeof(u32), hipMemcpyHostToDevice, st));
-        download_array(E, staging.p, arena.p, P.nblocks, out_blocks.back().p, (uint32_t)P.outs[o].size(), outs[o],
-                       ct_bytes(P.out_widths[o]), n);
+        store_result(ctx, staging.p, arena.p, P.nblocks, out_blocks.back().p, (uint32_t)P.outs[o].size(), outs[o], header(o), n,
+                     tables, fresh);
     }
     E.sync();
+    fresh.commit();
     for (uint32_t o = 0; o < n_outputs; ++o) {
+        if (!outs[o].host) continue;
         const uint64_t stride = ct_bytes(P.out_widths[o]);
-        CtHeader h{CT_MAGIC, 1, (uint16_t)P.out_widths[o], (uint32_t)P.outs[o].size(), P.out_noises[o], P.out_degrees[o], 0};
-        for (uint64_t i = 0; i < n; ++i) std::memcpy(outs[o] + i * stride, &h, sizeof h);
+        const CtHeader h = header(o);
+        for (uint64_t i = 0; i < n; ++i) std::memcpy(outs[o].host + i * stride, &h, sizeof h);
     }
 }
 
@@ -977,20 +1128,23 @@ int32_t lfhe_program_dump(uint32_t op, uint32_t bit_width, int32_t lhs_noise, in
     return LFHE_OK;
 }
 
-int32_t lfhe_evaluate_batch(lfhe_ctx* ctx, uint32_t op, uint32_t bit_width, uint64_t n, const uint8_t* lhs,
-                            const uint8_t* rhs, int32_t rhs_is_scalar, const uint8_t* cond, uint8_t* out) {
+// n instances of one operator; a specialised operator (shift amount, divisor) with clear operands that
+// differ between instances runs once per distinct value, on the instances that share it
+static int32_t evaluate_batch_impl(lfhe_ctx* ctx, uint32_t op, uint32_t bit_width, uint64_t n, const Src& lhs,
+                                   const Src& rhs_src, int32_t rhs_is_scalar, const Src& cond, const Dst& out) {
     if (!ctx) return LFHE_ERR_ARG;
     if (op == LFHE_OP_CAST) {
         ctx->err = "cast has no batch form: it moves no data through the GPU";
         return LFHE_ERR_UNSUPPORTED;
     }
     int32_t rc = guarded(ctx, [&]() -> int32_t {
+        const uint8_t* rhs = rhs_src.host;
         const bool special = rhs_is_scalar && specialised_op(op) && rhs && n > 1;
         bool uniform = true;
         if (special)
             for (uint64_t i = 1; i < n && uniform; ++i) uniform = !std::memcmp(rhs, rhs + i * 32, 32);
         if (uniform) {
-            run_batch(ctx, op, bit_width, n, lhs, rhs, rhs_is_scalar != 0, cond, out);
+            run_batch(ctx, op, bit_width, n, lhs, rhs_src, rhs_is_scalar != 0, cond, out);
             return LFHE_OK;
         }
         // instances grouped by their clear operand; each group is one specialised run
@@ -1003,13 +1157,24 @@ int32_t lfhe_evaluate_batch(lfhe_ctx* ctx, uint32_t op, uint32_t bit_width, uint
         }
         const uint64_t stride = ct_bytes(bit_width);
         for (const auto& [sc, idx] : groups) {
-            std::vector<uint8_t> gl(idx.size() * stride), gr(idx.size() * 32), go(idx.size() * stride);
-            for (size_t k = 0; k < idx.size(); ++k) {
-                std::memcpy(gl.data() + k * stride, lhs + idx[k] * stride, stride);
-                std::memcpy(gr.data() + k * 32, sc.data(), 32);
+            std::vector<uint8_t> gr(idx.size() * 32);
+            for (size_t k = 0; k < idx.size(); ++k) std::memcpy(gr.data() + k * 32, sc.data(), 32);
+            if (lhs.handles) {   // handles in, handles out: the group's handles side by side
+                if (!out.handles) throw std::invalid_argument("operands from the store need results into the store");
+                std::vector<uint8_t> gl(idx.size() * 32), go(idx.size() * 32);
+                for (size_t k = 0; k < idx.size(); ++k) {
+                    std::memcpy(gl.data() + k * 32, lhs.handles + idx[k] * 32, 32);
+                    std::memcpy(go.data() + k * 32, out.handles + idx[k] * 32, 32);
+                }
+                run_batch(ctx, op, bit_width, idx.size(), Src{nullptr, gl.data()}, Src{gr.data(), nullptr}, true, Src{},
+                          Dst{nullptr, go.data()});
+                continue;
             }
-            run_batch(ctx, op, bit_width, idx.size(), gl.data(), gr.data(), true, nullptr, go.data());
-            for (size_t k = 0; k < idx.size(); ++k) std::memcpy(out + idx[k] * stride, go.data() + k * stride, stride);
+            std::vector<uint8_t> gl(idx.size() * stride), go(idx.size() * stride);
+            for (size_t k = 0; k < idx.size(); ++k) std::memcpy(gl.data() + k * stride, lhs.host + idx[k] * stride, stride);
+            run_batch(ctx, op, bit_width, idx.size(), Src{gl.data(), nullptr}, Src{gr.data(), nullptr}, true, Src{},
+                      Dst{go.data(), nullptr});
+            for (size_t k = 0; k < idx.size(); ++k) std::memcpy(out.host + idx[k] * stride, go.data() + k * stride, stride);
         }
         return LFHE_OK;
     });
@@ -1017,15 +1182,123 @@ int32_t lfhe_evaluate_batch(lfhe_ctx* ctx, uint32_t op, uint32_t bit_width, uint
     return rc;
 }
 
+int32_t lfhe_evaluate_batch(lfhe_ctx* ctx, uint32_t op, uint32_t bit_width, uint64_t n, const uint8_t* lhs,
+                            const uint8_t* rhs, int32_t rhs_is_scalar, const uint8_t* cond, uint8_t* out) {
+    return evaluate_batch_impl(ctx, op, bit_width, n, Src{lhs, nullptr}, Src{rhs, nullptr}, rhs_is_scalar, Src{cond, nullptr},
+                               Dst{out, nullptr});
+}
+
+int32_t lfhe_evaluate_batch_handles(lfhe_ctx* ctx, uint32_t op, uint32_t bit_width, uint64_t n, const uint8_t* lhs_handles,
+                                    const uint8_t* rhs, int32_t rhs_is_scalar, const uint8_t* cond_handles,
+                                    const uint8_t* out_handles) {
+    return evaluate_batch_impl(ctx, op, bit_width, n, Src{nullptr, lhs_handles},
+                               rhs_is_scalar ? Src{rhs, nullptr} : Src{nullptr, rhs}, rhs_is_scalar, Src{nullptr, cond_handles},
+                               Dst{nullptr, out_handles});
+}
+
 int32_t lfhe_evaluate_fused(lfhe_ctx* ctx, const lfhe_step* steps, uint32_t nsteps, uint32_t n_inputs,
                             const uint32_t* input_widths, uint64_t n, const uint8_t* const* inputs,
                             const int32_t* outputs, uint32_t n_outputs, uint8_t* const* outs) {
     int32_t rc = guarded(ctx, [&]() -> int32_t {
-        run_fused(ctx, steps, nsteps, n_inputs, input_widths, n, inputs, outputs, n_outputs, outs);
+        if (!inputs || !outs) throw std::invalid_argument("null or empty argument");
+        std::vector<Src> in(n_inputs);
+        std::vector<Dst> out(n_outputs);
+        for (uint32_t i = 0; i < n_inputs; ++i) in[i].host = inputs[i];
+        for (uint32_t o = 0; o < n_outputs; ++o) out[o].host = outs[o];
+        run_fused(ctx, steps, nsteps, n_inputs, input_widths, n, in.data(), outputs, n_outputs, out.data());
         return LFHE_OK;
     });
     if (rc == LFHE_ERR_ARG && ctx->err == "operator not supported") rc = LFHE_ERR_UNSUPPORTED;
     return rc;
+}
+
+int32_t lfhe_evaluate_fused_handles(lfhe_ctx* ctx, const lfhe_step* steps, uint32_t nsteps, uint32_t n_inputs,
+                                    const uint32_t* input_widths, uint64_t n, const uint8_t* const* input_handles,
+                                    const int32_t* outputs, uint32_t n_outputs, const uint8_t* const* out_handles) {
+    int32_t rc = guarded(ctx, [&]() -> int32_t {
+        if (!input_handles || !out_handles) throw std::invalid_argument("null or empty argument");
+        std::vector<Src> in(n_inputs);
+        std::vector<Dst> out(n_outputs);
+        for (uint32_t i = 0; i < n_inputs; ++i) in[i].handles = input_handles[i];
+        for (uint32_t o = 0; o < n_outputs; ++o) out[o].handles = out_handles[o];
+        run_fused(ctx, steps, nsteps, n_inputs, input_widths, n, in.data(), outputs, n_outputs, out.data());
+        return LFHE_OK;
+    });
+    if (rc == LFHE_ERR_ARG && ctx->err == "operator not supported") rc = LFHE_ERR_UNSUPPORTED;
+    return rc;
+}
+
+// ---- the ciphertext store itself
+int32_t lfhe_store_put(lfhe_ctx* ctx, const uint8_t handle[32], const uint8_t* ct, uint64_t ct_len) {
+    return guarded(ctx, [&]() -> int32_t {
+        if (!handle || !ct || ct_len < sizeof(CtHeader)) throw std::invalid_argument("null or short argument");
+        CtHeader h;
+        std::memcpy(&h, ct, sizeof h);
+        if (h.magic != CT_MAGIC || h.version != 1 || !width_ok(h.bit_width) || h.nblocks != blocks_of(h.bit_width) ||
+            ct_len != ct_bytes(h.bit_width))
+            throw std::invalid_argument("malformed ciphertext");
+        if (h.noise_level < 1 || h.noise_level > 2 || h.degree > 3) throw std::invalid_argument("ciphertext metadata out of range");
+        if (!ctx->radix) ctx->radix.reset(new lfhe_radix());
+        HC(hipSetDevice(ctx->eng->device()));
+        lfhe_store& S = ctx->radix->store;
+        FreshEntries fresh(S);
+        StoreEntry e;
+        e.dev = S.alloc(h.nblocks);
+        e.width = h.bit_width; e.nblocks = h.nblocks; e.noise = h.noise_level; e.degree = h.degree;
+        fresh.items.emplace_back(handle_at(handle, 0), e);
+        HC(hipMemcpy(e.dev, ct + sizeof h, (size_t)h.nblocks * BLK_BYTES, hipMemcpyHostToDevice));
+        fresh.commit();
+        return LFHE_OK;
+    });
+}
+
+int32_t lfhe_store_get(lfhe_ctx* ctx, const uint8_t handle[32], uint8_t* out, uint64_t* out_len) {
+    return guarded(ctx, [&]() -> int32_t {
+        if (!handle || !out_len) throw std::invalid_argument("null argument");
+        if (!ctx->radix) throw std::invalid_argument("unknown handle");
+        const auto it = ctx->radix->store.map.find(handle_at(handle, 0));
+        if (it == ctx->radix->store.map.end()) throw std::invalid_argument("unknown handle");
+        const StoreEntry& e = it->second;
+        const uint64_t need = ct_bytes(e.width);
+        if (!out) { *out_len = need; return LFHE_OK; }
+        if (*out_len < need) { *out_len = need; return LFHE_ERR_SIZE; }
+        HC(hipSetDevice(ctx->eng->device()));
+        ctx->eng->sync();
+        const CtHeader h{CT_MAGIC, 1, e.width, e.nblocks, e.noise, e.degree, 0};
+        std::memcpy(out, &h, sizeof h);
+        HC(hipMemcpy(out + sizeof h, e.dev, (size_t)e.nblocks * BLK_BYTES, hipMemcpyDeviceToHost));
+        *out_len = need;
+        return LFHE_OK;
+    });
+}
+
+int32_t lfhe_store_drop(lfhe_ctx* ctx, const uint8_t handle[32]) {
+    return guarded(ctx, [&]() -> int32_t {
+        if (!handle) throw std::invalid_argument("null argument");
+        if (!ctx->radix) throw std::invalid_argument("unknown handle");
+        lfhe_store& S = ctx->radix->store;
+        const auto it = S.map.find(handle_at(handle, 0));
+        if (it == S.map.end()) throw std::invalid_argument("unknown handle");
+        ctx->eng->sync();          // nothing in flight reads the blocks that go back to the free list
+        S.release(it->second);
+        S.map.erase(it);
+        return LFHE_OK;
+    });
+}
+
+int32_t lfhe_store_stat(const lfhe_ctx* ctx, const uint8_t handle[32], uint64_t* entries, uint64_t* device_bytes,
+                        uint32_t* bit_width) {
+    if (!ctx) return LFHE_ERR_ARG;
+    const lfhe_store* S = ctx->radix ? &ctx->radix->store : nullptr;
+    if (entries) *entries = S ? S->map.size() : 0;
+    if (device_bytes) *device_bytes = S ? S->reserved : 0;
+    if (handle) {
+        if (!S) return LFHE_ERR_ARG;
+        const auto it = S->map.find(handle_at(handle, 0));
+        if (it == S->map.end()) return LFHE_ERR_ARG;
+        if (bit_width) *bit_width = it->second.width;
+    }
+    return LFHE_OK;
 }
 
 int32_t lfhe_fused_dump(const lfhe_step* steps, uint32_t nsteps, uint32_t n_inputs, const uint32_t* input_widths,

@@ -121,6 +121,12 @@ def load():
         "lfhe_program_dump": (i32, [u32, u32, i32, i32, i32, C.c_char_p, C.c_char_p, pu64]),
         "lfhe_evaluate_fused": (i32, [vp, vp, u32, u32, pu32, u64, vp, vp, u32, vp]),
         "lfhe_fused_dump": (i32, [vp, u32, u32, pu32, vp, vp, u32, C.c_char_p, pu64]),
+        "lfhe_store_put": (i32, [vp, C.c_char_p, vp, u64]),
+        "lfhe_store_get": (i32, [vp, C.c_char_p, vp, pu64]),
+        "lfhe_store_drop": (i32, [vp, C.c_char_p]),
+        "lfhe_store_stat": (i32, [vp, C.c_char_p, pu64, pu64, pu32]),
+        "lfhe_evaluate_batch_handles": (i32, [vp, u32, u32, u64, vp, vp, i32, vp, vp]),
+        "lfhe_evaluate_fused_handles": (i32, [vp, vp, u32, u32, pu32, u64, vp, vp, u32, vp]),
         "lfhe_rand": (i32, [vp, u32, C.c_char_p, u32, vp, pu64]),
         "lfhe_pbs_count": (i32, [vp, pu64]),
         "lfhe_bsk_image_form": (i32, [vp, C.POINTER(C.c_uint32)]),
@@ -471,6 +477,75 @@ class Context:
         self._ck(self._L.lfhe_evaluate_fused(self._h, arr, len(steps), len(in_widths), w, n, in_ptrs, o, len(outputs),
                                              out_ptrs))
         return [self._rows(a, n, sz, as_array) for a, sz in zip(outs, sizes)]
+
+    # ---- ciphertexts resident on the GPU, addressed by 32-byte handles
+    @staticmethod
+    def _handles(hs, n: int | None = None) -> np.ndarray:
+        a = np.frombuffer(b"".join(bytes(h) for h in hs), dtype=np.uint8)
+        if a.size != 32 * len(hs) or (n is not None and len(hs) != n):
+            raise ValueError("handles are 32 bytes each, one per instance")
+        return a
+
+    def store_put(self, handle: bytes, ct: bytes):
+        buf = np.frombuffer(ct, dtype=np.uint8)
+        self._ck(self._L.lfhe_store_put(self._h, bytes(handle), _ptr(buf), buf.size))
+
+    def store_get(self, handle: bytes) -> bytes:
+        n = C.c_uint64(0)
+        self._ck(self._L.lfhe_store_get(self._h, bytes(handle), None, C.byref(n)))
+        buf = np.empty(n.value, dtype=np.uint8)
+        self._ck(self._L.lfhe_store_get(self._h, bytes(handle), _ptr(buf), C.byref(n)))
+        return buf.tobytes()
+
+    def store_drop(self, handle: bytes):
+        self._ck(self._L.lfhe_store_drop(self._h, bytes(handle)))
+
+    def store_has(self, handle: bytes) -> bool:
+        return self._L.lfhe_store_stat(self._h, bytes(handle), None, None, None) == LFHE_OK
+
+    def store_stat(self):
+        """(entries, device bytes held by the store)."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._ck(self._L.lfhe_store_stat(self._h, None, C.byref(a), C.byref(b), None))
+        return a.value, b.value
+
+    def evaluate_batch_handles(self, op: str, bit_width: int, lhs: list, rhs, cond, out: list):
+        """evaluate_batch on stored ciphertexts: lhs / rhs / cond / out are lists of handles (rhs may be a
+        list of ints: clear operands); the results are entered under the `out` handles."""
+        n = len(lhs)
+        if n == 0:
+            return
+        scalar = rhs is not None and len(rhs) > 0 and isinstance(rhs[0], int)
+        A = self._handles(lhs)
+        if rhs is None:
+            B = None
+        elif scalar:
+            if len(rhs) != n:
+                raise ValueError(f"rhs: {len(rhs)} clear operands for {n} instances")
+            B = np.frombuffer(b"".join(le32(v % (1 << 256)) for v in rhs), dtype=np.uint8)
+        else:
+            B = self._handles(rhs, n)
+        Cn = None if cond is None else self._handles(cond, n)
+        O = self._handles(out, n)
+        self._ck(self._L.lfhe_evaluate_batch_handles(self._h, OPS[op], bit_width, n, _ptr(A), _ptr(B), 1 if scalar else 0,
+                                                     _ptr(Cn), _ptr(O)))
+
+    def evaluate_fused_handles(self, steps: list, in_widths: list, inputs: list, outputs: list, out_handles: list):
+        """evaluate_fused on stored ciphertexts: inputs[i] and out_handles[o] are lists of n handles."""
+        n = len(inputs[0])
+        if n == 0:
+            return
+        arr = make_steps(steps)
+        w = (C.c_uint32 * len(in_widths))(*in_widths)
+        o = (C.c_int32 * len(outputs))(*outputs)
+        if len(inputs) != len(in_widths) or len(out_handles) != len(outputs):
+            raise ValueError("one width per input, one handle list per output")
+        ins = [self._handles(col, n) for col in inputs]
+        outs = [self._handles(col, n) for col in out_handles]
+        in_ptrs = (C.c_void_p * len(ins))(*[a.ctypes.data for a in ins])
+        out_ptrs = (C.c_void_p * len(outs))(*[a.ctypes.data for a in outs])
+        self._ck(self._L.lfhe_evaluate_fused_handles(self._h, arr, len(steps), len(in_widths), w, n, in_ptrs, o,
+                                                     len(outputs), out_ptrs))
 
     # ---- compression for storage
     def compression_keygen(self):

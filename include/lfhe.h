@@ -260,6 +260,32 @@ typedef struct {
 int32_t lfhe_evaluate_fused(lfhe_ctx* ctx, const lfhe_step* steps, uint32_t nsteps, uint32_t n_inputs,
                             const uint32_t* input_widths, uint64_t n, const uint8_t* const* inputs,
                             const int32_t* outputs, uint32_t n_outputs, uint8_t* const* outs);
+/* ---- ciphertexts resident on the GPU, addressed by handle ----------------------------------------
+ * Replaces: the coprocessor's ciphertext store behind the executor events -- every event names its
+ * operands and its result by bytes32 handle (tests/fhevm-suite/e2e/test/utils.ts:182-214: lhs, rhs,
+ * result; test/instance.ts:137-139 reads a result back by handle) -- so that a chain of events keeps
+ * its ciphertexts in device memory and only inputs and decryption requests cross PCIe.
+ * lfhe_store_put: uploads a ciphertext under `handle` (an existing entry is replaced).
+ * lfhe_store_get: downloads it (size query as everywhere).  lfhe_store_drop: frees the entry.
+ * lfhe_store_stat: number of entries and device bytes held by the store (either may be NULL); with a
+ * handle, also whether it exists (LFHE_ERR_ARG if not) and its bit width.
+ * lfhe_evaluate_batch_handles: lfhe_evaluate_batch with every ciphertext operand given as a handle
+ * (arrays of n x 32 bytes; a clear right operand stays n x 32 bytes of values) and the results
+ * entered under out_handles; an unknown handle or a stored width that does not match is LFHE_ERR_ARG
+ * and nothing is stored.  lfhe_evaluate_fused_handles: the same for lfhe_evaluate_fused
+ * (input_handles[i] / out_handles[o]: n handles each).  Results are bit-identical to the host-buffer
+ * entry points. */
+int32_t lfhe_store_put(lfhe_ctx* ctx, const uint8_t handle[32], const uint8_t* ct, uint64_t ct_len);
+int32_t lfhe_store_get(lfhe_ctx* ctx, const uint8_t handle[32], uint8_t* out, uint64_t* out_len);
+int32_t lfhe_store_drop(lfhe_ctx* ctx, const uint8_t handle[32]);
+int32_t lfhe_store_stat(const lfhe_ctx* ctx, const uint8_t handle[32], uint64_t* entries, uint64_t* device_bytes,
+                        uint32_t* bit_width);
+int32_t lfhe_evaluate_batch_handles(lfhe_ctx* ctx, uint32_t op, uint32_t bit_width, uint64_t n, const uint8_t* lhs_handles,
+                                    const uint8_t* rhs /* n handles, or n clear values of 32 bytes */, int32_t rhs_is_scalar,
+                                    const uint8_t* cond_handles, const uint8_t* out_handles);
+int32_t lfhe_evaluate_fused_handles(lfhe_ctx* ctx, const lfhe_step* steps, uint32_t nsteps, uint32_t n_inputs,
+                                    const uint32_t* input_widths, uint64_t n, const uint8_t* const* input_handles,
+                                    const int32_t* outputs, uint32_t n_outputs, const uint8_t* const* out_handles);
 /* its schedule as JSON (no context, no GPU); input_noise may be NULL (all 1) */
 int32_t lfhe_fused_dump(const lfhe_step* steps, uint32_t nsteps, uint32_t n_inputs, const uint32_t* input_widths,
                         const int32_t* input_noise, const int32_t* outputs, uint32_t n_outputs, char* out,

@@ -68,6 +68,44 @@ class FusingMockBackend(MockBackend):
         return res
 
 
+class ResidentMockBackend(FusingMockBackend):
+    """The stand-in with a handle store of its own (the surface of the library's device store): what
+    crosses the "bus" is counted, so a test can see that a chain of events moves only its inputs in
+    and the requested results out."""
+
+    def __init__(self):
+        self._store = {}
+        self.uploads = self.downloads = 0
+
+    def store_put(self, handle, ct):
+        assert len(handle) == 32
+        self._store[bytes(handle)] = ct
+        self.uploads += 1
+
+    def store_get(self, handle):
+        self.downloads += 1
+        return self._store[bytes(handle)]
+
+    def store_drop(self, handle):
+        del self._store[bytes(handle)]
+
+    def evaluate_batch_handles(self, op, width, lhs, rhs, cond, out):
+        g = lambda col: None if col is None else [c if isinstance(c, int) else self._store[bytes(c)] for c in col]
+        for h, r in zip(out, self.evaluate_batch(op, width, g(lhs), g(rhs), g(cond))):
+            self._store[bytes(h)] = r
+
+    def evaluate_fused_handles(self, steps, in_widths, inputs, outputs, out_handles):
+        cols = [[self._store[bytes(h)] for h in col] for col in inputs]
+        out_w = []
+        for ref in outputs:
+            op, w = steps[ref - len(in_widths)][:2]
+            out_w.append(1 if op in ("eq", "ne", "ge", "gt", "le", "lt") else w)
+        res = self.evaluate_fused(steps, in_widths, cols, outputs, out_w)
+        for hs, col in zip(out_handles, res):
+            for h, r in zip(hs, col):
+                self._store[bytes(h)] = r
+
+
 # ---- a stand-in for fhe_amd.native.Context in the real ciphertext layout --------------------------
 import ctypes as _C
 import hashlib as _hashlib

@@ -165,6 +165,112 @@ def test_transactions_of_one_shape_are_fused():
     assert [tuple(b2.decrypt(cop2.get(h)) for h in o) for o in outs2] == plain2
 
 
+def test_resident_store_moves_only_inputs_and_requested_results():
+    """With a backend that keeps ciphertexts under handles the worker runs the events on handles: the
+    same results, and nothing crosses the bus between events."""
+    from tests.mock_engine import ResidentMockBackend
+    backend = ResidentMockBackend()
+    cop = Coprocessor(backend)
+    assert cop.resident
+    c = [0]
+
+    def new(w):
+        c[0] += 1
+        return mk_handle(c[0], w)
+    ev, outs, plain = _transfer_block(cop, backend.encrypt, 9, new)
+    x, y, r1, r2, r3, r4 = new(8), new(8), new(8), new(8), new(8), new(16)
+    cop.put(x, backend.encrypt(200, 8)); cop.put(y, backend.encrypt(100, 8))
+    ev += [Event("FheAdd", {"lhs": x, "rhs": y, "scalarByte": b"\x00", "result": r1}),
+           Event("FheMul", {"lhs": r1, "rhs": (3).to_bytes(32, "big"), "scalarByte": b"\x01", "result": r2}),
+           Event("FheNot", {"ct": y, "result": r3}),
+           Event("Cast", {"ct": r2, "toType": 3, "result": r4})]
+    uploads = backend.uploads
+    cop.execute(ev)
+    # the cast is made on the host (one download, one upload); everything else stayed where it was
+    assert backend.uploads - uploads <= 2 and backend.downloads <= 1
+    d = lambda h: backend.decrypt(cop.get(h))
+    assert [tuple(d(h) for h in o) for o in outs] == plain
+    assert (d(r1), d(r2), d(r3), d(r4)) == (44, 132, 155, 132)
+    assert backend.fused_calls == 2 and cop.executed == len(ev)
+    with pytest.raises(KeyError):
+        cop.get(new(8))
+    # the reference vectors through the handle route, too
+    b2 = ResidentMockBackend()
+    cop2 = Coprocessor(b2)
+    events, expect = kat_events(b2, cop2, KATS[:600])
+    cop2.execute(events)
+    for h, exp in expect:
+        assert b2.decrypt(cop2.get(h)) == exp
+
+
+@pytest.mark.gpu
+def test_events_on_handles_equal_the_host_buffer_route_bit_for_bit():
+    """A chain of events over handles (ciphertexts resident in device memory) against the same chain
+    with every operand and result crossing PCIe: identical ciphertext bytes, identical store traffic
+    (tests/fhevm-suite/e2e/test/utils.ts:182-214: handles in, handle out)."""
+    from fhe_amd.native import Context, LfheError
+    ctx = Context(seed=bytes(range(32)), params_id=3)
+    ctx.keygen()
+    try:
+        ctx.reseed_encryption(bytes(range(32)))
+        c = [0]
+
+        def new(w):
+            c[0] += 1
+            return mk_handle(c[0], w)
+        cops = [Coprocessor(ctx, resident=False), Coprocessor(ctx, resident=True)]
+        assert cops[1].resident and not cops[0].resident
+        n = 5
+        ev, outs, inputs = [], [], []
+        zero = new(64)
+        ev.append(Event("TrivialEncrypt", {"pt": 0, "toType": 5, "result": zero}))
+        for i in range(n):
+            bal, to, amt = 1000 + 37 * i, 5 * i, (700 * i) % 1500
+            hb, ht, ha = new(64), new(64), new(64)
+            inputs += [(hb, ctx.encrypt(bal, 64)), (ht, ctx.encrypt(to, 64)), (ha, ctx.encrypt(amt, 64))]
+            ok, v, nb, nt = new(1), new(64), new(64), new(64)
+            ev += [Event("FheLe", {"lhs": ha, "rhs": hb, "scalarByte": b"\x00", "result": ok}),
+                   Event("FheIfThenElse", {"control": ok, "ifTrue": ha, "ifFalse": zero, "result": v}),
+                   Event("FheSub", {"lhs": hb, "rhs": v, "scalarByte": b"\x00", "result": nb}),
+                   Event("FheAdd", {"lhs": ht, "rhs": v, "scalarByte": b"\x00", "result": nt})]
+            outs += [ok, v, nb, nt]
+        # a second wave on the results: lone events (not fused), clear operands, a shift by a clear amount, a unary
+        x, y = outs[2], outs[6]
+        m1, m2, m3, m4, m5 = new(64), new(1), new(64), new(64), new(64)
+        ev += [Event("FheMul", {"lhs": x, "rhs": (1000003).to_bytes(32, "big"), "scalarByte": b"\x01", "result": m1}),
+               Event("FheGt", {"lhs": x, "rhs": y, "scalarByte": b"\x00", "result": m2})]
+        ev2 = [Event("FheShl", {"lhs": m1, "rhs": (13).to_bytes(32, "big"), "scalarByte": b"\x01", "result": m3}),
+               Event("FheNeg", {"ct": y, "result": m4}),
+               Event("FheBitXor", {"lhs": m1, "rhs": y, "scalarByte": b"\x00", "result": m5})]
+        outs += [m1, m2, m3, m4, m5]
+        for cop in cops:
+            for h, ct in inputs:
+                cop.put(h, ct)
+            cop.execute(ev)
+            cop.execute(ev2)
+        for h in outs:
+            assert cops[0].get(h) == cops[1].get(h), h.hex()
+        bal0, amt1 = 1000, 700
+        assert ctx.decrypt(cops[1].get(outs[2])) == bal0 and ctx.decrypt(cops[1].get(outs[6])) == 1037 - amt1
+        assert ctx.decrypt(cops[1].get(m3)) == ((bal0 * 1000003) << 13) & ((1 << 64) - 1)
+        # the store itself: sizes, replacement, errors
+        entries, held = ctx.store_stat()
+        assert entries == len(inputs) + 1 + len(outs) and held >= entries * 1 * 16392
+        ctx.store_put(m4, ctx.store_get(m5))            # replace an entry
+        assert ctx.store_get(m4) == cops[0].get(m5)
+        ctx.store_drop(m4)
+        assert not ctx.store_has(m4) and ctx.store_stat()[0] == entries - 1
+        with pytest.raises(LfheError) as e:
+            ctx.evaluate_batch_handles("add", 64, [m4], [m5], None, [new(64)])    # unknown handle
+        assert e.value.code == -1
+        with pytest.raises(LfheError) as e:
+            ctx.evaluate_batch_handles("add", 32, [m5], [m5], None, [new(32)])    # stored width differs
+        assert e.value.code == -1
+        assert ctx.store_stat()[0] == entries - 1          # a failed call stores nothing
+    finally:
+        ctx.close()
+
+
 @pytest.mark.gpu
 def test_block_of_transfers_and_rand_on_gpu():
     """A block of transfers (le, select, sub, add per transfer: EncryptedERC20.sol:87-93,208-220)

@@ -2,11 +2,10 @@
 broadcasts), and one rank over RCCL (the product's own collectives on a communicator of size one).
 Both start fresh processes and watch them with a bound: a rank that dies or stalls inside a
 collective leaves its peer waiting forever, and a silent wait is what ends a GPU run.
-gloo is used on host tensors only: an earlier form of the two-rank test ran gloo broadcasts and an
-all-reduce directly on device tensors, passed once and stalled once in that section with nothing
-else changed; the ranks' start-up was not the cause (this file's four processes start and finish in
-seconds on a box that has run the suite).  The product never does that either -- its device-tensor
-collectives are RCCL's."""
+gloo is used on host tensors only: gloo broadcasts directly on device tensors, two ranks on one GPU,
+stall inside torch.distributed.broadcast on both ranks (tests/gloo_device_probe.py shows the frame;
+neither stream ordering nor the wrapping of library memory is involved).  The product never does
+that either -- its device-tensor collectives are RCCL's."""
 import pytest
 
 pytestmark = pytest.mark.gpu

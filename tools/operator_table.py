@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Latency of one operation and rate of a batch, for every integer operator at 8 .. 64 bits (and the
 wide types for add / compare): tools/operator_table.py [params id] [batch] > table.json.
-Operands and results in host memory (the shape of POST /evaluate); every result is decrypted and
-compared with the clear model.  Needs a GPU."""
+Operands and results in host memory (the shape of POST /evaluate), and the same batch again on
+ciphertexts resident in the library's device store (handles in, handles out: the shape of the
+executor events); every result of either route is decrypted and compared with the clear model.
+Needs a GPU."""
 from __future__ import annotations
 
 import json
@@ -62,11 +64,36 @@ def main():
         outs = ctx.evaluate_batch(op, w, A, Bv, conds)
         dt = time.perf_counter() - t0
         ok = ok and [ctx.decrypt(o) for o in outs] == want
+        # the same batch on resident ciphertexts: only handles cross the bus inside the timed region
+        hd = lambda tag, i: bytes([tag]) + i.to_bytes(4, "big") + bytes(27)
+        hA = [hd(1, i) for i in range(batch)]
+        for h, ct in zip(hA, A):
+            ctx.store_put(h, ct)
+        hB = Bv
+        if Bv is not None and not isinstance(Bv[0], int):
+            hB = [hd(2, i) for i in range(batch)]
+            for h, ct in zip(hB, Bv):
+                ctx.store_put(h, ct)
+        hC = None
+        if conds is not None:
+            hC = [hd(3, i) for i in range(batch)]
+            for h, ct in zip(hC, conds):
+                ctx.store_put(h, ct)
+        hO = [hd(4, i) for i in range(batch)]
+        ctx.evaluate_batch_handles(op, w, hA[:2], None if hB is None else hB[:2], None if hC is None else hC[:2], hO[:2])
+        t0 = time.perf_counter()
+        ctx.evaluate_batch_handles(op, w, hA, hB, hC, hO)
+        dt_res = time.perf_counter() - t0
+        ok = ok and [ctx.decrypt(ctx.store_get(h)) for h in hO] == want
+        for h in hA + hO + (hB if hB is not None and not isinstance(hB[0], int) else []) + (hC or []):
+            ctx.store_drop(h)
         kw = {} if scalar is None else {"scalar": scalar}
         p = program(op, w, **kw)
         rows.append({"op": op, "width": w, "clear_operand": scalar, "bootstraps": p["pbs"], "layers": len(p["layers"]),
                      "latency_ms": round(best * 1e3, 2), "batch": batch, "per_second": round(batch / dt, 1),
-                     "pbs_per_second": round(batch * p["pbs"] / dt), "verified": ok})
+                     "pbs_per_second": round(batch * p["pbs"] / dt),
+                     "resident_per_second": round(batch / dt_res, 1), "resident_pbs_per_second": round(batch * p["pbs"] / dt_res),
+                     "verified": ok})
         print(rows[-1], file=sys.stderr, flush=True)
     print(json.dumps({"params_id": pid, "rows": rows}), flush=True)
     ctx.close()
