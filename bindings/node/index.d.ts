@@ -51,6 +51,8 @@ export class NativeEngine {
   decrypt(ciphertext: Bytes): bigint;
   /** right: a ciphertext, or a clear value; cond: an ebool ciphertext, for 'select' only */
   evaluate(op: Operator, bitWidth: BitWidth, left: Bytes, right?: Bytes | ClearValue | null, cond?: Bytes | null): Buffer;
+  /** evaluate() on a worker thread; pending requests of one shape share their bootstrap launches */
+  evaluateAsync(op: Operator, bitWidth: BitWidth, left: Bytes, right?: Bytes | ClearValue | null, cond?: Bytes | null): Promise<Buffer>;
   /** n independent instances bootstrapped together */
   evaluateBatch(op: Operator, bitWidth: BitWidth, lefts: Bytes[], rights?: Array<Bytes | ClearValue> | null, conds?: Bytes[] | null): Buffer[];
   rand(bitWidth: BitWidth, seed16: Uint8Array, randomBits?: number): Buffer;

@@ -93,6 +93,25 @@ class NativeEngine {
     return native.evaluate(this.handle, code, bitWidth, Buffer.from(left), rhs, scalar, cond ? Buffer.from(cond) : null);
   }
 
+  /**
+   * evaluate() off the event loop: resolves with the result ciphertext.  Requests that are pending
+   * together and agree in operator, width and operand kind are bootstrapped as one batch, so
+   * `Promise.all` over many of them costs little more than one (the reference's tests fan out
+   * this way: tests/fhevm-suite/e2e/test/instance.ts:32-36).
+   * @returns {Promise<Buffer>}
+   */
+  evaluateAsync(op, bitWidth, left, right, cond) {
+    const code = native.opFromName(op);
+    if (code < 0) return Promise.reject(new Error(`unknown operation ${op}`));
+    const scalar = typeof right === 'number' || typeof right === 'bigint' || typeof right === 'string';
+    try {
+      const rhs = right === undefined || right === null ? null : scalar ? toLE32(right) : Buffer.from(right);
+      return native.evaluateAsync(this.handle, code, bitWidth, Buffer.from(left), rhs, scalar, cond ? Buffer.from(cond) : null);
+    } catch (e) {
+      return Promise.reject(e);
+    }
+  }
+
   /** n independent instances bootstrapped together; operands are arrays of ciphertexts (or of clear values). */
   evaluateBatch(op, bitWidth, lefts, rights, conds) {
     const code = native.opFromName(op);
@@ -184,8 +203,9 @@ class LuxFHEClient {
 
   async encrypt(value, bitWidth) { return new Uint8Array(this.engine.encrypt(value, bitWidth)); }
   async decrypt(ciphertext) { return this.engine.decrypt(ciphertext); }
+  /** Runs on a worker thread; concurrent calls of one shape share their bootstrap launches. */
   async evaluate(op, left, right, bitWidth, cond) {
-    return new Uint8Array(this.engine.evaluate(op, bitWidth, left, right, cond));
+    return new Uint8Array(await this.engine.evaluateAsync(op, bitWidth, left, right, cond));
   }
 }
 

@@ -9,12 +9,18 @@
  *
  * The library is opened with dlopen when the addon is first used, so loading the addon itself
  * needs neither a GPU nor the library; creating a context without a GPU throws.
- * Calls are synchronous and a context is single-threaded: run a context on one worker.
+ * The plain calls are synchronous.  evaluateAsync returns a Promise and runs on a libuv worker
+ * thread, so a 40 ms multiplication does not block the event loop; requests that are pending at the
+ * moment a worker starts and share context, operator, width and operand kind go out as ONE
+ * lfhe_evaluate_batch call (a bootstrap layer of a single operation leaves most of the GPU idle, so
+ * sixteen concurrent promises cost little more than one).  The library is entered by one thread at
+ * a time (a context is single-threaded).
  * Values cross the boundary as 32-byte little-endian buffers (index.js converts BigInt).
  */
 #define NAPI_VERSION 6
 #include <dlfcn.h>
 #include <node_api.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -411,6 +417,178 @@ static napi_value js_evaluate_batch(napi_env env, napi_callback_info info) {
     return out;
 }
 
+/* ---- evaluateAsync: Promise-returning evaluation on the libuv pool, with coalescing ---- */
+typedef struct eval_req {
+    lfhe_ctx* c;
+    uint32_t op, bits;
+    int scalar;
+    uint8_t *l, *r, *cd;          /* copies of the operands: the JS buffers may be gone when the worker runs */
+    size_t ll, rl, cl;
+    uint8_t* out;
+    uint64_t out_len;
+    int32_t rc;
+    char err[320];
+    int state;                    /* 0 queued, 1 taken by a batch, 2 done */
+    struct eval_req* next;
+    napi_deferred deferred;
+    napi_async_work work;
+} eval_req;
+
+static pthread_mutex_t g_q_mutex = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t g_q_cond = PTHREAD_COND_INITIALIZER;
+static pthread_mutex_t g_lib_mutex = PTHREAD_MUTEX_INITIALIZER;   /* one thread inside the library at a time */
+static eval_req* g_q_head;
+
+static void req_free(eval_req* q) {
+    free(q->l); free(q->r); free(q->cd); free(q->out); free(q);
+}
+
+static uint8_t* dup_bytes(const uint8_t* p, size_t n) {
+    if (!p) return NULL;
+    uint8_t* d = (uint8_t*)malloc(n ? n : 1);
+    if (d) memcpy(d, p, n);
+    return d;
+}
+
+static void run_one(eval_req* q) {
+    uint64_t n = 0;
+    q->rc = p_lfhe_evaluate(q->c, q->op, q->bits, q->l, q->ll, q->r, q->rl, q->scalar, q->cd, q->cl, NULL, &n);
+    if (q->rc == LFHE_OK) {
+        q->out = (uint8_t*)malloc(n ? n : 1);
+        if (!q->out) { q->rc = LFHE_ERR_DEVICE; snprintf(q->err, sizeof q->err, "out of memory"); return; }
+        q->rc = p_lfhe_evaluate(q->c, q->op, q->bits, q->l, q->ll, q->r, q->rl, q->scalar, q->cd, q->cl, q->out, &n);
+        q->out_len = n;
+    }
+    if (q->rc != LFHE_OK) snprintf(q->err, sizeof q->err, "Evaluation failed (%d): %s", q->rc, p_lfhe_last_error(q->c));
+}
+
+static int same_shape(const eval_req* a, const eval_req* b) {
+    return a->c == b->c && a->op == b->op && a->bits == b->bits && a->scalar == b->scalar && a->ll == b->ll &&
+           a->rl == b->rl && a->cl == b->cl && (a->r != NULL) == (b->r != NULL) && (a->cd != NULL) == (b->cd != NULL);
+}
+
+/* worker thread: serve this request and every queued request of the same shape in one batch */
+static void eval_execute(napi_env env, void* data) {
+    (void)env;
+    eval_req* me = (eval_req*)data;
+    pthread_mutex_lock(&g_q_mutex);
+    if (me->state != 0) {                       /* another worker took it into its batch */
+        while (me->state != 2) pthread_cond_wait(&g_q_cond, &g_q_mutex);
+        pthread_mutex_unlock(&g_q_mutex);
+        return;
+    }
+    eval_req* batch[256];
+    size_t count = 0;
+    for (eval_req** pp = &g_q_head; *pp;) {
+        eval_req* q = *pp;
+        if (q->state == 0 && count < 256 && (q == me || (me->op != LFHE_OP_CAST && same_shape(q, me)))) {
+            q->state = 1;
+            batch[count++] = q;
+            *pp = q->next;
+        } else {
+            pp = &q->next;
+        }
+    }
+    pthread_mutex_unlock(&g_q_mutex);
+
+    pthread_mutex_lock(&g_lib_mutex);
+    int done = 0;
+    if (count > 1) {
+        uint64_t out_sz = 0;
+        const int cmp = me->op >= LFHE_OP_EQ && me->op <= LFHE_OP_LT;
+        uint8_t *L = (uint8_t*)malloc(count * me->ll), *R = me->r ? (uint8_t*)malloc(count * me->rl) : NULL,
+                *Cd = me->cd ? (uint8_t*)malloc(count * me->cl) : NULL, *O = NULL;
+        if (p_lfhe_ciphertext_size(me->c, cmp ? 1 : me->bits, &out_sz) == LFHE_OK) O = (uint8_t*)malloc(count * out_sz);
+        if (L && O && (!me->r || R) && (!me->cd || Cd)) {
+            for (size_t i = 0; i < count; ++i) {
+                memcpy(L + i * me->ll, batch[i]->l, me->ll);
+                if (R) memcpy(R + i * me->rl, batch[i]->r, me->rl);
+                if (Cd) memcpy(Cd + i * me->cl, batch[i]->cd, me->cl);
+            }
+            if (p_lfhe_evaluate_batch(me->c, me->op, me->bits, count, L, R, me->scalar, Cd, O) == LFHE_OK) {
+                done = 1;
+                for (size_t i = 0; i < count; ++i) {
+                    batch[i]->out = dup_bytes(O + i * out_sz, out_sz);
+                    batch[i]->out_len = out_sz;
+                    batch[i]->rc = batch[i]->out ? LFHE_OK : LFHE_ERR_DEVICE;
+                    if (!batch[i]->out) snprintf(batch[i]->err, sizeof batch[i]->err, "out of memory");
+                }
+            }
+        }
+        free(L); free(R); free(Cd); free(O);
+    }
+    if (!done)                                   /* a single request, or a batch that failed: one by one, each with its own error */
+        for (size_t i = 0; i < count; ++i) run_one(batch[i]);
+    pthread_mutex_unlock(&g_lib_mutex);
+
+    pthread_mutex_lock(&g_q_mutex);
+    for (size_t i = 0; i < count; ++i) batch[i]->state = 2;
+    pthread_cond_broadcast(&g_q_cond);
+    pthread_mutex_unlock(&g_q_mutex);
+}
+
+/* main thread: settle the promise */
+static void eval_complete(napi_env env, napi_status status, void* data) {
+    eval_req* q = (eval_req*)data;
+    if (status == napi_ok && q->rc == LFHE_OK) {
+        napi_value buf;
+        void* dst;
+        if (napi_create_buffer_copy(env, q->out_len, q->out, &dst, &buf) == napi_ok) napi_resolve_deferred(env, q->deferred, buf);
+        else { napi_value e, m; napi_create_string_utf8(env, "out of memory", NAPI_AUTO_LENGTH, &m); napi_create_error(env, NULL, m, &e); napi_reject_deferred(env, q->deferred, e); }
+    } else {
+        napi_value e, m;
+        napi_create_string_utf8(env, status == napi_ok ? q->err : "evaluation was cancelled", NAPI_AUTO_LENGTH, &m);
+        napi_create_error(env, NULL, m, &e);
+        napi_reject_deferred(env, q->deferred, e);
+    }
+    napi_delete_async_work(env, q->work);
+    req_free(q);
+}
+
+/* evaluateAsync(ctx, op, bits, lhs, rhs|null, rhsIsScalar, cond|null) -> Promise<Buffer> */
+static napi_value js_evaluate_async(napi_env env, napi_callback_info info) {
+    NEED_LIB();
+    napi_value argv[7];
+    if (!get_args(env, info, 7, argv)) return NULL;
+    lfhe_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return NULL;
+    const uint8_t *l, *r, *cd; size_t ll, rl, cl;
+    if (!get_bytes(env, argv[3], &l, &ll) || !get_bytes(env, argv[4], &r, &rl) || !get_bytes(env, argv[6], &cd, &cl)) return NULL;
+    eval_req* q = (eval_req*)calloc(1, sizeof *q);
+    if (!q) return throw_msg(env, "out of memory");
+    q->c = c;
+    napi_get_value_uint32(env, argv[1], &q->op);
+    napi_get_value_uint32(env, argv[2], &q->bits);
+    bool scalar = false;
+    napi_get_value_bool(env, argv[5], &scalar);
+    q->scalar = scalar ? 1 : 0;
+    q->l = dup_bytes(l, ll); q->r = dup_bytes(r, rl); q->cd = dup_bytes(cd, cl);
+    q->ll = ll; q->rl = rl; q->cl = cl;
+    if (!l || !q->l || (r && !q->r) || (cd && !q->cd)) { req_free(q); return throw_msg(env, l ? "out of memory" : "missing left operand"); }
+    napi_value promise, name;
+    if (napi_create_promise(env, &q->deferred, &promise) != napi_ok) { req_free(q); return throw_msg(env, "cannot create a promise"); }
+    napi_create_string_utf8(env, "lfhe.evaluate", NAPI_AUTO_LENGTH, &name);
+    if (napi_create_async_work(env, NULL, name, eval_execute, eval_complete, q, &q->work) != napi_ok) {
+        req_free(q);
+        return throw_msg(env, "cannot create async work");
+    }
+    pthread_mutex_lock(&g_q_mutex);               /* queued before the work can start: a running worker may already take it */
+    eval_req** pp = &g_q_head;
+    while (*pp) pp = &(*pp)->next;
+    *pp = q;
+    pthread_mutex_unlock(&g_q_mutex);
+    if (napi_queue_async_work(env, q->work) != napi_ok) {
+        pthread_mutex_lock(&g_q_mutex);
+        for (pp = &g_q_head; *pp; pp = &(*pp)->next)
+            if (*pp == q) { *pp = q->next; break; }
+        const int taken = q->state != 0;
+        pthread_mutex_unlock(&g_q_mutex);
+        if (!taken) { napi_delete_async_work(env, q->work); req_free(q); }
+        return throw_msg(env, "cannot queue async work");
+    }
+    return promise;
+}
+
 /* rand(ctx, bits, seed16, randomBits) -> Buffer */
 static napi_value js_rand(napi_env env, napi_callback_info info) {
     NEED_LIB();
@@ -568,19 +746,35 @@ static napi_value js_pbs_count(napi_env env, napi_callback_info info) {
     return v;
 }
 
+/* Every synchronous export enters the library under the same mutex as the async workers. */
+typedef struct { const char* name; napi_callback fn; int locked; } export_entry;
+
+static napi_value locked_call(napi_env env, napi_callback_info info) {
+    void* data = NULL;
+    size_t argc = 0;
+    if (napi_get_cb_info(env, info, &argc, NULL, NULL, &data) != napi_ok || !data) return throw_msg(env, "bad call");
+    const export_entry* e = (const export_entry*)data;
+    pthread_mutex_lock(&g_lib_mutex);
+    napi_value v = e->fn(env, info);
+    pthread_mutex_unlock(&g_lib_mutex);
+    return v;
+}
+
 static napi_value init(napi_env env, napi_value exports) {
-    static const struct { const char* name; napi_callback fn; } tab[] = {
-        {"open", js_open}, {"createContext", js_create}, {"destroy", js_destroy}, {"keygen", js_keygen},
-        {"health", js_health}, {"publicKey", js_public_key}, {"keysExport", js_keys_export},
-        {"keysImport", js_keys_import}, {"encrypt", js_encrypt}, {"encryptPublic", js_encrypt_public},
-        {"decrypt", js_decrypt}, {"opFromName", js_op_from_name}, {"evaluate", js_evaluate},
-        {"evaluateBatch", js_evaluate_batch}, {"pbsCount", js_pbs_count}, {"rand", js_rand},
-        {"importClientKeys", js_import_client}, {"keygenServer", js_keygen_server}, {"setPkeKey", js_set_pke_key},
-        {"castFromPke", js_cast_from_pke}, {"compressionKeygen", js_compression_keygen}, {"compress", js_compress},
-        {"decompress", js_decompress}, {"expandCompactList", js_expand_compact_list}};
+    static const export_entry tab[] = {
+        {"open", js_open, 1}, {"createContext", js_create, 1}, {"destroy", js_destroy, 1}, {"keygen", js_keygen, 1},
+        {"health", js_health, 1}, {"publicKey", js_public_key, 1}, {"keysExport", js_keys_export, 1},
+        {"keysImport", js_keys_import, 1}, {"encrypt", js_encrypt, 1}, {"encryptPublic", js_encrypt_public, 1},
+        {"decrypt", js_decrypt, 1}, {"opFromName", js_op_from_name, 0}, {"evaluate", js_evaluate, 1},
+        {"evaluateBatch", js_evaluate_batch, 1}, {"evaluateAsync", js_evaluate_async, 0}, {"pbsCount", js_pbs_count, 1},
+        {"rand", js_rand, 1}, {"importClientKeys", js_import_client, 1}, {"keygenServer", js_keygen_server, 1},
+        {"setPkeKey", js_set_pke_key, 1}, {"castFromPke", js_cast_from_pke, 1},
+        {"compressionKeygen", js_compression_keygen, 1}, {"compress", js_compress, 1}, {"decompress", js_decompress, 1},
+        {"expandCompactList", js_expand_compact_list, 1}};
     for (size_t i = 0; i < sizeof tab / sizeof tab[0]; ++i) {
         napi_value f;
-        napi_create_function(env, tab[i].name, NAPI_AUTO_LENGTH, tab[i].fn, NULL, &f);
+        if (tab[i].locked) napi_create_function(env, tab[i].name, NAPI_AUTO_LENGTH, locked_call, (void*)&tab[i], &f);
+        else napi_create_function(env, tab[i].name, NAPI_AUTO_LENGTH, tab[i].fn, NULL, &f);
         napi_set_named_property(env, exports, tab[i].name, f);
     }
     return exports;

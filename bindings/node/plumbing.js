@@ -24,6 +24,35 @@ const { LuxFHEClient, NativeEngine } = require('./index.js');
     rand: String(engine.decrypt(engine.rand(16, Buffer.alloc(16, 7), 10))),
     pbs: engine.pbsCount(),
   };
+  // sixteen concurrent evaluate promises (the reference's tests fan out with Promise.all,
+  // tests/fhevm-suite/e2e/test/instance.ts:32-36): they run off the event loop and share their
+  // bootstrap launches, so the lot costs little more than one
+  const conc = async (op, bits, n, vx, vy, model) => {
+    const xs = [], ys = [];
+    for (let i = 0; i < n; i++) { xs.push(await sdk.encrypt(vx(i), bits)); ys.push(await sdk.encrypt(vy(i), bits)); }
+    await sdk.evaluate(op, xs[0], ys[0], bits);                       // schedule built and uploaded
+    let best = Infinity;
+    for (let k = 0; k < 3; k++) {
+      const t = process.hrtime.bigint();
+      await sdk.evaluate(op, xs[0], ys[0], bits);
+      best = Math.min(best, Number(process.hrtime.bigint() - t) / 1e6);
+    }
+    let ticks = 0;
+    const timer = setInterval(() => { ticks++; }, 2);                 // the event loop keeps turning meanwhile
+    const t0 = process.hrtime.bigint();
+    const outs = await Promise.all(xs.map((x, i) => sdk.evaluate(op, x, ys[i], bits)));
+    const all = Number(process.hrtime.bigint() - t0) / 1e6;
+    clearInterval(timer);
+    const vals = await Promise.all(outs.map((o) => sdk.decrypt(o)));
+    return { single_ms: best, all_ms: all, n, ticks, ok: vals.every((v, i) => v === model(vx(i), vy(i))) };
+  };
+  // an addition's bootstrap layers hold a few dozen ciphertexts: sixteen of them still fit the launches of one
+  res.concurrent = await conc('add', 16, 16, (i) => 1000n * BigInt(i + 1), (i) => 77n + BigInt(i), (x, y) => (x + y) % (1n << 16n));
+  // sixteen euint64 products are 29 000 bootstraps: they run at the batch rate instead of one after the other
+  res.concurrentMul = await conc('mul', 64, 16, (i) => 1000003n * BigInt(i + 1), (i) => 77n + BigInt(i), (x, y) => (x * y) % (1n << 64n));
+  // a failing request rejects its own promise only
+  const mixed = await Promise.all([sdk.evaluate('add', a, b, 8), sdk.evaluate('add', a, Buffer.alloc(a.length), 8).then(() => 'resolved', () => 'rejected')]);
+  res.mixed = [String(await sdk.decrypt(mixed[0])), mixed[1]];
   // compression for storage: both operands into one blob and back
   engine.compressionKeygen();
   const blob = engine.compress([a, b]);
@@ -48,6 +77,9 @@ const { LuxFHEClient, NativeEngine } = require('./index.js');
   const ok = compactOk && res.health === 'ok' && res.add === '59' && res.sub === '25' && res.lt === '0' && res.eq === '1' &&
     res.addScalar === '242' && res.shl === String((42 << 3) & 255) && res.mul64 === '18434227713315959936' &&
     res.batch[0] === '1' && res.batch[1] === '0' && Number(res.rand) < 1024 &&
+    res.concurrent.ok && res.concurrent.all_ms < 2 * res.concurrent.single_ms && res.concurrent.ticks > 2 &&
+    res.concurrentMul.ok && res.concurrentMul.all_ms < 10 * res.concurrentMul.single_ms &&
+    res.mixed[0] === '59' && res.mixed[1] === 'rejected' &&
     res.restored[0] === '42' && res.restored[1] === '17' && back.length === a.length + b.length && blob.length < a.length / 8;
   engine.close();
   process.exit(ok ? 0 : 1);

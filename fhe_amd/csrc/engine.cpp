@@ -54,6 +54,18 @@ Engine::Engine(int device, const EngineParams& p) : device_(device), prm_(p) {
     if (const char* e = std::getenv("LFHE_KS_MFMA_MIN")) ksm_min_ = std::atoi(e);     // 0: VALU key switch only
     if (!ksm_supported(N, (int)p.ks_level, (int)p.lwe_dim)) ksm_min_ = 0;
 
+    if (!single_modulus() && p.bsk_grouping == 2) {
+        // lift guard of the grouped key over 2^64 (kernels.hip: k_blind_rotate_g64_pair): marks of one launch and
+        // the count of ciphertexts that took the slow path, made here so that no bootstrap call allocates
+        g64_guard_.capacity = 65536;
+        HC(hipMalloc(&g64_guard_.fault, g64_guard_.capacity * sizeof(int)));
+        HC(hipMalloc(&g64_guard_.fallbacks, sizeof(unsigned long long)));
+        HC(hipMemset(g64_guard_.fallbacks, 0, sizeof(unsigned long long)));
+        double frac = 0.875;      // of the half-window p1 / 2
+        if (const char* e = std::getenv("LFHE_G64_GUARD_FRAC")) frac = std::atof(e);   // tests force the slow path with a small one
+        g64_guard_.k_guard = frac * 0.5 * P1;
+    }
+
     HostTables H;
     build_host_tables(H);
     HC(hipMalloc(&d_tw_, sizeof(double) * (4 * N + 2 * (MONO_WORDS + 8))));
@@ -96,12 +108,22 @@ Engine::~Engine() {
     (void)hipFree(d_ksm_prod_);
     (void)hipFree(d_pack_limbs_);
     (void)hipFree(d_decomp_bsk_);
+    (void)hipFree(g64_guard_.fault);
+    (void)hipFree(g64_guard_.fallbacks);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
 void Engine::sync() {
     HC(hipSetDevice(device_));
     HC(hipStreamSynchronize(stream_));
+}
+
+uint64_t Engine::lift_fallbacks() {
+    if (!g64_guard_.fallbacks) return 0;
+    sync();
+    unsigned long long v = 0;
+    HC(hipMemcpy(&v, g64_guard_.fallbacks, sizeof v, hipMemcpyDeviceToHost));
+    return v;
 }
 
 void Engine::load_bsk(const u64* host_bsk) {
@@ -454,8 +476,10 @@ void Engine::blind_rotate_with(const double* bsk, uint32_t n, const u64* lwe_sma
     // ciphertexts in flight: four per CU, two with the one-bit-per-step key over 2^64
     const size_t slots = (size_t)(single_modulus() || prm_.bsk_grouping == 2 ? 4 : 2) * (size_t)cu_count_;
     if (omap.idx && !omap.ops) throw std::logic_error("block map without a period");
-    const size_t chunk = br_chunk_ > 0 ? (omap.ops ? ((size_t)br_chunk_ + omap.ops - 1) / omap.ops * omap.ops : (size_t)br_chunk_)
-                                       : launch_chunk(count, omap.ops, slots);
+    size_t chunk = br_chunk_ > 0 ? (omap.ops ? ((size_t)br_chunk_ + omap.ops - 1) / omap.ops * omap.ops : (size_t)br_chunk_)
+                                 : launch_chunk(count, omap.ops, slots);
+    if (g64_guard_.capacity && chunk > g64_guard_.capacity)   // one mark per ciphertext of a launch
+        chunk = omap.ops ? std::max<size_t>(1, g64_guard_.capacity / omap.ops) * omap.ops : g64_guard_.capacity;
     for (size_t c0 = 0; c0 < count; c0 += chunk) {
         const size_t cnt = count - c0 < chunk ? count - c0 : chunk;
         // the launch sees ciphertext c0 as its ciphertext 0: shift every per-ciphertext pointer
@@ -476,7 +500,7 @@ void Engine::blind_rotate_with(const double* bsk, uint32_t n, const u64* lwe_sma
         else
             launch_blind_rotate(T_, bsk, in, (int)n, luts, li, gout, lout, cnt, omap,
                                 prm_.bsk_grouping == 2 && fact ? 3 : (int)prm_.bsk_grouping,
-                                pair_above_ != -2 ? pair_above_ : (cnt > 2 * (size_t)cu_count_ ? 0 : -1), stream_);
+                                pair_above_ != -2 ? pair_above_ : (cnt > 2 * (size_t)cu_count_ ? 0 : -1), g64_guard_, stream_);
         HC(hipGetLastError());
     }
 }

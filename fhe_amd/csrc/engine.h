@@ -49,9 +49,18 @@ void launch_ntt_forward(const Tables& T, const u64* in, double* out, size_t poly
 void launch_ntt_inverse(const Tables& T, const double* in, u64* out, size_t polys, hipStream_t st);
 void launch_external_product(const Tables& T, const double* bsk, const u32* idx, const u64* glwe, u64* out,
                              size_t count, hipStream_t st);
+// Lift guard of the grouped key over 2^64: per-ciphertext marks of one launch (`capacity` of them), the
+// bound on the lift's quotient from which a coefficient counts as near the window's edge, and the
+// running count of ciphertexts that were bootstrapped again on the slow path.
+struct G64Guard {
+    int* fault = nullptr;
+    size_t capacity = 0;
+    double k_guard = 0;
+    unsigned long long* fallbacks = nullptr;
+};
 void launch_blind_rotate(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
                          const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
-                         const BlockMap& omap, int grouping, int pair_above, hipStream_t st);
+                         const BlockMap& omap, int grouping, int pair_above, const G64Guard& guard, hipStream_t st);
 void launch_bskq_prepare(const Tables& T, const u64* in, double* out, size_t polys, hipStream_t st);
 // grouped key image -> factored form, in place (row_words: BSKQ_ROW or BSK_ROW); *degenerate (device) is set
 // when a word has none
@@ -205,6 +214,9 @@ public:
     void ntt_forward(const u64* polys, double* out, size_t count);
     void ntt_inverse(const double* in, u64* out, size_t count);
     void sync();
+    // ciphertexts whose bootstrap was redone on the slow, unconditionally exact path because a lift came
+    // near the end of its window (grouped key over 2^64 only; 0 for every other key)
+    uint64_t lift_fallbacks();
 
     // scratch owned by the engine (grow-only): the small-LWE intermediate of pbs_batch
     u64* small_scratch(size_t count);
@@ -239,6 +251,7 @@ private:
     bool bsk_factored_ = false, decomp_factored_ = false;
     void publish_key_flags();   // the count word of the key-switching key image also says how the other image is held
     MsParams ms_{};
+    G64Guard g64_guard_{};
     int cu_count_ = 256;
     int br_chunk_ = 0;      // ciphertexts per blind-rotation launch; 0: about four rounds of resident workgroups
     int wide_below_ = -1;   // launches of at most this many ciphertexts use 512 threads each

@@ -1059,7 +1059,8 @@ constexpr size_t g64_lds_bytes(int nc) { return (size_t)nc * LDS_BYTES + G64_TW_
 // One prime's share of a step for the NC (two, or one for launches that do not fill the GPU) ciphertexts of a workgroup: digits in x (pass-1
 // ownership) -> residues of the external product in x (|x| < 2 p, pass-1 ownership).  Ends with the
 // workgroup barrier that frees the exchange buffers.
-template <int R, bool FACTORED, int NC>
+// TERM: -1 the whole step's GGSW; 0..3 one of its four terms alone (the slow path, see below).
+template <int R, bool FACTORED, int NC, int TERM = -1>
 __device__ __forceinline__ void g64_prime_pass(double (&x)[NC][2][E], const Tables& T,
                                                const double* __restrict__ rows, const unsigned (&am)[NC][2],
                                                unsigned t) {
@@ -1168,8 +1169,10 @@ __device__ __forceinline__ void g64_prime_pass(double (&x)[NC][2][E], const Tabl
 #pragma unroll
                     for (int h = 0; h < 2; ++h)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            ggsw_entry_row<FACTORED>(m, B[c][q][h], S[c][q][h], kc[q][h], M1[c][h], M2[c][h], P);
+                        for (int q = 0; q < 4; ++q) {
+                            if constexpr (TERM < 0) ggsw_entry_row<FACTORED>(m, B[c][q][h], S[c][q][h], kc[q][h], M1[c][h], M2[c][h], P);
+                            else ggsw_term_row<FACTORED, TERM>(m, B[c][q][h], kc[q][h], M1[c][h], M2[c][h], P);
+                        }
                 asm volatile("" ::: "memory");
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { kc[q][0] = kn[q][0]; kc[q][1] = kn[q][1]; }
@@ -1248,20 +1251,37 @@ __device__ __forceinline__ void g64_prime_pass(double (&x)[NC][2][E], const Tabl
     __syncthreads();  // the last pass's reads are done before the buffers are written again
 }
 
-template <bool FACTORED, int NC>
+// Every lift of the fast path is looked at (crt_wrap_checked): a ciphertext with a coefficient in the
+// guard band at the end of the lift's window is marked in `fault`, and the SAFE instantiation -- launched
+// right behind the fast one over the same ciphertexts, its workgroups leaving at once unless their
+// ciphertext is marked -- bootstraps it again with the step taken apart into its four terms
+//     acc <- G0 [.] acc + G1 [.] X^a acc + G2 [.] X^a' acc + G3 [.] X^(a+a') acc ,
+// the same polynomial before the reduction to 2^64, each term the product with ONE GGSW (below 2^97:
+// exact without condition), summed in wrapping 64-bit words: the same bits as an exact evaluation of
+// the fast path's formula, at four times the transforms.  The order on the stream does the rest;
+// the host is not involved.  `fallbacks` counts the ciphertexts that took the slow path.
+template <bool FACTORED, int NC, bool SAFE = false>
 __global__ void __launch_bounds__(NT, 2) k_blind_rotate_g64_pair(Tables T, const double* __restrict__ bsk,
                                                                 const u64* __restrict__ lwe_small, int n,
                                                                 const u64* __restrict__ luts,
                                                                 const u32* __restrict__ lut_index,
                                                                 u64* __restrict__ glwe_out,
                                                                 u64* __restrict__ lwe_out, BlockMap omap,
-                                                                unsigned count) {
+                                                                unsigned count, int* __restrict__ fault,
+                                                                double k_guard, unsigned long long* __restrict__ fallbacks) {
+    static_assert(!SAFE || NC == 1, "the slow path takes one ciphertext per workgroup");
     const unsigned t = threadIdx.x;
+    if constexpr (SAFE) {
+        if (!fault[blockIdx.x]) return;   // the same for every thread of the workgroup
+        if (t == 0) atomicAdd(fallbacks, 1ull);
+    }
     size_t ct[NC];
     const u64* __restrict__ lwe[NC];
     u64 acc[NC][2][E];
+    bool near_edge[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
+        near_edge[c] = false;
         const size_t want = (size_t)blockIdx.x * NC + c;
         ct[c] = want < count ? want : (size_t)count - 1;
         lwe[c] = lwe_small + ct[c] * (size_t)(n + 1);
@@ -1293,36 +1313,76 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_g64_pair(Tables T, const
         const double* __restrict__ rows = bsk + (size_t)4 * g * BSK_ROW;
         int dig[NC][2][E];
         double x[NC][2][E], y0[NC][2][E];
+        auto digits_to_x = [&]() {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < E; ++j) x[c][q][j] = (double)dig[c][q][j];
+        };
+        auto keep_prime0 = [&]() {
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < E; ++j) y0[c][q][j] = x[c][q][j];
+        };
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int j = 0; j < E; ++j) {
-                    dig[c][q][j] = decomp23(acc[c][q][j]);
-                    x[c][q][j] = (double)dig[c][q][j];
-                }
-        g64_prime_pass<0, FACTORED, NC>(x, T, rows, am, t);
+                for (int j = 0; j < E; ++j) dig[c][q][j] = decomp23(acc[c][q][j]);
+        if constexpr (!SAFE) {
+            digits_to_x();
+            g64_prime_pass<0, FACTORED, NC>(x, T, rows, am, t);
+            keep_prime0();
+            digits_to_x();
+            g64_prime_pass<1, FACTORED, NC>(x, T, rows, am, t);
 #pragma unroll
-        for (int c = 0; c < NC; ++c)
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < E; ++j)
+                        acc[c][q][j] = crt_wrap_checked(y0[c][q][j], x[c][q][j], T.p0inv_mod_p1, T.pr[1], k_guard, near_edge[c]);
+        } else {
+            u64 sum[2][E];
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int j = 0; j < E; ++j) {
-                    y0[c][q][j] = x[c][q][j];
-                    x[c][q][j] = (double)dig[c][q][j];
-                }
-        g64_prime_pass<1, FACTORED, NC>(x, T, rows, am, t);
+                for (int j = 0; j < E; ++j) sum[q][j] = 0;
+            auto term = [&](auto term_tag) {
+                constexpr int TERM = decltype(term_tag)::value;
+                digits_to_x();
+                g64_prime_pass<0, FACTORED, NC, TERM>(x, T, rows, am, t);
+                keep_prime0();
+                digits_to_x();
+                g64_prime_pass<1, FACTORED, NC, TERM>(x, T, rows, am, t);
 #pragma unroll
-        for (int c = 0; c < NC; ++c)
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < E; ++j) sum[q][j] += crt_wrap(y0[0][q][j], x[0][q][j], T.p0inv_mod_p1, T.pr[1]);
+            };
+            term(std::integral_constant<int, 0>{});
+            term(std::integral_constant<int, 1>{});
+            term(std::integral_constant<int, 2>{});
+            term(std::integral_constant<int, 3>{});
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int j = 0; j < E; ++j) acc[c][q][j] = crt_wrap(y0[c][q][j], x[c][q][j], T.p0inv_mod_p1, T.pr[1]);
+                for (int j = 0; j < E; ++j) acc[0][q][j] = sum[q][j];
+        }
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         if (c > 0 && (size_t)blockIdx.x * NC + c >= count) break;   // odd batch: the duplicate is not stored
+        if constexpr (!SAFE) {
+            // any thread of the workgroup that saw a lift near the edge marks the ciphertext (plain vector store)
+            if (near_edge[c]) fault[ct[c]] = 1;
+        }
         if (glwe_out) {
 #pragma unroll
             for (int q = 0; q < 2; ++q)
@@ -1581,6 +1641,8 @@ void blind_rotate_setup(int dev) {
     need(ask_lds(k_blind_rotate_q2_pair<false, true>, G2P_LDS_BYTES), "k_blind_rotate_q2_pair", G2P_LDS_BYTES);
     need(ask_lds(k_blind_rotate_g64_pair<false, 2>, g64_lds_bytes(2)), "k_blind_rotate_g64_pair", g64_lds_bytes(2));
     need(ask_lds(k_blind_rotate_g64_pair<true, 2>, g64_lds_bytes(2)), "k_blind_rotate_g64_pair", g64_lds_bytes(2));
+    need(ask_lds(k_blind_rotate_g64_pair<true, 1, true>, g64_lds_bytes(1)), "k_blind_rotate_g64_pair (slow path)", g64_lds_bytes(1));
+    need(ask_lds(k_blind_rotate_g64_pair<false, 1, true>, g64_lds_bytes(1)), "k_blind_rotate_g64_pair (slow path)", g64_lds_bytes(1));
     need(ask_lds(k_blind_rotate_q2_wide<false>, WIDE2_LDS_BYTES), "k_blind_rotate_q2_wide", WIDE2_LDS_BYTES);
     need(ask_lds(k_blind_rotate_q2_wide<true>, WIDE2_LDS_BYTES), "k_blind_rotate_q2_wide", WIDE2_LDS_BYTES);
     need(ask_lds(k_blind_rotate_q_wide, WIDE_LDS_BYTES), "k_blind_rotate_q_wide", WIDE_LDS_BYTES);
@@ -1798,18 +1860,23 @@ void launch_external_product(const Tables& T, const double* bsk, const u32* idx,
 }
 void launch_blind_rotate(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
                          const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
-                         const BlockMap& omap, int grouping, int pair_above, hipStream_t st) {
+                         const BlockMap& omap, int grouping, int pair_above, const G64Guard& guard, hipStream_t st) {
     if (grouping >= 2) {
         // four GGSWs per pair of key bits (3: in factored form); two ciphertexts per workgroup, one when
         // the launch would leave CUs without a workgroup otherwise (pair_above: as for the prime modulus)
+        if (!guard.fault || count > guard.capacity) throw std::logic_error("lift-guard flags missing or too few for this launch");
+        if (hipMemsetAsync(guard.fault, 0, count * sizeof(int), st) != hipSuccess) throw std::runtime_error("hipMemsetAsync failed");
         const bool pair = pair_above >= 0 && count > (size_t)pair_above;
         const dim3 grid((unsigned)(pair ? (count + 1) / 2 : count));
-        auto go = [&](auto kernel, int nc) {
-            hipLaunchKernelGGL(kernel, grid, dim3(NT), g64_lds_bytes(nc), st, T, bsk, lwe_small, n, luts, lut_index, glwe_out,
-                               lwe_out, omap, (unsigned)count);
+        auto go = [&](auto kernel, int nc, dim3 g) {
+            hipLaunchKernelGGL(kernel, g, dim3(NT), g64_lds_bytes(nc), st, T, bsk, lwe_small, n, luts, lut_index, glwe_out,
+                               lwe_out, omap, (unsigned)count, guard.fault, guard.k_guard, guard.fallbacks);
         };
-        if (grouping == 3) { if (pair) go(k_blind_rotate_g64_pair<true, 2>, 2); else go(k_blind_rotate_g64_pair<true, 1>, 1); }
-        else { if (pair) go(k_blind_rotate_g64_pair<false, 2>, 2); else go(k_blind_rotate_g64_pair<false, 1>, 1); }
+        if (grouping == 3) { if (pair) go(k_blind_rotate_g64_pair<true, 2>, 2, grid); else go(k_blind_rotate_g64_pair<true, 1>, 1, grid); }
+        else { if (pair) go(k_blind_rotate_g64_pair<false, 2>, 2, grid); else go(k_blind_rotate_g64_pair<false, 1>, 1, grid); }
+        // the slow path for whatever the fast one marked: one workgroup per ciphertext, gone at once when unmarked
+        if (grouping == 3) go(k_blind_rotate_g64_pair<true, 1, true>, 1, dim3((unsigned)count));
+        else go(k_blind_rotate_g64_pair<false, 1, true>, 1, dim3((unsigned)count));
         return;
     }
     hipLaunchKernelGGL(k_blind_rotate, dim3((unsigned)count), dim3(NT), LDS_BYTES, st, T, bsk, lwe_small, n, luts,

@@ -312,4 +312,17 @@ LFHE_HD u64 crt_wrap(double y0, double y1, double p0inv_mod_p1, const Prime& Q1)
     return (u64)f64_to_i64(y0) + P0_U * (u64)f64_to_i64(k);
 }
 
+// The same lift with a look at where it landed.  The lift tells integers apart inside (-P/2, P/2), P =
+// p0 p1; the quotient k = (value - y0) / p0 is centred in (-p1/2, p1/2), so a value near the end of
+// the window has |k| near p1/2.  A step of the grouped key over 2^64 stays 149 standard deviations
+// inside the window; should one ever leave it, it leaves by far less than the guard band |k| >
+// k_guard (the tail beyond the window falls off on a scale 2^14 times smaller than the band), so it
+// lands IN the band and is seen.  Nothing is ever flagged by chance either: the band starts 130
+// standard deviations out.
+LFHE_HD u64 crt_wrap_checked(double y0, double y1, double p0inv_mod_p1, const Prime& Q1, double k_guard, bool& near_edge) {
+    double k = mnorm(mmul(y1 - y0, p0inv_mod_p1, Q1), Q1);
+    near_edge = near_edge || __builtin_fabs(k) > k_guard;
+    return (u64)f64_to_i64(y0) + P0_U * (u64)f64_to_i64(k);
+}
+
 }  // namespace lfhe

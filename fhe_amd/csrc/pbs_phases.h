@@ -242,6 +242,28 @@ LFHE_HD void ggsw_entry_row(int m, double& B, double& S, double k, double m1, do
     }
 }
 
+// ONE of the four terms of the step's GGSW -- K0, m1 K1, m2 K2, m1 m2 K3 -- built from the same rows in
+// the same order.  Used by the slow path of the grouped key over 2^64 (k_blind_rotate_g64_pair<.., SAFE>),
+// which multiplies the accumulator by each term separately: every such product is the product with
+// ONE GGSW and lifts exactly without condition.  From factored rows (a, b, d, c) the key words come
+// back as K3 = d, K2 = a d, K1 = b d, K0 = c + a b d.
+template <bool FACTORED, int TERM>
+LFHE_HD void ggsw_term_row(int m, double& B, double k, double m1, double m2, const Prime& P) {
+    if constexpr (FACTORED) {
+        if constexpr (TERM == 0) {
+            if (m == 0) B = k; else if (m == 1 || m == 2) B = mmul(B, k, P); else B += k;
+        } else if constexpr (TERM == 1) {
+            if (m == 1) B = mmul(m1, k, P); else if (m == 2) B = mmul(B, k, P);
+        } else if constexpr (TERM == 2) {
+            if (m == 0) B = mmul(m2, k, P); else if (m == 2) B = mmul(B, k, P);
+        } else {
+            if (m == 0) B = mmul(m1, m2, P); else if (m == 2) B = mmul(B, k, P);
+        }
+    } else {
+        if (m == TERM) B = TERM == 0 ? k : TERM == 1 ? mmul(m1, k, P) : TERM == 2 ? mmul(m2, k, P) : mmul(mmul(m1, m2, P), k, P);
+    }
+}
+
 template <bool FACTORED = false>
 LFHE_HD void ep_group2_phase5(EpState& s, double* lds, unsigned t, const Tables& T,
                               const double* __restrict__ rows, unsigned a1, unsigned a2) {

@@ -1376,4 +1376,12 @@ int32_t lfhe_bsk_image_form(const lfhe_ctx* ctx, uint32_t* out) {
     return LFHE_OK;
 }
 
+int32_t lfhe_lift_fallback_count(lfhe_ctx* ctx, uint64_t* out) {
+    return guarded(ctx, [&]() -> int32_t {
+        if (!out) throw std::invalid_argument("null argument");
+        *out = ctx->eng->lift_fallbacks();
+        return LFHE_OK;
+    });
+}
+
 }  // extern "C"

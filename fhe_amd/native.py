@@ -130,6 +130,7 @@ def load():
         "lfhe_rand": (i32, [vp, u32, C.c_char_p, u32, vp, pu64]),
         "lfhe_pbs_count": (i32, [vp, pu64]),
         "lfhe_bsk_image_form": (i32, [vp, C.POINTER(C.c_uint32)]),
+        "lfhe_lift_fallback_count": (i32, [vp, pu64]),
         "lfhe_make_lut": (i32, [vp, vp, vp]),
         "lfhe_pbs_batch": (i32, [vp, u64, vp, vp, u32, vp, vp]),
         "lfhe_pbs_batch_device": (i32, [vp, u64, vp, vp, vp, vp]),
@@ -585,6 +586,13 @@ class Context:
         f = C.c_uint32(0)
         self._ck(self._L.lfhe_bsk_image_form(self._h, C.byref(f)))
         return bool(f.value)
+
+    def lift_fallbacks(self) -> int:
+        """Ciphertexts bootstrapped again on the slow exact path because a lift came near the end of its
+        window (grouped key over 2^64; 0 for the other keys)."""
+        n = C.c_uint64()
+        self._ck(self._L.lfhe_lift_fallback_count(self._h, C.byref(n)))
+        return n.value
 
     def pbs_count(self) -> int:
         n = C.c_uint64()

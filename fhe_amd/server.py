@@ -21,6 +21,7 @@ import argparse
 import json
 import re
 import threading
+import time
 from http.server import BaseHTTPRequestHandler, ThreadingHTTPServer
 
 WIDTHS = (1, 8, 16, 32, 64, 128, 160, 256)
@@ -56,6 +57,99 @@ class GpuBackend:
     def evaluate(self, op: str, width: int, left: bytes, right, cond) -> bytes:
         return self.ctx.evaluate(op, width, left, right, cond)
 
+    def evaluate_batch(self, op: str, width: int, lefts: list, rights, conds) -> list:
+        return self.ctx.evaluate_batch(op, width, lefts, rights, conds)
+
+
+class Coalescer:
+    """Concurrent /evaluate requests become one engine call per (operator, width, operand kind).
+
+    The reference's clients fan requests out (tests/fhevm-suite/e2e/test/instance.ts:32-36 uses
+    Promise.all), and a bootstrap layer of ONE operation is a few dozen ciphertexts on a GPU that holds
+    a thousand: requests that wait behind the same lock anyway are cheaper served together.  One
+    worker thread owns the engine's evaluate path: it takes everything that is queued -- after a
+    window of `window` seconds from the first arrival, so that requests sent together are seen
+    together; while a batch runs, later arrivals queue up by themselves -- groups it, and issues one
+    `evaluate_batch` per group.  A batch that fails is retried one request at a time, so a bad
+    ciphertext fails its own request only.  Backends without `evaluate_batch` are served one by one."""
+
+    def __init__(self, backend, lock: threading.Lock, window: float = 0.001, max_batch: int = 256):
+        self.backend, self.lock, self.window, self.max_batch = backend, lock, window, max_batch
+        self.cv = threading.Condition()
+        self.queue: list = []
+        self.batches = 0          # engine calls issued
+        self.served = 0           # requests served
+        self.closed = False
+        self.thread = threading.Thread(target=self._run, name="evaluate-coalescer", daemon=True)
+        self.thread.start()
+
+    def close(self):
+        with self.cv:
+            self.closed = True
+            self.cv.notify_all()
+
+    def submit(self, op, width, left, right, cond) -> bytes:
+        item = {"args": (op, width, left, right, cond), "done": threading.Event(), "out": None, "err": None}
+        with self.cv:
+            if self.closed:
+                raise RuntimeError("server is shutting down")
+            self.queue.append(item)
+            self.cv.notify_all()
+        item["done"].wait()
+        if item["err"] is not None:
+            raise item["err"]
+        return item["out"]
+
+    @staticmethod
+    def _key(args):
+        op, width, left, right, cond = args
+        kind = "none" if right is None else "clear" if isinstance(right, int) else "ct"
+        return (op, width, kind, cond is not None)
+
+    def _run(self):
+        while True:
+            with self.cv:
+                while not self.queue and not self.closed:
+                    self.cv.wait()
+                if self.closed and not self.queue:
+                    return
+            if self.window > 0:
+                time.sleep(self.window)        # requests sent together arrive together
+            with self.cv:
+                taken, self.queue = self.queue[:], []
+            groups: dict = {}
+            for it in taken:
+                groups.setdefault(self._key(it["args"]), []).append(it)
+            for (op, width, kind, has_cond), items in groups.items():
+                for i in range(0, len(items), self.max_batch):
+                    self._serve(op, width, kind, has_cond, items[i:i + self.max_batch])
+
+    def _serve(self, op, width, kind, has_cond, items):
+        batch = getattr(self.backend, "evaluate_batch", None)
+        if len(items) > 1 and batch is not None and op != "cast":
+            try:
+                with self.lock:
+                    outs = batch(op, width, [it["args"][2] for it in items],
+                                 None if kind == "none" else [it["args"][3] for it in items],
+                                 [it["args"][4] for it in items] if has_cond else None)
+                self.batches += 1
+                self.served += len(items)
+                for it, o in zip(items, outs):
+                    it["out"] = bytes(o)
+                    it["done"].set()
+                return
+            except Exception:
+                pass                            # one of them is bad: find out which, below
+        for it in items:
+            try:
+                with self.lock:
+                    it["out"] = self.backend.evaluate(*it["args"])
+                self.batches += 1
+            except Exception as e:              # handed to the request's own thread
+                it["err"] = e
+            self.served += 1
+            it["done"].set()
+
 
 def _bytes_field(v) -> bytes:
     if isinstance(v, list):
@@ -78,8 +172,9 @@ def _width_of(body: dict) -> int:
     return w
 
 
-def make_handler(backend, threshold: bool, parties: int):
+def make_handler(backend, threshold: bool, parties: int, coalesce_window: float = 0.001):
     lock = threading.Lock()
+    coalescer = Coalescer(backend, lock, coalesce_window)
 
     class Handler(BaseHTTPRequestHandler):
         protocol_version = "HTTP/1.1"
@@ -175,8 +270,7 @@ def make_handler(backend, threshold: bool, parties: int):
                     except (KeyError, ValueError) as e:
                         self._fail(400, f"bad request: {e}")
                         return
-                    with lock:
-                        out = backend.evaluate(op, w, left, right, cond)
+                    out = coalescer.submit(op, w, left, right, cond)
                     self._raw(out)
                 else:
                     self._fail(404, "not found")
@@ -185,12 +279,20 @@ def make_handler(backend, threshold: bool, parties: int):
             except Exception as e:
                 self._fail(500, str(e))
 
+    Handler.coalescer = coalescer
     return Handler
 
 
-def serve(backend, addr: str = ":8448", threshold: bool = False, parties: int = 1) -> ThreadingHTTPServer:
+class _Server(ThreadingHTTPServer):
+    request_queue_size = 256      # clients connect in bursts (Promise.all over many requests); the default backlog is 5
+    daemon_threads = True
+
+
+def serve(backend, addr: str = ":8448", threshold: bool = False, parties: int = 1,
+          coalesce_window: float = 0.001) -> ThreadingHTTPServer:
     host, _, port = addr.rpartition(":")
-    srv = ThreadingHTTPServer((host or "0.0.0.0", int(port)), make_handler(backend, threshold, parties))
+    srv = _Server((host or "0.0.0.0", int(port)), make_handler(backend, threshold, parties, coalesce_window))
+    srv.coalescer = srv.RequestHandlerClass.coalescer
     return srv
 
 

@@ -49,9 +49,11 @@ extern "C" {
 #define LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK_GROUPED 3u
 /* the named set itself -- every modulus 2^64, as published -- with the key bits taken two at a time:
  * four GGSWs over 2^64 per pair of bits, half the transforms of set 1 (two-prime transform and lift
- * per step).  The lift of a step is exact unless a sum of 4096 products of a 23-bit digit and a sum of
- * four uniform 64-bit key words (standard deviation 2^90.4) leaves the +-2^97.6 the two primes tell
- * apart, 149 standard deviations out; set 1 is exact without condition. */
+ * per step).  The lift of a step is exact as long as a sum of 4096 products of a 23-bit digit and a sum
+ * of four uniform 64-bit key words (standard deviation 2^90.4) stays inside the +-2^97.6 the two primes
+ * tell apart, 149 standard deviations out; every lift is checked against a guard band at the end of
+ * that window and a ciphertext that reaches it is redone on a path that is exact without condition
+ * (lfhe_lift_fallback_count).  Set 1 is exact without condition. */
 #define LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_GROUPED 4u
 
 typedef struct lfhe_ctx lfhe_ctx;
@@ -316,6 +318,14 @@ int32_t lfhe_pbs_count(const lfhe_ctx* ctx, uint64_t* out);
  * non-invertible word).  No counterpart in the reference: a measurement aid (the benchmark prices
  * the work that is actually done). */
 int32_t lfhe_bsk_image_form(const lfhe_ctx* ctx, uint32_t* out);
+/* Parameter set 4 (grouped key over 2^64) watches every lift of its blind rotation: a ciphertext with a
+ * coefficient in the guard band at the end of the lift's window (the last eighth of it, 130 standard
+ * deviations out) is bootstrapped again, in the same call and on the device, with the step taken apart
+ * into four products that lift exactly without condition -- the same bits as an exact evaluation, at four
+ * times the transforms.  *out = how many ciphertexts of this context took that slow path so far (waits
+ * for the context's stream; always 0 for the other sets).  No counterpart in the reference: the guard
+ * of a construction the reference does not have. */
+int32_t lfhe_lift_fallback_count(lfhe_ctx* ctx, uint64_t* out);
 
 /* ---- the bootstrap path itself ------------------------------------------------------------------
  * Replaces: tfhe-rs keyswitch_programmable_bootstrap + generate_accumulator as the reference calls

@@ -25,7 +25,7 @@ def test_addon_loads_and_exports_the_engine_calls():
     out = subprocess.run(["node", "-e", js], cwd=NODE_DIR, capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, out.stderr
     d = json.loads(out.stdout)
-    for fn in ("open", "createContext", "keygen", "publicKey", "encrypt", "decrypt", "evaluate", "evaluateBatch",
+    for fn in ("open", "createContext", "keygen", "publicKey", "encrypt", "decrypt", "evaluate", "evaluateBatch", "evaluateAsync",
                "compressionKeygen", "compress", "decompress"):
         assert fn in d["fns"]
     # the reference SDK's method names (packages/luxfhejs/src/index.ts:56-122)
@@ -76,3 +76,11 @@ def test_plumbing_case_through_node():
     assert d["add"] == "59" and d["sub"] == "25" and d["lt"] == "0" and d["eq"] == "1"
     assert d["mul64"] == "18434227713315959936" and d["batch"] == ["1", "0"]
     assert d["restored"] == ["42", "17"] and d["blobBytes"] < 8192      # compressed for storage and back
+    # sixteen concurrent evaluate promises: right results, under twice the time of one, the event loop kept turning
+    c = d["concurrent"]
+    assert c["ok"] and c["all_ms"] < 2 * c["single_ms"] and c["ticks"] > 2, c
+    m = d["concurrentMul"]          # 16 x 1814 bootstraps cannot hide in one product's launches: batch rate instead
+    assert m["ok"] and m["all_ms"] < 10 * m["single_ms"], m
+    assert d["mixed"] == ["59", "rejected"]
+    print(f"node: one euint16 add {c['single_ms']:.1f} ms, sixteen concurrent {c['all_ms']:.1f} ms; "
+          f"one euint64 mul {m['single_ms']:.1f} ms, sixteen concurrent {m['all_ms']:.1f} ms")

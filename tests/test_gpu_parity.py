@@ -576,6 +576,49 @@ def test_grouped_key_over_the_torus_full_parameters():
         ctx.close()
 
 
+@pytest.mark.parametrize("factored", [True, False], ids=["factored", "plain"])
+def test_lift_guard_of_the_grouped_key_over_the_torus(factored):
+    """Every lift of the grouped key over 2^64 is checked against a guard band at the end of its window;
+    a ciphertext that reaches the band is bootstrapped again, on the device, with the step taken apart
+    into four unconditionally exact products.  Never taken at the shipped band (130 standard
+    deviations out); with the band forced down to the middle of the window every ciphertext takes the
+    slow path -- and must come back with exactly the oracle's bits, like the fast path."""
+    import os
+    orc, keys, ctx = _mk(13, seed=9, grouped=True, factored=factored)
+    os.environ["LFHE_G64_GUARD_FRAC"] = "1e-4"
+    try:
+        _, _, forced = _mk(13, seed=9, grouped=True, factored=factored)
+    finally:
+        del os.environ["LFHE_G64_GUARD_FRAC"]
+    try:
+        lwe_sk, glwe_sk, bskg, ksk = keys
+        pb = orc.prepare_bsk_grouped(bskg)
+        r = Rng(seed_bytes(35))
+        f = [lambda x: x, lambda x: (5 * x + 2) % 16]
+        luts_o = [orc.make_lut(g) for g in f]
+        luts_g = np.stack([ctx.make_lut(g) for g in f])
+        smalls = np.stack([r.u64s(orc.n + 1) for _ in range(9)])
+        smalls[3][:] = 0
+        li = np.array([i % 2 for i in range(9)], dtype=np.uint32)
+        want = np.stack([orc.blind_rotate(pb, smalls[c], luts_o[li[c]]).reshape(2, N) for c in range(9)])
+        assert np.array_equal(ctx.blind_rotate(smalls, luts_g, li), want)
+        assert ctx.lift_fallbacks() == 0
+        assert np.array_equal(forced.blind_rotate(smalls, luts_g, li), want)
+        # ciphertext 3 has an all-zero mask and body: every step multiplies by the GGSW of 1, whose lift is tiny
+        assert 7 <= forced.lift_fallbacks() <= 9
+        cts = np.stack([orc.encrypt_block(glwe_sk, m, r) for m in range(16)] * 20)     # 320: two per workgroup
+        li = np.array([m % 2 for m in range(320)], dtype=np.uint32)
+        out = ctx.pbs_batch(cts, luts_g, li)
+        before = forced.lift_fallbacks()
+        assert np.array_equal(forced.pbs_batch(cts, luts_g, li), out)
+        assert forced.lift_fallbacks() - before >= 300 and ctx.lift_fallbacks() == 0
+        for m in range(16):
+            assert np.array_equal(out[m], orc.pbs(ksk, pb, cts[m], luts_o[li[m]])), m
+    finally:
+        ctx.close()
+        forced.close()
+
+
 @pytest.mark.parametrize("params_id", [1, 2, 3, 4])
 def test_library_keygen_round_trip(params_id):
     """Keys made by the library itself (both bootstrapping-key moduli): encrypt -> bootstrap ->

@@ -93,3 +93,93 @@ def test_http_surface_on_gpu():
     finally:
         srv.shutdown()
         be.ctx.close()
+
+
+def _concurrent(url, n, a, b, op="add", width=16):
+    """n clients post /evaluate at the same moment; returns (results in order, seconds)."""
+    import time
+    c = LuxFHEClient(serverUrl=url)
+    outs, errs = [None] * n, []
+    gate = threading.Barrier(n + 1)
+
+    def one(i):
+        try:
+            gate.wait()
+            outs[i] = LuxFHEClient(serverUrl=url).evaluate(op, a[i], b[i], width)
+        except Exception as e:       # noqa: BLE001 -- reported by the caller
+            errs.append(e)
+    ths = [threading.Thread(target=one, args=(i,)) for i in range(n)]
+    for t in ths:
+        t.start()
+    gate.wait()
+    t0 = time.perf_counter()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    return outs, time.perf_counter() - t0, c
+
+
+def test_concurrent_requests_are_coalesced_on_the_mock():
+    """Sixteen clients at once: one engine call for the lot (the reference's clients fan out with
+    Promise.all, tests/fhevm-suite/e2e/test/instance.ts:32-36); a bad request among them fails alone."""
+    from tests.mock_engine import MockBackend
+    be = MockBackend()
+    srv = serve(be, "127.0.0.1:0", coalesce_window=0.05)
+    threading.Thread(target=srv.serve_forever, daemon=True).start()
+    url = f"http://127.0.0.1:{srv.server_address[1]}"
+    try:
+        c = LuxFHEClient(serverUrl=url)
+        a = [c.encrypt(100 * i, 16) for i in range(16)]
+        b = [c.encrypt(7 + i, 16) for i in range(16)]
+        before = srv.coalescer.batches
+        outs, _, _ = _concurrent(url, 16, a, b)
+        assert [c.decrypt(o) for o in outs] == [100 * i + 7 + i for i in range(16)]
+        assert srv.coalescer.batches - before <= 3 and srv.coalescer.served >= 16     # not sixteen engine calls
+        # a malformed ciphertext among good ones: its request fails, the others are served
+        results, gate = {}, threading.Barrier(3)
+
+        def post(name, left):
+            gate.wait()
+            try:
+                results[name] = _post(url + "/evaluate", {"op": "add", "left": list(left), "right": list(b[0]), "bitWidth": 16})[0]
+            except urllib.error.HTTPError as e:
+                results[name] = e.code
+        ths = [threading.Thread(target=post, args=("good", a[1])), threading.Thread(target=post, args=("bad", b"\x01\x02"))]
+        for t in ths:
+            t.start()
+        gate.wait()
+        for t in ths:
+            t.join()
+        assert results["good"] == 200 and results["bad"] >= 400
+    finally:
+        srv.shutdown()
+
+
+@pytest.mark.gpu
+def test_sixteen_concurrent_clients_cost_less_than_two_single_requests():
+    """On the GPU the coalesced sixteen share their bootstrap launches: under twice one request's time."""
+    import time
+    from fhe_amd.server import GpuBackend
+    be = GpuBackend(seed=bytes(range(32)))
+    srv, url = _start(be)
+    try:
+        c = LuxFHEClient(serverUrl=url)
+        a = [c.encrypt(100 * i, 16) for i in range(16)]
+        b = [c.encrypt(7 + i, 16) for i in range(16)]
+        c.evaluate("add", a[0], b[0], 16)                     # schedule built and uploaded
+        _concurrent(url, 16, a, b)                            # ... for the batch shape too
+        single = min(_timed(lambda: c.evaluate("add", a[0], b[0], 16)) for _ in range(3))
+        outs, dt, _ = _concurrent(url, 16, a, b)
+        assert [c.decrypt(o) for o in outs] == [100 * i + 7 + i for i in range(16)]
+        print(f"http: one euint16 add {single * 1e3:.1f} ms, sixteen concurrent {dt * 1e3:.1f} ms")
+        assert dt < 2 * single, (dt, single)
+    finally:
+        srv.shutdown()
+        be.ctx.close()
+
+
+def _timed(fn):
+    import time
+    t0 = time.perf_counter()
+    fn()
+    return time.perf_counter() - t0
