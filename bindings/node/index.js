@@ -41,6 +41,35 @@ function openLibrary(libPath) {
   opened = true;
 }
 
+// evaluateAsync requests gathered over one turn of the event loop: one native call per group of a shape
+function sendSingle(engine, it) {
+  native.evaluateAsync(engine.handle, it.code, it.bitWidth, it.left, it.rhs, it.scalar, it.cond).then(it.resolve, it.reject);
+}
+
+function flushPending(engine) {
+  const groups = engine._pending;
+  engine._pending = new Map();
+  engine._flushing = false;
+  for (const items of groups.values()) {
+    if (items.length === 1 || items[0].op === 'cast') { items.forEach((it) => sendSingle(engine, it)); continue; }
+    const first = items[0];
+    const outBits = COMPARISONS.has(first.op) ? 1 : first.bitWidth;
+    let p;
+    try {
+      p = native.evaluateBatchAsync(engine.handle, first.code, first.bitWidth, items.length, Buffer.concat(items.map((it) => it.left)),
+        first.rhs ? Buffer.concat(items.map((it) => it.rhs)) : null, first.scalar,
+        first.cond ? Buffer.concat(items.map((it) => it.cond)) : null, outBits);
+    } catch (e) {
+      items.forEach((it) => sendSingle(engine, it));       // one of them is malformed: each gets its own verdict
+      continue;
+    }
+    p.then((all) => {
+      const sz = all.length / items.length;
+      items.forEach((it, i) => it.resolve(all.slice(i * sz, (i + 1) * sz)));
+    }, () => items.forEach((it) => sendSingle(engine, it)));
+  }
+}
+
 class NativeEngine {
   /**
    * @param {{seed?: Uint8Array, device?: number, params?: number, libPath?: string, keygen?: boolean}} opts
@@ -104,12 +133,21 @@ class NativeEngine {
     const code = native.opFromName(op);
     if (code < 0) return Promise.reject(new Error(`unknown operation ${op}`));
     const scalar = typeof right === 'number' || typeof right === 'bigint' || typeof right === 'string';
+    let item;
     try {
       const rhs = right === undefined || right === null ? null : scalar ? toLE32(right) : Buffer.from(right);
-      return native.evaluateAsync(this.handle, code, bitWidth, Buffer.from(left), rhs, scalar, cond ? Buffer.from(cond) : null);
+      item = { code, op, bitWidth, left: Buffer.from(left), rhs, scalar, cond: cond ? Buffer.from(cond) : null };
     } catch (e) {
       return Promise.reject(e);
     }
+    // the calls of one turn of the event loop (a Promise.all over many) are gathered and sent together
+    const key = `${code}:${bitWidth}:${scalar ? 's' : item.rhs ? 'c' : 'n'}:${item.cond ? 1 : 0}:${item.left.length}:${item.rhs ? item.rhs.length : 0}`;
+    if (!this._pending) this._pending = new Map();
+    const promise = new Promise((resolve, reject) => { item.resolve = resolve; item.reject = reject; });
+    if (!this._pending.has(key)) this._pending.set(key, []);
+    this._pending.get(key).push(item);
+    if (!this._flushing) { this._flushing = true; setImmediate(() => flushPending(this)); }
+    return promise;
   }
 
   /** n independent instances bootstrapped together; operands are arrays of ciphertexts (or of clear values). */

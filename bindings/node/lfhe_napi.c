@@ -10,10 +10,11 @@
  * The library is opened with dlopen when the addon is first used, so loading the addon itself
  * needs neither a GPU nor the library; creating a context without a GPU throws.
  * The plain calls are synchronous.  evaluateAsync returns a Promise and runs on a libuv worker
- * thread, so a 40 ms multiplication does not block the event loop; requests that are pending at the
- * moment a worker starts and share context, operator, width and operand kind go out as ONE
+ * thread, so a 40 ms multiplication does not block the event loop; requests that are pending when
+ * a worker gets the library and share context, operator, width and operand kind go out as ONE
  * lfhe_evaluate_batch call (a bootstrap layer of a single operation leaves most of the GPU idle, so
- * sixteen concurrent promises cost little more than one).  The library is entered by one thread at
+ * sixteen concurrent promises cost little more than one); index.js gathers the calls of one event-
+ * loop turn before they get here (evaluateBatchAsync).  The library is entered by one thread at
  * a time (a context is single-threaded).
  * Values cross the boundary as 32-byte little-endian buffers (index.js converts BigInt).
  */
@@ -21,6 +22,7 @@
 #include <dlfcn.h>
 #include <node_api.h>
 #include <pthread.h>
+#include <time.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -471,8 +473,14 @@ static int same_shape(const eval_req* a, const eval_req* b) {
 static void eval_execute(napi_env env, void* data) {
     (void)env;
     eval_req* me = (eval_req*)data;
+    /* Whoever holds the library gathers what is pending at that moment: a worker that started while
+     * the JS thread was still queueing a burst (Promise.all over many calls) would otherwise take the
+     * first request alone, and so would each of its siblings.  Waiting here also means that everything
+     * that arrives while one batch runs goes out together in the next. */
+    pthread_mutex_lock(&g_lib_mutex);
     pthread_mutex_lock(&g_q_mutex);
     if (me->state != 0) {                       /* another worker took it into its batch */
+        pthread_mutex_unlock(&g_lib_mutex);
         while (me->state != 2) pthread_cond_wait(&g_q_cond, &g_q_mutex);
         pthread_mutex_unlock(&g_q_mutex);
         return;
@@ -491,7 +499,6 @@ static void eval_execute(napi_env env, void* data) {
     }
     pthread_mutex_unlock(&g_q_mutex);
 
-    pthread_mutex_lock(&g_lib_mutex);
     int done = 0;
     if (count > 1) {
         uint64_t out_sz = 0;
@@ -584,6 +591,89 @@ static napi_value js_evaluate_async(napi_env env, napi_callback_info info) {
         const int taken = q->state != 0;
         pthread_mutex_unlock(&g_q_mutex);
         if (!taken) { napi_delete_async_work(env, q->work); req_free(q); }
+        return throw_msg(env, "cannot queue async work");
+    }
+    return promise;
+}
+
+/* ---- evaluateBatchAsync: one lfhe_evaluate_batch call on the libuv pool ---- */
+typedef struct {
+    lfhe_ctx* c;
+    uint32_t op, bits, count;
+    int scalar;
+    uint8_t *l, *r, *cd, *out;
+    size_t out_len;
+    int32_t rc;
+    char err[320];
+    napi_deferred deferred;
+    napi_async_work work;
+} batch_req;
+
+static void batch_free(batch_req* q) { free(q->l); free(q->r); free(q->cd); free(q->out); free(q); }
+
+static void batch_execute(napi_env env, void* data) {
+    (void)env;
+    batch_req* q = (batch_req*)data;
+    pthread_mutex_lock(&g_lib_mutex);
+    q->rc = p_lfhe_evaluate_batch(q->c, q->op, q->bits, q->count, q->l, q->r, q->scalar, q->cd, q->out);
+    if (q->rc != LFHE_OK) snprintf(q->err, sizeof q->err, "Evaluation failed (%d): %s", q->rc, p_lfhe_last_error(q->c));
+    pthread_mutex_unlock(&g_lib_mutex);
+}
+
+static void batch_complete(napi_env env, napi_status status, void* data) {
+    batch_req* q = (batch_req*)data;
+    napi_value buf, e, m;
+    void* dst;
+    if (status == napi_ok && q->rc == LFHE_OK && napi_create_buffer_copy(env, q->out_len, q->out, &dst, &buf) == napi_ok) {
+        napi_resolve_deferred(env, q->deferred, buf);
+    } else {
+        napi_create_string_utf8(env, status != napi_ok ? "evaluation was cancelled" : q->rc != LFHE_OK ? q->err : "out of memory",
+                                NAPI_AUTO_LENGTH, &m);
+        napi_create_error(env, NULL, m, &e);
+        napi_reject_deferred(env, q->deferred, e);
+    }
+    napi_delete_async_work(env, q->work);
+    batch_free(q);
+}
+
+/* evaluateBatchAsync(ctx, op, bits, count, lhsAll, rhsAll|null, rhsIsScalar, condAll|null, outBits) -> Promise<Buffer> */
+static napi_value js_evaluate_batch_async(napi_env env, napi_callback_info info) {
+    NEED_LIB();
+    napi_value argv[9];
+    if (!get_args(env, info, 9, argv)) return NULL;
+    lfhe_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return NULL;
+    uint32_t op, bits, count, out_bits;
+    napi_get_value_uint32(env, argv[1], &op);
+    napi_get_value_uint32(env, argv[2], &bits);
+    napi_get_value_uint32(env, argv[3], &count);
+    napi_get_value_uint32(env, argv[8], &out_bits);
+    const uint8_t *l, *r, *cd; size_t ll, rl, cl;
+    if (!get_bytes(env, argv[4], &l, &ll) || !get_bytes(env, argv[5], &r, &rl) || !get_bytes(env, argv[7], &cd, &cl)) return NULL;
+    bool scalar = false;
+    napi_get_value_bool(env, argv[6], &scalar);
+    uint64_t in_sz = 0, out_sz = 0, rhs_sz = 0, cond_sz = 0;
+    if (p_lfhe_ciphertext_size(c, bits, &in_sz) != LFHE_OK || p_lfhe_ciphertext_size(c, out_bits, &out_sz) != LFHE_OK)
+        return throw_msg(env, "unsupported bit width");
+    p_lfhe_ciphertext_size(c, 1, &cond_sz);
+    const int shift = op >= LFHE_OP_SHL && op <= LFHE_OP_ROTR;
+    if (shift) p_lfhe_ciphertext_size(c, 8, &rhs_sz); else rhs_sz = in_sz;
+    if (!count || !l || ll != (size_t)count * in_sz || (r && rl != (size_t)count * (scalar ? 32 : rhs_sz)) ||
+        (cd && cl != (size_t)count * cond_sz))
+        return throw_msg(env, "operand arrays do not hold `count` ciphertexts of the stated width");
+    batch_req* q = (batch_req*)calloc(1, sizeof *q);
+    if (!q) return throw_msg(env, "out of memory");
+    q->c = c; q->op = op; q->bits = bits; q->count = count; q->scalar = scalar ? 1 : 0;
+    q->l = dup_bytes(l, ll); q->r = dup_bytes(r, rl); q->cd = dup_bytes(cd, cl);
+    q->out_len = (size_t)count * out_sz;
+    q->out = (uint8_t*)malloc(q->out_len + 1);
+    if (!q->l || (r && !q->r) || (cd && !q->cd) || !q->out) { batch_free(q); return throw_msg(env, "out of memory"); }
+    napi_value promise, name;
+    if (napi_create_promise(env, &q->deferred, &promise) != napi_ok) { batch_free(q); return throw_msg(env, "cannot create a promise"); }
+    napi_create_string_utf8(env, "lfhe.evaluateBatch", NAPI_AUTO_LENGTH, &name);
+    if (napi_create_async_work(env, NULL, name, batch_execute, batch_complete, q, &q->work) != napi_ok ||
+        napi_queue_async_work(env, q->work) != napi_ok) {
+        batch_free(q);
         return throw_msg(env, "cannot queue async work");
     }
     return promise;
@@ -766,7 +856,8 @@ static napi_value init(napi_env env, napi_value exports) {
         {"health", js_health, 1}, {"publicKey", js_public_key, 1}, {"keysExport", js_keys_export, 1},
         {"keysImport", js_keys_import, 1}, {"encrypt", js_encrypt, 1}, {"encryptPublic", js_encrypt_public, 1},
         {"decrypt", js_decrypt, 1}, {"opFromName", js_op_from_name, 0}, {"evaluate", js_evaluate, 1},
-        {"evaluateBatch", js_evaluate_batch, 1}, {"evaluateAsync", js_evaluate_async, 0}, {"pbsCount", js_pbs_count, 1},
+        {"evaluateBatch", js_evaluate_batch, 1}, {"evaluateAsync", js_evaluate_async, 0},
+        {"evaluateBatchAsync", js_evaluate_batch_async, 0}, {"pbsCount", js_pbs_count, 1},
         {"rand", js_rand, 1}, {"importClientKeys", js_import_client, 1}, {"keygenServer", js_keygen_server, 1},
         {"setPkeKey", js_set_pke_key, 1}, {"castFromPke", js_cast_from_pke, 1},
         {"compressionKeygen", js_compression_keygen, 1}, {"compress", js_compress, 1}, {"decompress", js_decompress, 1},

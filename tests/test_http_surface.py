@@ -95,7 +95,7 @@ def test_http_surface_on_gpu():
         be.ctx.close()
 
 
-def _concurrent(url, n, a, b, op="add", width=16):
+def _concurrent(url, n, a, b, op="add", width=16, hex_payloads=False):
     """n clients post /evaluate at the same moment; returns (results in order, seconds)."""
     import time
     c = LuxFHEClient(serverUrl=url)
@@ -105,7 +105,7 @@ def _concurrent(url, n, a, b, op="add", width=16):
     def one(i):
         try:
             gate.wait()
-            outs[i] = LuxFHEClient(serverUrl=url).evaluate(op, a[i], b[i], width)
+            outs[i] = LuxFHEClient(serverUrl=url, hex_payloads=hex_payloads).evaluate(op, a[i], b[i], width)
         except Exception as e:       # noqa: BLE001 -- reported by the caller
             errs.append(e)
     ths = [threading.Thread(target=one, args=(i,)) for i in range(n)]
@@ -163,15 +163,20 @@ def test_sixteen_concurrent_clients_cost_less_than_two_single_requests():
     be = GpuBackend(seed=bytes(range(32)))
     srv, url = _start(be)
     try:
-        c = LuxFHEClient(serverUrl=url)
+        # ciphertexts as hex strings: as number arrays (the reference clients' encoding, also accepted) the sixteen
+        # bodies are 16 MB of JSON numbers that the server's interpreter parses one after the other for 0.2 s
+        c = LuxFHEClient(serverUrl=url, hex_payloads=True)
         a = [c.encrypt(100 * i, 16) for i in range(16)]
         b = [c.encrypt(7 + i, 16) for i in range(16)]
         c.evaluate("add", a[0], b[0], 16)                     # schedule built and uploaded
-        _concurrent(url, 16, a, b)                            # ... for the batch shape too
+        _concurrent(url, 16, a, b, hex_payloads=True)         # ... for the batch shape too
         single = min(_timed(lambda: c.evaluate("add", a[0], b[0], 16)) for _ in range(3))
-        outs, dt, _ = _concurrent(url, 16, a, b)
+        before = srv.coalescer.batches
+        outs, dt, _ = _concurrent(url, 16, a, b, hex_payloads=True)
         assert [c.decrypt(o) for o in outs] == [100 * i + 7 + i for i in range(16)]
-        print(f"http: one euint16 add {single * 1e3:.1f} ms, sixteen concurrent {dt * 1e3:.1f} ms")
+        print(f"http: one euint16 add {single * 1e3:.1f} ms, sixteen concurrent {dt * 1e3:.1f} ms in "
+              f"{srv.coalescer.batches - before} engine calls")
+        assert srv.coalescer.batches - before <= 3
         assert dt < 2 * single, (dt, single)
     finally:
         srv.shutdown()

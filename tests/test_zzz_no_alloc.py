@@ -5,6 +5,8 @@ contents), across the key-switch paths (matrix cores from 128 ciphertexts, VALU 
 blind-rotation kernels (256- and 512-thread), for every bootstrapping-key flavour."""
 import numpy as np
 import pytest
+import torch  # noqa: F401 -- at collection time, before any test loads liblfhe: PyTorch ships a HIP runtime of its
+#                own, and a process that loads the system's first (through liblfhe) finds no GPU in torch afterwards
 
 pytestmark = pytest.mark.gpu
 
