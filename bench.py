@@ -62,7 +62,11 @@ def measured_counters(flavour: str, batch: int) -> dict:
 # algorithmic bytes of one batch launch: both keys once + one ciphertext in and out per bootstrap
 BSK_BYTES, KSK_BYTES, CT_BYTES = 60162048, 60227584, 16392
 # device image of the bootstrapping key (f64 residues in the transform domain)
-KEY_IMAGE_BYTES = {"q64": 918 * 131072, "q64_grouped": 1836 * 131072, "prime": 918 * 65536, "grouped": 1836 * 65536}
+KEY_IMAGE_BYTES = {"q64": 918 * 131072, "q64_grouped": 1836 * 131072, "prime": 918 * 65536, "grouped": 1836 * 65536,
+                   "grouped3": 2448 * 65536}
+# three key bits per step: 306 steps of 4 transforms, per point 20 products for the step's GGSW entries (five each,
+# factored) + 4 for the external product
+MODMUL_PER_PBS_GROUPED3 = 306 * (4 * 11264 + 24 * 2048)
 
 
 # bootstrapping-key flavour -> (parameter set id, label, kernel, VALU peak in butterflies/s per GPU)
@@ -71,6 +75,7 @@ FLAVOURS = {
     "q64_grouped": (4, "2^64, key bits in pairs", "k_blind_rotate_g64_pair<true>"),
     "prime": (2, "703687441727489 (NTT prime)", "k_blind_rotate_q"),
     "grouped": (3, "703687441727489 (NTT prime), key bits in pairs", "k_blind_rotate_q2_pair<false, true>"),
+    "grouped3": (5, "703687441727489 (NTT prime), key bits in triples", "k_blind_rotate_q3<2>"),
 }
 
 
@@ -82,7 +87,9 @@ def cpu_baseline(seconds_budget: float = 20.0, flavour: str = "prime"):
     orc = Oracle()
     lwe_sk, glwe_sk, bsk, ksk = orc.gen_keys(seed_bytes(9))
     orc.set_ms(orc.gen_ms_zeros(lwe_sk, seed_bytes(9), orc.ms_params().zeros_count))   # same pipeline as the GPU's
-    if flavour == "grouped":
+    if flavour == "grouped3":
+        pb = orc.prepare_bsk_qp_grouped(orc.gen_bsk_qp_grouped(lwe_sk, glwe_sk, seed_bytes(9), 3), 3)
+    elif flavour == "grouped":
         pb = orc.prepare_bsk_qp_grouped(orc.gen_bsk_qp_grouped(lwe_sk, glwe_sk, seed_bytes(9)))
     elif flavour == "q64_grouped":
         pb = orc.prepare_bsk_grouped(orc.gen_bsk_grouped(lwe_sk, glwe_sk, seed_bytes(9)))
@@ -275,7 +282,9 @@ def main(argv=None, backend=None):
         br_s = br_ms * 1e-3
         # priced with the products the kernel really executes (12 per point with the factored key image, 16 without)
         modmul = MODMUL_PER_PBS
-        if flavour in ("grouped", "q64_grouped"):
+        if flavour == "grouped3":
+            modmul = MODMUL_PER_PBS_GROUPED3
+        elif flavour in ("grouped", "q64_grouped"):
             modmul = MODMUL_PER_PBS_GROUPED_FACTORED if factored else MODMUL_PER_PBS_GROUPED
         achieved = B * modmul / br_s / 1e9
         peak = PEAK_GBFLY_PER_PRIME / 2 if flavour in ("q64", "q64_grouped") else PEAK_GBFLY_PER_PRIME
@@ -285,7 +294,11 @@ def main(argv=None, backend=None):
         classic = B * MODMUL_PER_PBS / br_s / 1e9 / peak
         unit_note = (f"achieved = {B} bootstraps x modmul_per_pbs / blind-rotation launch time; modmul_per_pbs counts the modular "
                      "products this kernel's algorithm executes")
-        if flavour in ("grouped", "q64_grouped"):
+        if flavour == "grouped3":
+            unit_note += (f": {MODMUL_PER_PBS_GROUPED3} = 306 steps x (4 transforms x 11264 butterflies + 24 products x 2048 points) "
+                          f"with the key bits in triples, where the classic one-bit-per-step count ({MODMUL_PER_PBS}) would read "
+                          f"frac = {classic:.3f}")
+        elif flavour in ("grouped", "q64_grouped"):
             unit_note += (f": {MODMUL_PER_PBS_GROUPED_FACTORED if factored else MODMUL_PER_PBS_GROUPED} = 459 steps x (4 transforms x "
                           f"11264 butterflies + {12 if factored else 16} products x 2048 points) with the key bits in pairs, where the "
                           f"classic one-bit-per-step count (918 x 4 transforms + 918 x 4 x 2048 products = {MODMUL_PER_PBS}) would "

@@ -25,7 +25,9 @@ Engine::Engine(int device, const EngineParams& p) : device_(device), prm_(p) {
     if (p.lwe_dim < 1 || p.lwe_dim > 4096) throw std::runtime_error("unsupported LWE dimension");
     if (p.bsk_modulus != 0 && p.bsk_modulus != QP_U)
         throw std::runtime_error("unsupported bootstrapping-key modulus: 0 (2^64) or 703687441727489");
-    if (p.bsk_grouping != 1 && p.bsk_grouping != 2) throw std::runtime_error("unsupported key grouping: 1 or 2");
+    if (p.bsk_grouping < 1 || p.bsk_grouping > 3) throw std::runtime_error("unsupported key grouping: 1, 2 or 3");
+    if (p.bsk_grouping == 3 && p.bsk_modulus != QP_U)
+        throw std::runtime_error("unsupported key grouping: three key bits per step need the prime bootstrapping-key modulus");
     if (p.ms_zeros_count && (p.ms_bound_log2 < 27 || p.ms_bound_log2 > 63 || !(p.ms_r_sigma_factor > 0) ||
                              !(p.ms_r_sigma_factor < 1024) || !(p.ms_input_variance >= 0) ||
                              !(p.ms_input_variance < 1e-3)))
@@ -44,7 +46,7 @@ Engine::Engine(int device, const EngineParams& p) : device_(device), prm_(p) {
     // the 512-thread kernels hold one ciphertext per CU at a time (grouped key: 207 registers) or two
     // (one key bit per step); measured with the grouped key: 4.2 vs 4.5 ms at 64 ciphertexts, 4.6 vs 4.8 at
     // 256, but 8.8 vs 7.4 ms at 512
-    wide_below_ = (p.bsk_grouping == 2 ? 1 : 2) * cu_count_;
+    wide_below_ = (p.bsk_grouping >= 2 ? 1 : 2) * cu_count_;
     if (const char* e = std::getenv("LFHE_WIDE_BELOW")) wide_below_ = std::atoi(e);   // tuning / A-B runs
     pair_above_ = -2;   // automatic (pair_threshold)
     lockstep_above_ = 4 * cu_count_;
@@ -155,6 +157,32 @@ bool Engine::build_bsk_image(const u64* host_bsk, size_t total, double* dst) {
     const size_t row = single_modulus() ? BSKQ_ROW : BSK_ROW;
     u64* d_raw = nullptr;
     HC(hipMalloc(&d_raw, slab * 4 * N * sizeof(u64)));
+    if (prm_.bsk_grouping == 3) {
+        // three key bits per step: every slab of eight groups is transformed into a staging buffer and
+        // written out in the factored layout its kernel streams (kernels.hip: k_bsk_factor3).  A key with a
+        // non-invertible word (one in 10^8) has no such image: the caller has to come with another key.
+        double* d_tmp = nullptr;
+        int* d_flag = nullptr;
+        HC(hipMalloc(&d_tmp, slab * BSKQ_ROW * sizeof(double)));
+        HC(hipMalloc(&d_flag, sizeof(int)));
+        HC(hipMemsetAsync(d_flag, 0, sizeof(int), stream_));
+        for (size_t i0 = 0; i0 < total; i0 += slab) {
+            const size_t cnt = (total - i0) < slab ? (total - i0) : slab;
+            HC(hipMemcpyAsync(d_raw, host_bsk + i0 * 4 * N, cnt * 4 * N * sizeof(u64), hipMemcpyHostToDevice, stream_));
+            launch_bskq_prepare(T_, d_raw, d_tmp, cnt * 4, stream_);
+            launch_bsk_factor3(T_, d_tmp, dst + i0 * row, cnt / 8, d_flag, stream_);
+            HC(hipGetLastError());
+            HC(hipStreamSynchronize(stream_));
+        }
+        int flag = 0;
+        HC(hipMemcpy(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost));
+        HC(hipFree(d_tmp));
+        HC(hipFree(d_flag));
+        HC(hipFree(d_raw));
+        if (flag) throw std::runtime_error("unsupported key: a word of the bootstrapping key is not invertible modulo the prime "
+                                           "(one key in 10^8); generate another key");
+        return true;
+    }
     auto transform_all = [&]() {
         for (size_t i0 = 0; i0 < total; i0 += slab) {
             const size_t cnt = (total - i0) < slab ? (total - i0) : slab;
@@ -294,7 +322,7 @@ void Engine::attach_device_keys(double* bsk_dev, u64* ksk_dev_image) {
     bsk_factored_ = (zc & FACTORED_FLAG) != 0;
     zc &= ~FACTORED_FLAG;
     if (zc != 0 && zc != prm_.ms_zeros_count) throw std::runtime_error("attached key image does not match the parameter set");
-    if (bsk_factored_ && prm_.bsk_grouping != 2)
+    if (bsk_factored_ && prm_.bsk_grouping < 2)
         throw std::runtime_error("attached key image does not match the parameter set");
     set_ms_params((u32)zc);
     build_ksk_limbs();
@@ -474,7 +502,7 @@ void Engine::blind_rotate_with(const double* bsk, uint32_t n, const u64* lwe_sma
     HC(hipSetDevice(device_));
     const size_t n1 = (size_t)n + 1;
     // ciphertexts in flight: four per CU, two with the one-bit-per-step key over 2^64
-    const size_t slots = (size_t)(single_modulus() || prm_.bsk_grouping == 2 ? 4 : 2) * (size_t)cu_count_;
+    const size_t slots = (size_t)(single_modulus() || prm_.bsk_grouping >= 2 ? 4 : 2) * (size_t)cu_count_;
     if (omap.idx && !omap.ops) throw std::logic_error("block map without a period");
     size_t chunk = br_chunk_ > 0 ? (omap.ops ? ((size_t)br_chunk_ + omap.ops - 1) / omap.ops * omap.ops : (size_t)br_chunk_)
                                  : launch_chunk(count, omap.ops, slots);
@@ -495,7 +523,8 @@ void Engine::blind_rotate_with(const double* bsk, uint32_t n, const u64* lwe_sma
         if (single_modulus())
             launch_blind_rotate_q(T_, bsk, in, (int)n, luts, li, gout, lout, cnt, omap,
                                   1.0 / (double)qp_gadget(), wide_below_, lockstep_above_,
-                                  prm_.bsk_grouping == 2 && fact ? 3 : (int)prm_.bsk_grouping, pair_threshold(cnt),
+                                  prm_.bsk_grouping == 3 ? 4 : prm_.bsk_grouping == 2 && fact ? 3 : (int)prm_.bsk_grouping,
+                                  pair_threshold(cnt),
                                   stream_);
         else
             launch_blind_rotate(T_, bsk, in, (int)n, luts, li, gout, lout, cnt, omap,

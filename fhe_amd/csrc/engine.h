@@ -62,6 +62,8 @@ void launch_blind_rotate(const Tables& T, const double* bsk, const u64* lwe_smal
                          const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
                          const BlockMap& omap, int grouping, int pair_above, const G64Guard& guard, hipStream_t st);
 void launch_bskq_prepare(const Tables& T, const u64* in, double* out, size_t polys, hipStream_t st);
+// three key bits per step: groups of eight transformed GGSWs (src) -> the factored image the kernel streams (dst)
+void launch_bsk_factor3(const Tables& T, const double* src, double* dst, size_t groups, int* degenerate, hipStream_t st);
 // grouped key image -> factored form, in place (row_words: BSKQ_ROW or BSK_ROW); *degenerate (device) is set
 // when a word has none
 void launch_bsk_factor(const Tables& T, double* img, size_t groups, size_t row_words, int* degenerate, hipStream_t st);
@@ -143,7 +145,10 @@ public:
     bool has_keys() const { return d_bsk_ && d_ksk_; }
 
     // GGSWs in the bootstrapping key
-    size_t ggsw_count_for(uint32_t n) const { return prm_.bsk_grouping == 2 ? 4 * (((size_t)n + 1) / 2) : n; }
+    size_t ggsw_count_for(uint32_t n) const {
+        const size_t b = prm_.bsk_grouping;
+        return b >= 2 ? ((size_t)1 << b) * (((size_t)n + b - 1) / b) : n;
+    }
     size_t bsk_ggsw_count() const { return ggsw_count_for(prm_.lwe_dim); }
     size_t bsk_raw_words() const { return bsk_ggsw_count() * 4 * N; }
     size_t ksk_words() const { return (size_t)N * prm_.ks_level * (prm_.lwe_dim + 1); }

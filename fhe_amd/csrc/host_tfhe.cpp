@@ -103,16 +103,22 @@ static void parallel_for(size_t n, int threads, F&& fn) {
     for (auto& th : pool) th.join();
 }
 
-// the bit each GGSW of the bootstrapping key encrypts: the key bits themselves, or per pair (s, s')
-// the four products (1-s)(1-s'), s(1-s'), (1-s)s', s s' (s' = 0 past the end of an odd-length key)
+// the bit each GGSW of the bootstrapping key encrypts: the key bits themselves, or per group of b = 2 or 3
+// key bits the 2^b products over the group of s_i (bit i of the GGSW's number set) or 1 - s_i (bits past
+// the end of the key count as 0); for pairs: (1-s)(1-s'), s(1-s'), (1-s)s', s s'
 static std::vector<uint64_t> bsk_messages(const EngineParams& p, const uint64_t* lwe_sk) {
     std::vector<uint64_t> msg;
-    if (p.bsk_grouping == 2) {
-        for (uint32_t g = 0; 2 * g < p.lwe_dim; ++g) {
-            const uint64_t s0 = lwe_sk[2 * g], s1 = 2 * g + 1 < p.lwe_dim ? lwe_sk[2 * g + 1] : 0;
-            msg.push_back((1 - s0) & (1 - s1)); msg.push_back(s0 & (1 - s1));
-            msg.push_back((1 - s0) & s1); msg.push_back(s0 & s1);
-        }
+    const uint32_t b = p.bsk_grouping;
+    if (b >= 2) {
+        for (uint32_t g = 0; b * g < p.lwe_dim; ++g)
+            for (uint32_t m = 0; m < (1u << b); ++m) {
+                uint64_t v = 1;
+                for (uint32_t i = 0; i < b; ++i) {
+                    const uint64_t s = b * g + i < p.lwe_dim ? lwe_sk[b * g + i] : 0;
+                    v &= (m >> i & 1) ? s : 1 - s;
+                }
+                msg.push_back(v);
+            }
     } else {
         msg.assign(lwe_sk, lwe_sk + p.lwe_dim);
     }

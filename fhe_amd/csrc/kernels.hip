@@ -1037,6 +1037,329 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_q2_pair(Tables T, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// THREE key bits per step (prime ring modulus).  Per triple of key bits (s, s', s'') the key holds eight
+// GGSWs, GGSW m of the product over the bits of s_i (bit i of m set) or 1 - s_i, and a step is
+//     acc <- (sum over m of X^(a [m&1] + a' [m&2] + a'' [m&4]) G_m) [.] acc :
+// 306 steps of one external product instead of 459.  Point-wise the step's GGSW entry is
+//     B = A0 + m3 A1,   A0 = K0 + m1 K1 + m2 K2 + m1 m2 K3,   A1 = K4 + m1 K5 + m2 K6 + m1 m2 K7
+// with m1, m2, m3 the monomial factors of the three exponents at the position, and each A is held
+// factored as d (m1 + a)(m2 + b) + c like the pairs' image: five modular products per entry, 24 per
+// position with the external product itself (12 with pairs), against a third fewer transforms --
+// 12 % fewer FP64 instructions per bootstrap, a third more key words.
+//
+// Key image (k_bsk_factor3 writes it): per group and per position e = 8 t + p the eight words of an
+// entry q travel as four 16-byte pairs w = 0..3 = (a1, b1), (d1, c1), (a0, b0), (d0, c0):
+//     [group][p 0..7][w 0..3][q 0..3][thread][2]       (doubles; 65536 per group)
+// so that one unit of four loads (one per q) feeds one position and the per-entry state stays at two
+// values (B and the running m3 A1) -- the registers of the pairs' kernel.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double mod_inverse(double x, const Prime& P, u64 p);
+constexpr int BSK3_GROUP = 8 * BSKQ_ROW;    // doubles per group of eight GGSWs
+LFHE_HD unsigned bsk3_off(unsigned p, unsigned w, unsigned q, unsigned t) { return (((p * 4 + w) * 4 + q) * NT + t) * 2; }
+
+// eight GGSW rows in the transform layout of k_bskq_prepare (src: [m][q][c4][t][2]) -> the factored image
+__global__ void __launch_bounds__(256) k_bsk_factor3(Tables T, const double* __restrict__ src, double* __restrict__ dst,
+                                                     size_t groups, int* __restrict__ degenerate) {
+    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;     // (group, q, position e)
+    if (id >= groups * 4 * N) return;
+    const size_t g = id / (4 * N);
+    const unsigned q = (unsigned)(id / N % 4), e = (unsigned)(id % N);
+    const unsigned t = e >> 3, pp = e & 7;
+    const Prime P = T.pr[0];
+    const double* in = src + g * BSK3_GROUP + bsk_off(0, q, pp >> 1, t) + (pp & 1);
+    double k[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) k[m] = mnorm(mnorm(in[(size_t)m * BSKQ_ROW], P), P);
+    double out[8];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const double k0 = k[4 * half], k1 = k[4 * half + 1], k2 = k[4 * half + 2], k3 = k[4 * half + 3];
+        if (k3 == 0.0) { atomicOr(degenerate, 1); return; }
+        const double inv = mod_inverse(k3, P, P0_U);
+        const double a = mnorm(mmul(k2, inv, P), P), b = mnorm(mmul(k1, inv, P), P);
+        const double c = mnorm(k0 - mmul(k1, a, P), P);
+        // pairs in load order: (a1, b1), (d1, c1), (a0, b0), (d0, c0)
+        const int base = half == 1 ? 0 : 4;
+        out[base] = a; out[base + 1] = b; out[base + 2] = k3; out[base + 3] = c;
+    }
+    double* o = dst + g * BSK3_GROUP;
+#pragma unroll
+    for (unsigned w = 0; w < 4; ++w) {
+        const unsigned at = bsk3_off(pp, w, q, t);
+        o[at] = out[2 * w];
+        o[at + 1] = out[2 * w + 1];
+    }
+}
+
+void launch_bsk_factor3(const Tables& T, const double* src, double* dst, size_t groups, int* degenerate, hipStream_t st) {
+    const size_t words = groups * 4 * N;
+    hipLaunchKernelGGL(k_bsk_factor3, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, T, src, dst, groups, degenerate);
+}
+
+// NC ciphertexts per workgroup (2: throughput, as k_blind_rotate_q2_pair; 1: launches that would leave
+// compute units without a workgroup otherwise).  Transforms, exchanges and fences are the pairs' kernel's.
+template <int NC>
+__global__ void __launch_bounds__(NT, 2) k_blind_rotate_q3(Tables T, const double* __restrict__ bsk,
+                                                          const u64* __restrict__ lwe_small, int n,
+                                                          const u64* __restrict__ luts,
+                                                          const u32* __restrict__ lut_index,
+                                                          u64* __restrict__ glwe_out,
+                                                          u64* __restrict__ lwe_out, BlockMap omap,
+                                                          double inv_g, unsigned count) {
+    constexpr bool LOCKSTEP = false;
+    const unsigned t = threadIdx.x;
+    const Prime P = T.pr[0];
+    size_t ct[NC];
+    const u64* __restrict__ lwe[NC];
+    double x[NC][2][E];   // accumulator between steps, working residues inside a step
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const size_t want = (size_t)blockIdx.x * NC + c;
+        ct[c] = want < count ? want : (size_t)count - 1;
+        lwe[c] = lwe_small + ct[c] * (size_t)(n + 1);
+        const u64* __restrict__ lut = luts + (size_t)(lut_index ? lut_index[omap.ops ? ct[c] % omap.ops : ct[c]] : 0) * N;
+        const unsigned bt = modswitch_2n(lwe[c][n]);
+        const unsigned a = (2 * N - bt) & (2 * N - 1);  // multiply by X^-b~
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            bool neg;
+            const double v = torus_to_qp(lut[rot_index(own1(t, j), a, neg)]);
+            x[c][0][j] = 0.0;
+            x[c][1][j] = neg ? -v : v;
+        }
+    }
+    const double* __restrict__ twf_small = lds_dyn + NC * LDS_WORDS;   // entries 0..63 of the forward table
+    const double* __restrict__ twi_small = twf_small + G2_TW_SMALL;
+    for (unsigned i = t; i < (unsigned)G2_TW_SMALL; i += NT) {
+        lds_dyn[NC * LDS_WORDS + i] = T.tw_fwd[0][i];
+        lds_dyn[NC * LDS_WORDS + G2_TW_SMALL + i] = T.tw_inv[0][i];
+    }
+    __syncthreads();
+    // twiddles of passes 3 and 4 stay in registers for the whole blind rotation (as in the pairs' kernel)
+    double w3f[7], w4f[7], w3i[7], w4i[7];
+    load_tw8(T.tw_fwd[0], base3(t), w3f);
+    load_tw4x2(T.tw_fwd[0], t, w4f);
+    load_tw8(T.tw_inv[0], base3(t), w3i);
+    load_tw4x2(T.tw_inv[0], t, w4i);
+    w4f[6] = 0.0; w4i[6] = 0.0;
+
+    auto buf = [&](int c, int q) { return lds_dyn + (2 * c + q) * POLY_STRIDE; };
+    const int groups = (n + 2) / 3;
+    for (int g = 0; g < groups; ++g) {
+        unsigned am[NC][3];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) am[c][i] = 3 * g + i < n ? modswitch_2n(lwe[c][3 * g + i]) : 0u;
+        unsigned tt = t, zero = 0;
+        asm volatile("" : "+v"(tt));
+        asm volatile("" : "+s"(zero));
+        const double* __restrict__ mono = T.mono + zero;
+        const double* __restrict__ rows = bsk + (size_t)g * BSK3_GROUP;
+        double w[7];
+        // ---- forward transform of the digits
+        load_tw8(twf_small, 1, w);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                for (int j = 0; j < E; ++j) x[c][q][j] = __builtin_rint(x[c][q][j] * inv_g);
+                ct_radix8(x[c][q], w, P);
+                st_o1p12(buf(c, q), tt, x[c][q]);
+            }
+        load_tw8(twf_small, base2(tt), w);
+        __syncthreads();
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) ld_o2p12(buf(c, q), tt, x[c][q]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) ct_radix8(x[c][q], w, P);
+        phase_sync<g2_sync_after<LOCKSTEP>(1)>();
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) st_o2p23(buf(c, q), tt, x[c][q]);
+        phase_sync<g2_sync_after<LOCKSTEP>(2)>();
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) ld_o3p23(buf(c, q), tt, x[c][q]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) ct_radix8(x[c][q], w3f, P);
+        phase_sync<g2_sync_after<LOCKSTEP>(3)>();
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) st_o3p34(buf(c, q), tt, x[c][q]);
+        phase_sync<g2_sync_after<LOCKSTEP>(4)>();
+        // ---- last forward pass, the step's GGSW formed point by point and applied, first inverse pass
+        asm volatile("" : "+v"(tt));
+        {
+            const unsigned ut = 2 * rev8(tt) + 1;
+            double base[NC][3];
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) base[c][i] = ldt(mono, (am[c][i] * ut) & (2 * N - 1));
+            // unit u = 4 p + w: position 8 t + p, word pair w, the four polynomials q; the next unit's four
+            // 16-byte loads are in flight while this one is multiplied into the ciphertexts
+            double kc[4][2], kn[4][2];
+#pragma unroll
+            for (unsigned q = 0; q < 4; ++q) { const unsigned o = bsk3_off(0, 0, q, tt); kc[q][0] = LFHE_LDK(rows, o); kc[q][1] = LFHE_LDK(rows, o + 1); }
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) ld_o4p34(buf(c, q), tt, x[c][q]);
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) ct_radix4x2_bounded(x[c][q], w4f, P);   // |d| < 3.4 p
+            const double* __restrict__ w8 = mono + MONO_WORDS;
+            auto chunk = [&](auto c4_tag) {
+                constexpr int c4 = decltype(c4_tag)::value;
+                double M[NC][3][2];
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) mono_pair<c4>(base[c][i], w8, am[c][i], P, M[c][i][0], M[c][i][1]);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int p = 2 * c4 + h;
+                    double B[NC][4], Tm[NC][4];
+#pragma unroll
+                    for (int wd = 0; wd < 4; ++wd) {
+                        const int u = 4 * p + wd;
+                        if (u < 31) {
+                            const unsigned pn = (unsigned)(u + 1) / 4, wn = (unsigned)(u + 1) % 4;
+#pragma unroll
+                            for (unsigned q = 0; q < 4; ++q) {
+                                const unsigned o = bsk3_off(pn, wn, q, tt);
+                                kn[q][0] = LFHE_LDK(rows, o); kn[q][1] = LFHE_LDK(rows, o + 1);
+                            }
+                        }
+#pragma unroll
+                        for (int c = 0; c < NC; ++c)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const double m1 = M[c][0][h], m2 = M[c][1][h], m3 = M[c][2][h];
+                                if (wd == 0) Tm[c][q] = mmul(m1 + kc[q][0], m2 + kc[q][1], P);              // (m1 + a1)(m2 + b1)
+                                else if (wd == 1) Tm[c][q] = mmul(mmul(Tm[c][q], kc[q][0], P) + kc[q][1], m3, P);   // m3 A1
+                                else if (wd == 2) B[c][q] = mmul(m1 + kc[q][0], m2 + kc[q][1], P);          // (m1 + a0)(m2 + b0)
+                                else B[c][q] = (mmul(B[c][q], kc[q][0], P) + kc[q][1]) + Tm[c][q];          // A0 + m3 A1, |B| < 1.8 p
+                            }
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { kc[q][0] = kn[q][0]; kc[q][1] = kn[q][1]; }
+                    }
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        const double d0 = x[c][0][p], d1 = x[c][1][p];
+                        x[c][0][p] = mmul(B[c][0], d0, P) + mmul(B[c][2], d1, P);
+                        x[c][1][p] = mmul(B[c][1], d0, P) + mmul(B[c][3], d1, P);
+                    }
+                }
+            };
+            chunk(std::integral_constant<int, 0>{});
+            chunk(std::integral_constant<int, 1>{});
+            chunk(std::integral_constant<int, 2>{});
+            chunk(std::integral_constant<int, 3>{});
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) gs_radix4x2<GS_NORM_PASS4[0], GS_NORM_PASS4[1]>(x[c][q], w4i, P);
+        }
+        phase_sync<g2_sync_after<LOCKSTEP>(5)>();   // the next phase rewrites the words this thread has just read
+        // ---- inverse transform
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) st_o4p34(buf(c, q), tt, x[c][q]);
+        phase_sync<g2_sync_after<LOCKSTEP>(6)>();
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) ld_o3p34(buf(c, q), tt, x[c][q]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) gs_radix8<GS_NORM_PASS3[0], GS_NORM_PASS3[1], GS_NORM_PASS3[2]>(x[c][q], w3i, P);
+        phase_sync<g2_sync_after<LOCKSTEP>(7)>();
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) st_o3p23(buf(c, q), tt, x[c][q]);
+        load_tw8(twi_small, base2(tt), w);
+        phase_sync<g2_sync_after<LOCKSTEP>(8)>();
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) ld_o2p23(buf(c, q), tt, x[c][q]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) gs_radix8<GS_NORM_PASS2_GROUPED[0], GS_NORM_PASS2_GROUPED[1], GS_NORM_PASS2_GROUPED[2]>(x[c][q], w, P);
+        phase_sync<g2_sync_after<LOCKSTEP>(9)>();
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) st_o2p12(buf(c, q), tt, x[c][q]);
+        load_tw8(twi_small, 1, w);
+        __syncthreads();
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) ld_o1p12(buf(c, q), tt, x[c][q]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                gs_radix8<GS_NORM_PASS1[0], GS_NORM_PASS1[1], GS_NORM_PASS1[2]>(x[c][q], w, P);
+#pragma unroll
+                for (int j = 0; j < E; ++j) x[c][q][j] = qp_canon(x[c][q][j], P);
+            }
+        __syncthreads();  // the last pass's reads are done before the next step overwrites the buffers
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (c > 0 && (size_t)blockIdx.x * NC + c >= count) break;   // odd batch: the duplicate is not stored
+        if (glwe_out) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    const double v = x[c][q][j];
+                    glwe_out[(ct[c] * 2 + q) * N + own1(t, j)] = v < 0 ? QP_U - (u64)(-v) : (u64)v;
+                }
+        }
+        if (lwe_out) {  // sample extraction of coefficient 0, every word switched back to 2^64
+            u64* o = lwe_out + omap.block(ct[c]) * (size_t)(N + 1);
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const unsigned e = own1(t, j);
+                if (e == 0) { o[0] = qp_to_torus(x[c][0][j]); o[N] = qp_to_torus(x[c][1][j]); }
+                else o[N - e] = qp_to_torus(-x[c][0][j]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // The grouped key over 2^64.  Four GGSWs per pair of key bits as above, but encryptions over the
 // torus 2^64 itself: ciphertexts, accumulator and key stay in the published ring, the step
 //     acc <- (G0 + X^a G1 + X^a' G2 + X^(a+a') G3) [.] acc
@@ -1639,6 +1962,7 @@ void blind_rotate_setup(int dev) {
     need(ask_lds(k_blind_rotate_q2_pair<false, false>, G2P_LDS_BYTES), "k_blind_rotate_q2_pair", G2P_LDS_BYTES);
     need(ask_lds(k_blind_rotate_q2_pair<true, true>, G2P_LDS_BYTES), "k_blind_rotate_q2_pair", G2P_LDS_BYTES);
     need(ask_lds(k_blind_rotate_q2_pair<false, true>, G2P_LDS_BYTES), "k_blind_rotate_q2_pair", G2P_LDS_BYTES);
+    need(ask_lds(k_blind_rotate_q3<2>, G2P_LDS_BYTES), "k_blind_rotate_q3", G2P_LDS_BYTES);
     need(ask_lds(k_blind_rotate_g64_pair<false, 2>, g64_lds_bytes(2)), "k_blind_rotate_g64_pair", g64_lds_bytes(2));
     need(ask_lds(k_blind_rotate_g64_pair<true, 2>, g64_lds_bytes(2)), "k_blind_rotate_g64_pair", g64_lds_bytes(2));
     need(ask_lds(k_blind_rotate_g64_pair<true, 1, true>, g64_lds_bytes(1)), "k_blind_rotate_g64_pair (slow path)", g64_lds_bytes(1));
@@ -1688,6 +2012,15 @@ void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_sm
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) throw std::runtime_error("hipGetDevice failed");
         blind_rotate_setup(dev);   // a no-op after the engine's own call at start-up
+    }
+    if (grouping == 4) {   // three key bits per step: two ciphertexts per workgroup, one when that would leave CUs idle
+        if (pair_above >= 0 && count > (size_t)pair_above)
+            hipLaunchKernelGGL(k_blind_rotate_q3<2>, dim3((unsigned)((count + 1) / 2)), dim3(NT), G2P_LDS_BYTES, st, T, bsk,
+                               lwe_small, n, luts, lut_index, glwe_out, lwe_out, omap, inv_g, (unsigned)count);
+        else
+            hipLaunchKernelGGL(k_blind_rotate_q3<1>, dim3((unsigned)count), dim3(NT), G2_LDS_BYTES, st, T, bsk, lwe_small, n,
+                               luts, lut_index, glwe_out, lwe_out, omap, inv_g, (unsigned)count);
+        return;
     }
     if (grouping == 3) {
         launch_grouped<true>(T, bsk, lwe_small, n, luts, lut_index, glwe_out, lwe_out, count, omap, inv_g, wide_below,

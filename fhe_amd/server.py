@@ -67,9 +67,10 @@ class Coalescer:
     The reference's clients fan requests out (tests/fhevm-suite/e2e/test/instance.ts:32-36 uses
     Promise.all), and a bootstrap layer of ONE operation is a few dozen ciphertexts on a GPU that holds
     a thousand: requests that wait behind the same lock anyway are cheaper served together.  One
-    worker thread owns the engine's evaluate path: it takes everything that is queued -- after a
-    window of `window` seconds from the first arrival, so that requests sent together are seen
-    together; while a batch runs, later arrivals queue up by themselves -- groups it, and issues one
+    worker thread owns the engine's evaluate path: it takes everything that is queued -- once a
+    window of `window` seconds has passed without a new arrival (at most eight windows), so that
+    requests sent together are seen together; while a batch runs, later arrivals queue up by
+    themselves -- groups it, and issues one
     `evaluate_batch` per group.  A batch that fails is retried one request at a time, so a bad
     ciphertext fails its own request only.  Backends without `evaluate_batch` are served one by one."""
 
@@ -113,8 +114,16 @@ class Coalescer:
                     self.cv.wait()
                 if self.closed and not self.queue:
                     return
+            # requests sent together arrive together: wait until a window passes without a new arrival
+            # (a burst of large bodies takes the interpreter a few milliseconds to read), at most eight windows
             if self.window > 0:
-                time.sleep(self.window)        # requests sent together arrive together
+                for _ in range(8):
+                    with self.cv:
+                        before = len(self.queue)
+                    time.sleep(self.window)
+                    with self.cv:
+                        if len(self.queue) == before:
+                            break
             with self.cv:
                 taken, self.queue = self.queue[:], []
             groups: dict = {}

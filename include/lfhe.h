@@ -55,6 +55,10 @@ extern "C" {
  * that window and a ciphertext that reaches it is redone on a path that is exact without condition
  * (lfhe_lift_fallback_count).  Set 1 is exact without condition. */
 #define LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_GROUPED 4u
+/* the prime-modulus set with the LWE key bits taken THREE at a time: eight GGSWs per triple of bits
+ * (one per product of s_i or 1 - s_i over the triple), 306 blind-rotation steps instead of 459, a
+ * server key of 2448 GGSWs (157 MB on the device).  Everything a client sees is that of the named set. */
+#define LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK_GROUPED3 5u
 
 typedef struct lfhe_ctx lfhe_ctx;
 
@@ -83,8 +87,8 @@ typedef struct {
      * CRT lift), LFHE_BSK_MODULUS_PRIME = that prime (one transform, no lift; the construction of
      * tfhe-rs programmable_bootstrap_ntt64_lwe_ciphertext) */
     uint64_t bsk_modulus;
-    /* LWE key bits per blind-rotation step: 1, or 2 (with LFHE_BSK_MODULUS_PRIME only; the
-     * bootstrapping key then has 4 * ceil(lwe_dim / 2) GGSWs) */
+    /* LWE key bits per blind-rotation step: 1, 2 (the bootstrapping key then has 4 * ceil(lwe_dim / 2)
+     * GGSWs) or 3 (with LFHE_BSK_MODULUS_PRIME only; 8 * ceil(lwe_dim / 3) GGSWs) */
     uint32_t bsk_grouping;
     uint32_t reserved;        /* 0 */
 } lfhe_params;

@@ -134,6 +134,9 @@ def lib():
         "orc_bsk_qp_grouped_count": (sz, [C.POINTER(_Params)]),
         "orc_gen_bsk_qp_grouped": (None, [vp, _u64p, _u64p, C.POINTER(_Rng), _u64p]),
         "orc_bsk_qp_grouped_prepare": (vp, [vp, _u64p]),
+        "orc_bsk_qp_grouped_count_n": (sz, [C.POINTER(_Params), u32]),
+        "orc_gen_bsk_qp_grouped_n": (None, [vp, _u64p, _u64p, C.POINTER(_Rng), u32, _u64p]),
+        "orc_bsk_qp_grouped_prepare_n": (vp, [vp, _u64p, u32]),
         "orc_bsk_grouped_count": (sz, [C.POINTER(_Params)]),
         "orc_gen_bsk_grouped": (None, [vp, _u64p, _u64p, C.POINTER(_Rng), _u64p]),
         "orc_bsk_grouped_prepare": (vp, [vp, _u64p]),
@@ -397,15 +400,15 @@ class Oracle:
         lib().orc_gen_bsk_qp(self._ctx, lwe_sk, glwe_sk, Rng(seed, 6).ref, bsk)
         return bsk
 
-    def gen_bsk_qp_grouped(self, lwe_sk: np.ndarray, glwe_sk: np.ndarray, seed: bytes) -> np.ndarray:
-        """Grouped key over q': four GGSWs per pair of key bits (tfhe_oracle.h)."""
-        count = lib().orc_bsk_qp_grouped_count(C.byref(self._cp))
+    def gen_bsk_qp_grouped(self, lwe_sk: np.ndarray, glwe_sk: np.ndarray, seed: bytes, bits: int = 2) -> np.ndarray:
+        """Grouped key over q': 2^bits GGSWs per group of `bits` (2 or 3) key bits (tfhe_oracle.h)."""
+        count = lib().orc_bsk_qp_grouped_count_n(C.byref(self._cp), bits)
         bsk = np.zeros(count * self.ggsw_words(), dtype=np.uint64)
-        lib().orc_gen_bsk_qp_grouped(self._ctx, lwe_sk, glwe_sk, Rng(seed, 7).ref, bsk)
+        lib().orc_gen_bsk_qp_grouped_n(self._ctx, lwe_sk, glwe_sk, Rng(seed, 7 if bits == 2 else 9).ref, bits, bsk)
         return bsk
 
-    def prepare_bsk_qp_grouped(self, bsk: np.ndarray):
-        return _PreparedBsk(self, bsk, prime=True, grouped=True)
+    def prepare_bsk_qp_grouped(self, bsk: np.ndarray, bits: int = 2):
+        return _PreparedBsk(self, bsk, prime=True, grouped=True, bits=bits)
 
     def external_product_qp(self, ggsw: np.ndarray, glwe: np.ndarray) -> np.ndarray:
         out = np.zeros((self.k + 1) * self.N, dtype=np.uint64)
@@ -447,14 +450,15 @@ class Oracle:
 
 class _PreparedBsk:
     def __init__(self, orc: Oracle, bsk: np.ndarray, prime: bool = False, grouped: bool = False,
-                 grouped64: bool = False):
+                 grouped64: bool = False, bits: int = 2):
         self._orc = orc
         prep = lib().orc_bsk_qp_prepare if prime else lib().orc_bsk_prepare
-        if grouped:
-            prep = lib().orc_bsk_qp_grouped_prepare
         if grouped64:
             prep = lib().orc_bsk_grouped_prepare
-        self.h = prep(orc._ctx, np.ascontiguousarray(bsk, dtype=np.uint64))
+        if grouped:
+            self.h = lib().orc_bsk_qp_grouped_prepare_n(orc._ctx, np.ascontiguousarray(bsk, dtype=np.uint64), bits)
+        else:
+            self.h = prep(orc._ctx, np.ascontiguousarray(bsk, dtype=np.uint64))
 
     def __del__(self):
         try:

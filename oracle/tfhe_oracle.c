@@ -927,22 +927,36 @@ void orc_gen_bsk_qp(const orc_ctx* c, const uint64_t* lwe_sk, const uint64_t* gl
     free(tmp);
 }
 
-/* Grouped key: the LWE key bits are taken in pairs (s, s') = (s_2g, s_2g+1) (s' = 0 past the end of
- * an odd-length key); group g holds four GGSWs, of (1-s)(1-s'), s(1-s'), (1-s)s' and s s'. */
-size_t orc_bsk_qp_grouped_count(const orc_params* p) { return 4 * (((size_t)p->lwe_dim + 1) / 2); }
+/* Grouped key: the LWE key bits are taken `bits` at a time (2 or 3; bits past the end of the key count
+ * as 0); group g holds 2^bits GGSWs, GGSW m encrypting the product over the group's bits i of
+ * s_i (bit i of m set) or 1 - s_i (clear): exactly one of them encrypts 1.  For pairs that is
+ * (1-s)(1-s'), s(1-s'), (1-s)s', s s'. */
+size_t orc_bsk_qp_grouped_count_n(const orc_params* p, uint32_t bits) {
+    return ((size_t)1 << bits) * (((size_t)p->lwe_dim + bits - 1) / bits);
+}
+size_t orc_bsk_qp_grouped_count(const orc_params* p) { return orc_bsk_qp_grouped_count_n(p, 2); }
+
+void orc_gen_bsk_qp_grouped_n(const orc_ctx* c, const uint64_t* lwe_sk, const uint64_t* glwe_sk, orc_rng* r,
+                              uint32_t bits, uint64_t* bsk) {
+    const orc_params* P = &c->prm;
+    const size_t per = (size_t)(P->glwe_dim + 1) * (P->glwe_dim + 1) * P->poly_size;
+    const u32 groups = (P->lwe_dim + bits - 1) / bits, terms = 1u << bits;
+    u64* tmp = (u64*)malloc(sizeof(u64) * P->poly_size);
+    for (u32 g = 0; g < groups; ++g)
+        for (u32 m = 0; m < terms; ++m) {
+            u64 msg = 1;
+            for (u32 i = 0; i < bits; ++i) {
+                const u64 s = bits * g + i < P->lwe_dim ? lwe_sk[bits * g + i] : 0;
+                msg &= (m >> i & 1) ? s : 1 - s;
+            }
+            gen_ggsw_qp(c, msg, glwe_sk, r, bsk + ((size_t)terms * g + m) * per, tmp);
+        }
+    free(tmp);
+}
 
 void orc_gen_bsk_qp_grouped(const orc_ctx* c, const uint64_t* lwe_sk, const uint64_t* glwe_sk, orc_rng* r,
                             uint64_t* bsk) {
-    const orc_params* P = &c->prm;
-    const size_t per = (size_t)(P->glwe_dim + 1) * (P->glwe_dim + 1) * P->poly_size;
-    const u32 groups = (P->lwe_dim + 1) / 2;
-    u64* tmp = (u64*)malloc(sizeof(u64) * P->poly_size);
-    for (u32 g = 0; g < groups; ++g) {
-        const u64 s0 = lwe_sk[2 * g], s1 = 2 * g + 1 < P->lwe_dim ? lwe_sk[2 * g + 1] : 0;
-        const u64 msg[4] = {(1 - s0) & (1 - s1), s0 & (1 - s1), (1 - s0) & s1, s0 & s1};
-        for (u32 m = 0; m < 4; ++m) gen_ggsw_qp(c, msg[m], glwe_sk, r, bsk + ((size_t)4 * g + m) * per, tmp);
-    }
-    free(tmp);
+    orc_gen_bsk_qp_grouped_n(c, lwe_sk, glwe_sk, r, 2, bsk);
 }
 
 /* NTT-domain image of one GGSW over q': hat[row][poly][N], Montgomery form */
@@ -1007,6 +1021,10 @@ orc_prepared_bsk* orc_bsk_qp_grouped_prepare(const orc_ctx* c, const uint64_t* b
     return bsk_qp_prepare_n(c, bsk, orc_bsk_qp_grouped_count(&c->prm), 2);
 }
 
+orc_prepared_bsk* orc_bsk_qp_grouped_prepare_n(const orc_ctx* c, const uint64_t* bsk, uint32_t bits) {
+    return bsk_qp_prepare_n(c, bsk, orc_bsk_qp_grouped_count_n(&c->prm, bits), bits);
+}
+
 /* X^rot * in over Z_q' */
 static void qp_monomial_mul(u64* out, const u64* in, u32 rot, u32 N) {
     for (u32 j = 0; j < N; ++j) {
@@ -1022,19 +1040,22 @@ static void qp_monomial_mul(u64* out, const u64* in, u32 rot, u32 N) {
  * transform domain, where a monomial is a point-wise factor, so a step costs one external product.
  * The accumulator is replaced, not added to: what the gadget decomposition rounds away
  * (|.| <= G/2 per coefficient and step) stays in the error instead of being carried. */
-/* one step: acc <- B [.] acc for the four NTT-domain GGSWs at hat4 and the exponents a0, a1 */
-static void group_step_hat(const orc_ctx* c, const u64* hat4, size_t per, u32 a0, u32 a1, u64* acc) {
+/* one step: acc <- B [.] acc for the 2^bits NTT-domain GGSWs at hat and the exponents a[0 .. bits-1]: term m
+ * carries X^(sum of the a_i whose bit is set in m) */
+static void group_step_hat_n(const orc_ctx* c, const u64* hat, size_t per, u32 bits, const u32* ai, u64* acc) {
     const orc_params* P = &c->prm;
-    const u32 N = P->poly_size, k1 = P->glwe_dim + 1;
+    const u32 N = P->poly_size, k1 = P->glwe_dim + 1, terms = 1u << bits;
     const mont_t* M = &c->qp.m;
-    const u32 a[4] = {0, a0, a1, (a0 + a1) % (2 * N)};
-    u64* tmp = (u64*)malloc(sizeof(u64) * ((size_t)k1 * N * 2 + 4 * (size_t)N));
+    u64* tmp = (u64*)malloc(sizeof(u64) * ((size_t)k1 * N * 2 + (size_t)terms * N));
     u64 *dig = tmp, *out = tmp + (size_t)k1 * N, *mono = tmp + (size_t)2 * k1 * N;
     /* transform of X^a, Montgomery form */
-    for (u32 m = 0; m < 4; ++m) {
+    for (u32 m = 0; m < terms; ++m) {
+        u32 a = 0;
+        for (u32 i = 0; i < bits; ++i)
+            if (m >> i & 1) a = (a + ai[i]) % (2 * N);
         u64* mm = mono + (size_t)m * N;
         memset(mm, 0, sizeof(u64) * N);
-        if (a[m] < N) mm[a[m]] = 1; else mm[a[m] - N] = ORC_QP - 1;
+        if (a < N) mm[a] = 1; else mm[a - N] = ORC_QP - 1;
         ntt_fwd(&c->qp, mm, N);
         for (u32 j = 0; j < N; ++j) mm[j] = to_mont(M, mm[j]);
     }
@@ -1052,9 +1073,9 @@ static void group_step_hat(const orc_ctx* c, const u64* hat4, size_t per, u32 a0
             u64 sum = 0;
             for (u32 rr = 0; rr < k1; ++rr) {
                 u64 b = 0;
-                for (u32 m = 0; m < 4; ++m) {
+                for (u32 m = 0; m < terms; ++m) {
                     /* both factors are Montgomery forms: two reductions give the plain product */
-                    const u64 h = hat4[(size_t)m * per + ((size_t)rr * k1 + cc) * N + j];
+                    const u64 h = hat[(size_t)m * per + ((size_t)rr * k1 + cc) * N + j];
                     b = qp_add(b, mont_mul(M, mont_mul(M, mono[(size_t)m * N + j], h), 1));
                 }
                 sum = qp_add(sum, mont_mul(M, dig[(size_t)rr * N + j], to_mont(M, b)));
@@ -1065,6 +1086,11 @@ static void group_step_hat(const orc_ctx* c, const u64* hat4, size_t per, u32 a0
     }
     memcpy(acc, out, sizeof(u64) * (size_t)k1 * N);
     free(tmp);
+}
+
+static void group_step_hat(const orc_ctx* c, const u64* hat4, size_t per, u32 a0, u32 a1, u64* acc) {
+    const u32 a[2] = {a0, a1};
+    group_step_hat_n(c, hat4, per, 2, a, acc);
 }
 
 void orc_group_step_qp(const orc_ctx* c, const uint64_t* ggsw4, uint32_t a0, uint32_t a1, uint64_t* acc) {
@@ -1080,7 +1106,7 @@ static void blind_rotate_qp_grouped(const orc_ctx* c, const orc_prepared_bsk* pb
                                     const u64* lut, u64* acc) {
     const orc_params* P = &c->prm;
     const u32 N = P->poly_size, k1 = P->glwe_dim + 1, n = P->lwe_dim;
-    const u32 log2n = c->logN + 1, groups = (n + 1) / 2;
+    const u32 bits = pb->grouping, log2n = c->logN + 1, groups = (n + bits - 1) / bits;
     u64* tmp = (u64*)malloc(sizeof(u64) * (size_t)k1 * N);
     for (size_t j = 0; j < (size_t)k1 * N; ++j) tmp[j] = orc_to_qp(lut[j]);
     const u32 bt = orc_modswitch(lwe_small[n], log2n);
@@ -1088,17 +1114,18 @@ static void blind_rotate_qp_grouped(const orc_ctx* c, const orc_prepared_bsk* pb
         qp_monomial_mul(acc + (size_t)q * N, tmp + (size_t)q * N, (2 * N - bt) % (2 * N), N);
     free(tmp);
     for (u32 g = 0; g < groups; ++g) {
-        const u32 a0 = orc_modswitch(lwe_small[2 * g], log2n);
-        const u32 a1 = 2 * g + 1 < n ? orc_modswitch(lwe_small[2 * g + 1], log2n) : 0;
-        /* every step runs, also the one whose exponents are both zero (B then encrypts 1): the
-         * sequence of operations does not depend on the ciphertext */
-        group_step_hat(c, pb->hat + (size_t)4 * g * pb->per_ggsw, pb->per_ggsw, a0, a1, acc);
+        /* every step runs, also one whose exponents are all zero (B then encrypts 1): the sequence of
+         * operations does not depend on the ciphertext */
+        u32 a[3] = {0, 0, 0};
+        for (u32 i = 0; i < bits; ++i)
+            if (bits * g + i < n) a[i] = orc_modswitch(lwe_small[bits * g + i], log2n);
+        group_step_hat_n(c, pb->hat + ((size_t)g << bits) * pb->per_ggsw, pb->per_ggsw, bits, a, acc);
     }
 }
 
 void orc_blind_rotate_qp(const orc_ctx* c, const orc_prepared_bsk* pb, const uint64_t* lwe_small,
                          const uint64_t* lut, uint64_t* acc) {
-    if (pb->grouping == 2) { blind_rotate_qp_grouped(c, pb, lwe_small, lut, acc); return; }
+    if (pb->grouping >= 2) { blind_rotate_qp_grouped(c, pb, lwe_small, lut, acc); return; }
     const orc_params* P = &c->prm;
     const u32 N = P->poly_size, k1 = P->glwe_dim + 1, n = P->lwe_dim;
     const u32 log2n = c->logN + 1;

@@ -217,6 +217,13 @@ size_t orc_bsk_qp_grouped_count(const orc_params* p);   /* GGSWs in the grouped 
 void orc_gen_bsk_qp_grouped(const orc_ctx* c, const uint64_t* lwe_sk, const uint64_t* glwe_sk, orc_rng* r,
                             uint64_t* bsk);
 orc_prepared_bsk* orc_bsk_qp_grouped_prepare(const orc_ctx* c, const uint64_t* bsk);
+/* the same with `bits` (2 or 3) key bits per blind-rotation step: 2^bits GGSWs per group, GGSW m of the
+ * product over the group's bits of s_i (bit i of m set) or 1 - s_i; a step multiplies the accumulator
+ * by the sum over m of X^(sum of the a_i with bit i of m set) GGSW_m */
+size_t orc_bsk_qp_grouped_count_n(const orc_params* p, uint32_t bits);
+void orc_gen_bsk_qp_grouped_n(const orc_ctx* c, const uint64_t* lwe_sk, const uint64_t* glwe_sk, orc_rng* r,
+                              uint32_t bits, uint64_t* bsk);
+orc_prepared_bsk* orc_bsk_qp_grouped_prepare_n(const orc_ctx* c, const uint64_t* bsk, uint32_t bits);
 /* one step on its own: ggsw4 = four GGSWs over q' in the coefficient domain, acc (k+1 polys of
  * residues) is replaced by B [.] acc for the exponents a0, a1 in [0, 2N) */
 void orc_group_step_qp(const orc_ctx* c, const uint64_t* ggsw4, uint32_t a0, uint32_t a1, uint64_t* acc);

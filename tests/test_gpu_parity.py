@@ -244,7 +244,7 @@ def test_ms_noise_reduction_bit_exact(full):
 
 
 # ---- bootstrap over the prime ring modulus (bootstrapping key and accumulator in Z_q') ------------
-def _mk_prime(n, seed, ms_zeros=0, wide=True, grouped=False):
+def _mk_prime(n, seed, ms_zeros=0, wide=True, grouped=False, bits=2):
     """wide=False forces the 256-thread blind rotation for small launches too (by default launches
     of up to two ciphertexts per CU take the 512-thread kernel).  grouped: the key with four GGSWs
     per pair of key bits, blind rotation in (n + 1) / 2 steps."""
@@ -256,11 +256,11 @@ def _mk_prime(n, seed, ms_zeros=0, wide=True, grouped=False):
     op = OParams(lwe_dim=n)
     orc = Oracle(op)
     lwe_sk, glwe_sk, _, ksk = orc.gen_keys(seed_bytes(seed))
-    gen = orc.gen_bsk_qp_grouped if grouped else orc.gen_bsk_qp
-    bskq = gen(lwe_sk, glwe_sk, seed_bytes(seed))
+    bskq = (orc.gen_bsk_qp_grouped(lwe_sk, glwe_sk, seed_bytes(seed), bits) if grouped
+            else orc.gen_bsk_qp(lwe_sk, glwe_sk, seed_bytes(seed)))
     p = Params(**{k: getattr(op, k) for k in op.__dataclass_fields__})
     p.bsk_modulus = BSK_MODULUS_PRIME
-    p.bsk_grouping = 2 if grouped else 1
+    p.bsk_grouping = bits if grouped else 1
     zeros = None
     if ms_zeros:
         d = default_params()
@@ -372,6 +372,69 @@ def test_grouped_key_blind_rotation_bit_exact(n, wide):
         for m in range(16):
             assert np.array_equal(out[m], orc.pbs_qp(ksk, pb, cts[m], luts_o[li[m]])), m
             assert orc.decrypt_block(glwe_sk, out[m]) == f[li[m]](m) % 16
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("n", [12, 13, 14])
+def test_three_key_bits_per_step_bit_exact(n):
+    """Eight GGSWs per triple of key bits, a third fewer steps: accumulators and bootstrapped
+    ciphertexts equal the oracle's bit for bit, for key lengths that leave a full, a one-bit and a
+    two-bit last group, one and two ciphertexts per workgroup (odd batch), all-zero masks and masks
+    whose exponents cancel."""
+    orc, keys, ctx = _mk_prime(n, seed=6, grouped=True, bits=3)
+    try:
+        lwe_sk, glwe_sk, bskg, ksk = keys
+        assert len(bskg) == 8 * ((n + 2) // 3) * orc.ggsw_words()
+        pb = orc.prepare_bsk_qp_grouped(bskg, 3)
+        r = Rng(seed_bytes(29))
+        f = [lambda x: x, lambda x: (3 * x + 1) % 16]
+        luts_o = [orc.make_lut(g) for g in f]
+        luts_g = np.stack([ctx.make_lut(g) for g in f])
+        smalls = np.stack([r.u64s(orc.n + 1) for _ in range(7)])
+        smalls[3][:] = 0
+        smalls[4][:n] = np.uint64(1 << 63)            # every exponent N: pairs of them cancel, triples give X^N
+        smalls[5][0:n:3] = 0                          # a = 0, a', a'' random
+        li = np.array([0, 1, 1, 0, 1, 0, 1], dtype=np.uint32)
+        got = ctx.blind_rotate(smalls, luts_g, li)    # seven: one ciphertext per workgroup (a small launch)
+        for c in range(7):
+            assert np.array_equal(got[c].reshape(-1), orc.blind_rotate_qp(pb, smalls[c], luts_o[li[c]])), c
+        cts = np.stack([orc.encrypt_block(glwe_sk, m, r) for m in range(16)] * 37)[:577]     # two per workgroup, odd
+        li = np.array([m % 2 for m in range(577)], dtype=np.uint32)
+        out = ctx.pbs_batch(cts, luts_g, li)
+        for m in (0, 1, 7, 15, 16, 300, 575, 576):
+            assert np.array_equal(out[m], orc.pbs_qp(ksk, pb, cts[m], luts_o[li[m]])), m
+        assert ctx.decrypt_blocks(out) == [f[li[i]](i % 16) % 16 for i in range(577)]
+        assert np.array_equal(ctx.pbs_batch(cts[:9], luts_g, li[:9]), out[:9])
+    finally:
+        ctx.close()
+
+
+def test_three_key_bits_per_step_full_parameters():
+    """n = 918 = 306 triples, noise reduction on: every output decrypts to f(m) with noise far below
+    half a message step, every one of the 600 bit-identical to the oracle."""
+    orc, keys, ctx = _mk_prime(918, seed=11, ms_zeros=1449, grouped=True, bits=3)
+    try:
+        lwe_sk, glwe_sk, bskg, ksk = keys
+        pb = orc.prepare_bsk_qp_grouped(bskg, 3)
+        r = Rng(seed_bytes(36))
+        f = [lambda x: x, lambda x: (x * x + 3) % 16]
+        luts_o = [orc.make_lut(g) for g in f]
+        luts_g = np.stack([ctx.make_lut(g) for g in f])
+        B = 600
+        msgs = [int(r.u64() % 16) for _ in range(B)]
+        cts = np.stack([orc.encrypt_block(glwe_sk, m, r) for m in msgs])
+        idx = np.array([i % 2 for i in range(B)], dtype=np.uint32)
+        out = ctx.pbs_batch(cts, luts_g, idx)
+        worst = 0
+        for i in range(B):
+            want = f[idx[i]](msgs[i]) % 16
+            assert orc.decrypt_block(glwe_sk, out[i]) == want, i
+            e = (orc.lwe_phase(glwe_sk, out[i]) - orc.encode(want)) % (1 << 64)
+            worst = max(worst, min(e, (1 << 64) - e))
+        assert worst < 1 << 53
+        assert np.array_equal(out, orc.pbs_batch_qp(ksk, pb, cts, np.stack(luts_o), idx, nthreads=16))
+        assert np.array_equal(ctx.pbs_batch(cts[:8], luts_g, idx[:8]), out[:8])
     finally:
         ctx.close()
 
