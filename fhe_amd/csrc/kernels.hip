@@ -1890,6 +1890,163 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q2_wide(Tables T, co
     }
 }
 
+// Three key bits per step for launches too small to fill the GPU: 512 threads per ciphertext, one half
+// per polynomial, as k_blind_rotate_q2_wide.  A step's key words for one thread are 128 doubles, twice
+// what the registers can hold a step ahead: four positions' worth (64 doubles) are kept.  Positions
+// 0..3 of step g + 1 are requested as the point-wise stage of step g releases the registers (a whole
+// transform of cover), positions 4..7 of a step as its own positions 0..3 are consumed (three
+// positions of arithmetic of cover).  The loads are pinned behind the last use of the words they
+// replace by making their addresses depend on the point-wise result.
+__global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_q3_wide(Tables T, const double* __restrict__ bsk,
+                                                                    const u64* __restrict__ lwe_small, int n,
+                                                                    const u64* __restrict__ luts,
+                                                                    const u32* __restrict__ lut_index,
+                                                                    u64* __restrict__ glwe_out,
+                                                                    u64* __restrict__ lwe_out, BlockMap omap,
+                                                                    double inv_g) {
+    const unsigned h = threadIdx.x >> 8;   // polynomial of this half (wave-uniform)
+    const unsigned t0 = threadIdx.x & (NT - 1);
+    const size_t ct = blockIdx.x;
+    const Prime P = T.pr[0];
+    const u64* __restrict__ lwe = lwe_small + ct * (size_t)(n + 1);
+    const u64* __restrict__ lut = luts + (size_t)(lut_index ? lut_index[omap.ops ? ct % omap.ops : ct] : 0) * N;
+    double* mine = lds_dyn + h * POLY_STRIDE;
+    double* theirs = lds_dyn + (1 - h) * POLY_STRIDE;
+    double* back = lds_dyn + WIDE2_BACK + h * POLY_STRIDE;
+    const double* __restrict__ twf = lds_dyn + WIDE_TWF;   // passes 2-4; pass 1's live in scalar registers
+    const double* __restrict__ twi = lds_dyn + WIDE_TWI;
+    const double* __restrict__ mono = lds_dyn + WIDE_MONO;
+    wide_fill_tables(T, true);
+
+    double acc[E], x[E], w[7], w1f[7], w1i[7];
+    load_tw8_uniform(T.tw_fwd[0], w1f);
+    load_tw8_uniform(T.tw_inv[0], w1i);
+    {
+        const unsigned bt = modswitch_2n(lwe[n]);
+        const unsigned a = (2 * N - bt) & (2 * N - 1);  // multiply by X^-b~
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            bool neg;
+            const double v = torus_to_qp(lut[rot_index(own1(t0, j), a, neg)]);
+            acc[j] = h ? (neg ? -v : v) : 0.0;
+        }
+    }
+    __syncthreads();
+
+    const int groups = (n + 2) / 3;
+    // key words in flight or in use: slot s holds position s or s + 4; [w][entry: 0 own digits, 1 the other half's][2]
+    double kw[4][4][2][2];
+    auto load_pos = [&](int g, int p, int slot, unsigned t) {
+        const double* __restrict__ rows = bsk + (size_t)g * BSK3_GROUP;
+#pragma unroll
+        for (unsigned wd = 0; wd < 4; ++wd) {
+            const unsigned ox = bsk3_off((unsigned)p, wd, 3 * h, t), oy = bsk3_off((unsigned)p, wd, 2 - h, t);
+#pragma unroll
+            for (unsigned k = 0; k < 2; ++k) { kw[slot][wd][0][k] = ldt(rows, ox + k); kw[slot][wd][1][k] = ldt(rows, oy + k); }
+        }
+    };
+    auto exponent = [&](int g, int i) { return 3 * g + i < n ? modswitch_2n(lwe[3 * g + i]) : 0u; };
+    int g = 0;
+    unsigned a0 = exponent(0, 0), a1 = exponent(0, 1), a2 = exponent(0, 2);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) load_pos(0, p, p, t0);
+
+    while (g < groups) {
+        // exponents of the following step: requested now, looked at after the point-wise stage
+        unsigned na0 = exponent(g + 1, 0), na1 = exponent(g + 1, 1), na2 = exponent(g + 1, 2);
+        unsigned t = t0;
+        asm volatile("" : "+v"(t));  // addresses are recomputed per step instead of living in registers
+#pragma unroll
+        for (int j = 0; j < E; ++j) x[j] = __builtin_rint(acc[j] * inv_g);
+        ct_radix8(x, w1f, P);
+        st_o1p12(mine, t, x); load_tw8(twf, base2(t), w);
+        __syncthreads();
+        ld_o2p12(mine, t, x); ct_radix8(x, w, P);
+        wave_sync();
+        st_o2p23(mine, t, x); load_tw8(twf, base3(t), w);
+        wave_sync();
+        ld_o3p23(mine, t, x); ct_radix8(x, w, P);
+        wave_sync();
+        st_o3p34(mine, t, x); load_tw4x2(twf, t, w);
+        wave_sync();
+        ld_o4p34(mine, t, x); ct_radix4x2_bounded(x, w, P);   // |d| < 3.4 p for the wide operand of the point-wise stage
+        st_o4p34(mine, t, x); load_tw4x2(twi, t, w);
+        __syncthreads();
+        {
+            double y[E];
+            ld_o4p34(theirs, t, y);
+            const unsigned ut = 2 * rev8(t) + 1;
+            const unsigned am[3] = {a0, a1, a2};
+            const double* __restrict__ w8 = mono + MONO_WORDS;
+            double base[3];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) base[m] = ldt(mono, (am[m] * ut) & (2 * N - 1));
+            const int gnext = g + 1;
+            auto chunk = [&](auto c4_tag) {
+                constexpr int c4 = decltype(c4_tag)::value;
+                double M[3][2];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) mono_pair<c4>(base[i], w8, am[i], P, M[i][0], M[i][1]);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int p = 2 * c4 + k, slot = p & 3;
+                    double b[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        // B = A0 + m3 A1 from the pairs (a1, b1), (d1, c1), (a0, b0), (d0, c0); |B| < 1.8 p
+                        double tm = mmul(M[0][k] + kw[slot][0][e][0], M[1][k] + kw[slot][0][e][1], P);
+                        tm = mmul(mmul(tm, kw[slot][1][e][0], P) + kw[slot][1][e][1], M[2][k], P);
+                        const double a = mmul(M[0][k] + kw[slot][2][e][0], M[1][k] + kw[slot][2][e][1], P);
+                        b[e] = (mmul(a, kw[slot][3][e][0], P) + kw[slot][3][e][1]) + tm;
+                    }
+                    x[p] = mmul(b[0], x[p], P) + mmul(b[1], y[p], P);
+                    // this slot's words are used up: request the ones that take their place
+                    unsigned tk = t;
+                    asm volatile("" : "+v"(tk) : "v"(x[p]));
+                    if (p < 4) load_pos(g, p + 4, slot, tk);
+                    else if (gnext < groups) load_pos(gnext, p - 4, slot, tk);
+                }
+            };
+            chunk(std::integral_constant<int, 0>{});
+            chunk(std::integral_constant<int, 1>{});
+            chunk(std::integral_constant<int, 2>{});
+            chunk(std::integral_constant<int, 3>{});
+        }
+        gs_radix4x2<GS_NORM_PASS4[0], GS_NORM_PASS4[1]>(x, w, P);
+        st_o4p34(back, t, x); load_tw8(twi, base3(t), w);
+        wave_sync();
+        ld_o3p34(back, t, x); gs_radix8<GS_NORM_PASS3[0], GS_NORM_PASS3[1], GS_NORM_PASS3[2]>(x, w, P);
+        wave_sync();
+        st_o3p23(back, t, x); load_tw8(twi, base2(t), w);
+        wave_sync();
+        ld_o2p23(back, t, x); gs_radix8<GS_NORM_PASS2_GROUPED[0], GS_NORM_PASS2_GROUPED[1], GS_NORM_PASS2_GROUPED[2]>(x, w, P);
+        wave_sync();
+        st_o2p12(back, t, x);
+        __syncthreads();
+        ld_o1p12(back, t, x); gs_radix8<GS_NORM_PASS1[0], GS_NORM_PASS1[1], GS_NORM_PASS1[2]>(x, w1i, P);
+#pragma unroll
+        for (int j = 0; j < E; ++j) acc[j] = qp_canon(x[j], P);
+        g = g + 1; a0 = na0; a1 = na1; a2 = na2;
+    }
+
+    if (glwe_out) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const double c = acc[j];
+            glwe_out[(ct * 2 + h) * N + own1(t0, j)] = c < 0 ? QP_U - (u64)(-c) : (u64)c;
+        }
+    }
+    if (lwe_out) {  // sample extraction of coefficient 0, every word switched back to 2^64
+        u64* o = lwe_out + omap.block(ct) * (size_t)(N + 1);
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const unsigned e = own1(t0, j);
+            if (h == 0) o[e == 0 ? 0 : N - e] = qp_to_torus(e == 0 ? acc[j] : -acc[j]);
+            else if (e == 0) o[N] = qp_to_torus(acc[j]);
+        }
+    }
+}
+
 void launch_bskq_prepare(const Tables& T, const u64* in, double* out, size_t polys, hipStream_t st) {
     hipLaunchKernelGGL(k_bskq_prepare, dim3((unsigned)polys), dim3(NT), LDS_BYTES, st, T, in, out);
 }
@@ -1963,6 +2120,7 @@ void blind_rotate_setup(int dev) {
     need(ask_lds(k_blind_rotate_q2_pair<true, true>, G2P_LDS_BYTES), "k_blind_rotate_q2_pair", G2P_LDS_BYTES);
     need(ask_lds(k_blind_rotate_q2_pair<false, true>, G2P_LDS_BYTES), "k_blind_rotate_q2_pair", G2P_LDS_BYTES);
     need(ask_lds(k_blind_rotate_q3<2>, G2P_LDS_BYTES), "k_blind_rotate_q3", G2P_LDS_BYTES);
+    need(ask_lds(k_blind_rotate_q3_wide, WIDE2_LDS_BYTES), "k_blind_rotate_q3_wide", WIDE2_LDS_BYTES);
     need(ask_lds(k_blind_rotate_g64_pair<false, 2>, g64_lds_bytes(2)), "k_blind_rotate_g64_pair", g64_lds_bytes(2));
     need(ask_lds(k_blind_rotate_g64_pair<true, 2>, g64_lds_bytes(2)), "k_blind_rotate_g64_pair", g64_lds_bytes(2));
     need(ask_lds(k_blind_rotate_g64_pair<true, 1, true>, g64_lds_bytes(1)), "k_blind_rotate_g64_pair (slow path)", g64_lds_bytes(1));
@@ -2013,8 +2171,12 @@ void launch_blind_rotate_q(const Tables& T, const double* bsk, const u64* lwe_sm
         if (hipGetDevice(&dev) != hipSuccess) throw std::runtime_error("hipGetDevice failed");
         blind_rotate_setup(dev);   // a no-op after the engine's own call at start-up
     }
-    if (grouping == 4) {   // three key bits per step: two ciphertexts per workgroup, one when that would leave CUs idle
-        if (pair_above >= 0 && count > (size_t)pair_above)
+    if (grouping == 4) {   // three key bits per step: 512 threads per ciphertext up to one per CU, else two ciphertexts per
+                           // workgroup, or one when that would leave CUs idle
+        if (count <= (size_t)wide_below)
+            hipLaunchKernelGGL(k_blind_rotate_q3_wide, dim3((unsigned)count), dim3(2 * NT), WIDE2_LDS_BYTES, st, T, bsk, lwe_small,
+                               n, luts, lut_index, glwe_out, lwe_out, omap, inv_g);
+        else if (pair_above >= 0 && count > (size_t)pair_above)
             hipLaunchKernelGGL(k_blind_rotate_q3<2>, dim3((unsigned)((count + 1) / 2)), dim3(NT), G2P_LDS_BYTES, st, T, bsk,
                                lwe_small, n, luts, lut_index, glwe_out, lwe_out, omap, inv_g, (unsigned)count);
         else

@@ -376,13 +376,14 @@ def test_grouped_key_blind_rotation_bit_exact(n, wide):
         ctx.close()
 
 
+@pytest.mark.parametrize("wide", [True, False], ids=["512-thread", "256-thread"])
 @pytest.mark.parametrize("n", [12, 13, 14])
-def test_three_key_bits_per_step_bit_exact(n):
+def test_three_key_bits_per_step_bit_exact(n, wide):
     """Eight GGSWs per triple of key bits, a third fewer steps: accumulators and bootstrapped
     ciphertexts equal the oracle's bit for bit, for key lengths that leave a full, a one-bit and a
-    two-bit last group, one and two ciphertexts per workgroup (odd batch), all-zero masks and masks
-    whose exponents cancel."""
-    orc, keys, ctx = _mk_prime(n, seed=6, grouped=True, bits=3)
+    two-bit last group, for the 512-thread kernel and for one and two ciphertexts per 256-thread
+    workgroup (odd batches), all-zero masks and masks whose exponents cancel."""
+    orc, keys, ctx = _mk_prime(n, seed=6, grouped=True, bits=3, wide=wide)
     try:
         lwe_sk, glwe_sk, bskg, ksk = keys
         assert len(bskg) == 8 * ((n + 2) // 3) * orc.ggsw_words()
@@ -396,16 +397,17 @@ def test_three_key_bits_per_step_bit_exact(n):
         smalls[4][:n] = np.uint64(1 << 63)            # every exponent N: pairs of them cancel, triples give X^N
         smalls[5][0:n:3] = 0                          # a = 0, a', a'' random
         li = np.array([0, 1, 1, 0, 1, 0, 1], dtype=np.uint32)
-        got = ctx.blind_rotate(smalls, luts_g, li)    # seven: one ciphertext per workgroup (a small launch)
+        got = ctx.blind_rotate(smalls, luts_g, li)    # seven: 512 threads each, or two per workgroup with an odd one left
         for c in range(7):
             assert np.array_equal(got[c].reshape(-1), orc.blind_rotate_qp(pb, smalls[c], luts_o[li[c]])), c
-        cts = np.stack([orc.encrypt_block(glwe_sk, m, r) for m in range(16)] * 37)[:577]     # two per workgroup, odd
+        cts = np.stack([orc.encrypt_block(glwe_sk, m, r) for m in range(16)] * 37)[:577]     # one per workgroup (2 .. 3.5 per CU)
         li = np.array([m % 2 for m in range(577)], dtype=np.uint32)
         out = ctx.pbs_batch(cts, luts_g, li)
         for m in (0, 1, 7, 15, 16, 300, 575, 576):
             assert np.array_equal(out[m], orc.pbs_qp(ksk, pb, cts[m], luts_o[li[m]])), m
         assert ctx.decrypt_blocks(out) == [f[li[i]](i % 16) % 16 for i in range(577)]
         assert np.array_equal(ctx.pbs_batch(cts[:9], luts_g, li[:9]), out[:9])
+        assert np.array_equal(ctx.pbs_batch(cts[:301], luts_g, li[:301]), out[:301])       # two per workgroup, odd
     finally:
         ctx.close()
 
