@@ -14,14 +14,14 @@ export type Operator =
   | 'div' | 'rem' | 'cast';
 
 /** Parameter set ids of include/lfhe.h: bootstrapping key over 2^64, over the NTT prime, over the prime with key bits in pairs. */
-export const PARAMS: { readonly Q64: 1; readonly PRIME_BSK: 2; readonly PRIME_BSK_GROUPED: 3; readonly Q64_GROUPED: 4 };
+export const PARAMS: { readonly Q64: 1; readonly PRIME_BSK: 2; readonly PRIME_BSK_GROUPED: 3; readonly Q64_GROUPED: 4; readonly PRIME_BSK_GROUPED3: 5 };
 export const KEY: { readonly CLIENT: 1; readonly SERVER: 2 };
 
 export interface NativeEngineOptions {
   /** 32 bytes the keys derive from (as secret as the keys); default: fresh randomness */
   seed?: Uint8Array;
   device?: number;
-  /** default PARAMS.PRIME_BSK_GROUPED, as the HTTP server */
+  /** default PARAMS.PRIME_BSK_GROUPED3, as the HTTP server */
   params?: number;
   /** path of liblfhe.so; default: $LFHE_LIB, then fhe_amd/liblfhe.so of this checkout */
   libPath?: string;

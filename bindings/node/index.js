@@ -13,7 +13,7 @@ const path = require('path');
 const crypto = require('crypto');
 const native = require('./lfhe_napi.node');
 
-const PARAMS = { Q64: 1, PRIME_BSK: 2, PRIME_BSK_GROUPED: 3, Q64_GROUPED: 4 };
+const PARAMS = { Q64: 1, PRIME_BSK: 2, PRIME_BSK_GROUPED: 3, Q64_GROUPED: 4, PRIME_BSK_GROUPED3: 5 };
 const KEY = { CLIENT: 1, SERVER: 2 };
 const COMPARISONS = new Set(['eq', 'ne', 'ge', 'gt', 'le', 'lt']);
 const WIDTHS = new Set([1, 8, 16, 32, 64, 128, 160, 256]);
@@ -74,7 +74,7 @@ class NativeEngine {
   /**
    * @param {{seed?: Uint8Array, device?: number, params?: number, libPath?: string, keygen?: boolean}} opts
    * seed: 32 bytes the keys derive from -- as secret as the keys, so the default is fresh
-   * randomness; a fixed seed is for tests.  params: default PARAMS.PRIME_BSK_GROUPED, as the
+   * randomness; a fixed seed is for tests.  params: default PARAMS.PRIME_BSK_GROUPED3, as the
    * HTTP server and the Python binding's GpuBackend.
    */
   constructor(opts) {
@@ -82,7 +82,7 @@ class NativeEngine {
     openLibrary(o.libPath);
     const seed = o.seed ? Buffer.from(o.seed) : crypto.randomBytes(32);
     if (seed.length !== 32) throw new RangeError('seed must be 32 bytes');
-    this.handle = native.createContext(seed, o.device || 0, o.params || PARAMS.PRIME_BSK_GROUPED);
+    this.handle = native.createContext(seed, o.device || 0, o.params || PARAMS.PRIME_BSK_GROUPED3);
     if (o.keygen !== false) native.keygen(this.handle);
   }
 

@@ -122,7 +122,7 @@ def extract(glwe: np.ndarray, count: int) -> np.ndarray:
 
 class Decompressor:
     """Bootstrap of extracted blocks under a key for the compression secret (an Oracle of LWE
-    dimension KC * NC, key of the given flavour: 'q64', 'q64_grouped', 'prime' or 'grouped')."""
+    dimension KC * NC, key of the given flavour: 'q64', 'q64_grouped', 'prime', 'grouped' or 'grouped3')."""
 
     def __init__(self, flavour: str, comp_sk: np.ndarray, glwe_sk: np.ndarray, seed: bytes):
         self.flavour = flavour
@@ -141,8 +141,9 @@ class Decompressor:
             self.bsk = self.orc.gen_bsk_qp(comp_sk, glwe_sk, seed)
             self.pb = self.orc.prepare_bsk_qp(self.bsk)
         else:
-            self.bsk = self.orc.gen_bsk_qp_grouped(comp_sk, glwe_sk, seed)
-            self.pb = self.orc.prepare_bsk_qp_grouped(self.bsk)
+            bits = 3 if flavour == "grouped3" else 2
+            self.bsk = self.orc.gen_bsk_qp_grouped(comp_sk, glwe_sk, seed, bits)
+            self.pb = self.orc.prepare_bsk_qp_grouped(self.bsk, bits)
 
     def table(self, message_modulus: int = 4) -> np.ndarray:
         return self.orc.make_lut(lambda x: ((x + message_modulus // 2) // message_modulus) % message_modulus)

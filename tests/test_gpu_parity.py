@@ -684,7 +684,7 @@ def test_lift_guard_of_the_grouped_key_over_the_torus(factored):
         forced.close()
 
 
-@pytest.mark.parametrize("params_id", [1, 2, 3, 4])
+@pytest.mark.parametrize("params_id", [1, 2, 3, 4, 5])
 def test_library_keygen_round_trip(params_id):
     """Keys made by the library itself (both bootstrapping-key moduli): encrypt -> bootstrap ->
     decrypt, and the oracle decrypts library ciphertexts with the exported secret key."""
@@ -709,7 +709,8 @@ def test_library_keygen_round_trip(params_id):
         ctx.close()
 
 
-@pytest.mark.parametrize("params_id", [1, 2, 3, 4], ids=["bsk_q64", "bsk_prime", "bsk_prime_grouped", "bsk_q64_grouped"])
+@pytest.mark.parametrize("params_id", [1, 2, 3, 4, 5],
+                         ids=["bsk_q64", "bsk_prime", "bsk_prime_grouped", "bsk_q64_grouped", "bsk_prime_grouped3"])
 def test_full_size_batch_properties(params_id):
     """The benchmark's configuration (4096 blocks, 16 distinct tables) through size-independent
     properties: every output decrypts to f(m); a second pass gives the same bits (no dependence on

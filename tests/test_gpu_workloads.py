@@ -9,7 +9,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[1, 3], ids=["bsk_q64", "bsk_prime_grouped"])
+@pytest.fixture(scope="module", params=[1, 5], ids=["bsk_q64", "bsk_prime_grouped3"])
 def ctx(request):
     from fhe_amd.native import Context
     c = Context(seed=bytes(range(32)), params_id=request.param)

@@ -19,6 +19,7 @@ DOCUMENTED = {
     "prime": (1.01, -130.0),
     "grouped": (1.38, -129.2),
     "q64_grouped": (1.38, -129.1),
+    "grouped3": (1.46, -128.9),
 }
 
 

@@ -7,7 +7,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from fhe_amd.native import Context
 
-ctx = Context(seed=bytes(range(32)), params_id=3)
+ctx = Context(seed=bytes(range(32)), params_id=5)
 ctx.keygen()
 t0 = time.perf_counter()
 ctx.compression_keygen()

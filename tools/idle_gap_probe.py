@@ -15,7 +15,7 @@ def main():
     from fhe_amd.native import Context
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     dev = torch.device("cuda", 0)
-    ctx = Context(seed=bytes(range(32)), params_id=3)
+    ctx = Context(seed=bytes(range(32)), params_id=5)
     ctx.keygen()
     N = ctx.N
     vals = np.random.default_rng(1).integers(0, 256, size=(B + 3) // 4)

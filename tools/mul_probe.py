@@ -1,7 +1,7 @@
 import sys, os, time
 sys.path.insert(0, os.getcwd())
 from fhe_amd.native import Context
-ctx = Context(seed=bytes(range(32)), params_id=3)
+ctx = Context(seed=bytes(range(32)), params_id=int(sys.argv[1]) if len(sys.argv) > 1 else 3)
 ctx.keygen()
 a, b = ctx.encrypt(0x123456789ABCDEF0, 64), ctx.encrypt(0x0FEDCBA987654321, 64)
 ctx.evaluate("mul", 64, a, b)

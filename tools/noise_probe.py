@@ -27,7 +27,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-FLAVOURS = (("q64", 1), ("prime", 2), ("grouped", 3), ("q64_grouped", 4))
+FLAVOURS = (("q64", 1), ("prime", 2), ("grouped", 3), ("q64_grouped", 4), ("grouped3", 5))
 CHUNK = 16384
 KEEP = 32768      # candidate records kept per key
 
@@ -52,7 +52,13 @@ def main():
     prefix = sys.argv[2] if len(sys.argv) > 2 else os.path.join("gpurun_out", "noise_probe")
     os.makedirs(os.path.dirname(prefix) or ".", exist_ok=True)
     res, cand = {}, {}
+    only = os.environ.get("NOISE_PROBE_ONLY")      # a comma-separated subset of the flavours, merged into an existing file
+    if only and os.path.exists(prefix + ".json"):
+        res = json.load(open(prefix + ".json"))
+        cand = dict(np.load(prefix + "_candidates.npz"))
     for name, pid in FLAVOURS:
+        if only and name not in only.split(","):
+            continue
         ctx = Context(seed=bytes((13 * i + 1) & 0xFF for i in range(32)), params_id=pid)
         ctx.keygen()
         blob = ctx.export_keys(KEY_CLIENT)

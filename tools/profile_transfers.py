@@ -11,7 +11,7 @@ from fhe_amd import workloads
 from fhe_amd.native import Context
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-ctx = Context(seed=bytes(range(32)), params_id=3)
+ctx = Context(seed=bytes(range(32)), params_id=5)
 ctx.keygen()
 rnd = random.Random(1)
 t0 = time.perf_counter()
