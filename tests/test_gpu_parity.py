@@ -748,13 +748,14 @@ def test_full_size_batch_properties(params_id):
         # made (exported, handed to the oracle as raw words)
         from fhe_amd.native import KEY_SERVER
         words = np.frombuffer(ctx.export_keys(KEY_SERVER), dtype=np.uint8)
-        n_ggsw = {1: 918, 2: 918, 3: 1836, 4: 1836}[params_id]
+        n_ggsw = {1: 918, 2: 918, 3: 1836, 4: 1836, 5: 2448}[params_id]
         nb, nk, nz = n_ggsw * 4 * N, N * 4 * 919, 1449 * 919
         raw = np.frombuffer(words[-(nb + nk + nz) * 8:].tobytes(), dtype=np.uint64)
         bsk_raw, ksk_raw, zeros_raw = raw[:nb].copy(), raw[nb:nb + nk].copy(), raw[nb + nk:].reshape(1449, 919).copy()
         orc = Oracle()
         orc.set_ms(zeros_raw)
-        prep = {1: orc.prepare_bsk, 2: orc.prepare_bsk_qp, 3: orc.prepare_bsk_qp_grouped, 4: orc.prepare_bsk_grouped}[params_id]
+        prep = {1: orc.prepare_bsk, 2: orc.prepare_bsk_qp, 3: orc.prepare_bsk_qp_grouped, 4: orc.prepare_bsk_grouped,
+                5: lambda k: orc.prepare_bsk_qp_grouped(k, 3)}[params_id]
         batch = orc.pbs_batch if params_id in (1, 4) else orc.pbs_batch_qp
         pick = np.arange(0, B, 31)[:128]
         luts_o = np.stack([np.concatenate([np.zeros(N, dtype=np.uint64), l]) for l in luts])
