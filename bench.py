@@ -332,6 +332,15 @@ def main(argv=None, backend=None):
                          # from the tracked rocprofv3 --pmc summary of this build (null: none for these sources)
                          "traffic": traffic, "traffic_source": traffic_source,
                          "traffic_ratio": traffic / algo_bytes if traffic else None,
+                         # what leaves the L2s is the key image, once per XCD and per round of co-resident
+                         # workgroups at best (the image does not fit the 4 MB L2 of an XCD, which holds about
+                         # eight steps of it, so workgroups that drift further apart fetch a step again; it does
+                         # fit the 256 MB memory-side cache, so little of this reaches HBM)
+                         "traffic_note": (f"{traffic / KEY_IMAGE_BYTES[flavour]:.1f} sweeps of the {KEY_IMAGE_BYTES[flavour] >> 20} MiB "
+                                          f"key image (8 XCDs x {B // CTS_PER_WORKGROUP[flavour] // 512:d} rounds of 2 workgroups per CU "
+                                          f"= {8 * (B // CTS_PER_WORKGROUP[flavour] // 512):d} if every round shared each fetch); "
+                                          f"{traffic / br_s / 1e9:.0f} GB/s; traffic_ratio is against keys once + ciphertexts in and out")
+                                         if traffic and flavour in ("grouped", "grouped3") else None,
                          "issue_frac": pmc.get("issue_frac"), "clock_ghz": pmc.get("clock_ghz"),
                          "valu_wave_insts_per_launch": pmc.get("valu_wave_insts_per_launch"),
                          "hbm": {"achieved": algo_bytes / ((ks_ms + br_ms) * 1e-3) / 1e9, "peak": 8000.0,
