@@ -62,9 +62,9 @@ def measured_counters(flavour: str, batch: int) -> dict:
 # algorithmic bytes of one batch launch: both keys once + one ciphertext in and out per bootstrap
 BSK_BYTES, KSK_BYTES, CT_BYTES = 60162048, 60227584, 16392
 # device image of the bootstrapping key (f64 residues in the transform domain)
-KEY_IMAGE_BYTES = {"q64": 918 * 131072, "q64_grouped": 1836 * 131072, "prime": 918 * 65536, "grouped": 1836 * 65536,
-                   "grouped3": 2448 * 65536}
-CTS_PER_WORKGROUP = {"q64": 1, "q64_grouped": 2, "prime": 1, "grouped": 2, "grouped3": 2}
+KEY_IMAGE_BYTES = {"q64": 918 * 131072, "q64_grouped": 1836 * 131072, "q64_grouped3": 2448 * 131072, "prime": 918 * 65536,
+                   "grouped": 1836 * 65536, "grouped3": 2448 * 65536}
+CTS_PER_WORKGROUP = {"q64": 1, "q64_grouped": 2, "q64_grouped3": 2, "prime": 1, "grouped": 2, "grouped3": 2}
 # three key bits per step: 306 steps of 4 transforms, per point 20 products for the step's GGSW entries (five each,
 # factored) + 4 for the external product
 MODMUL_PER_PBS_GROUPED3 = 306 * (4 * 11264 + 24 * 2048)
@@ -73,7 +73,8 @@ MODMUL_PER_PBS_GROUPED3 = 306 * (4 * 11264 + 24 * 2048)
 # bootstrapping-key flavour -> (parameter set id, label, kernel, VALU peak in butterflies/s per GPU)
 FLAVOURS = {
     "q64": (1, "2^64", "k_blind_rotate"),
-    "q64_grouped": (4, "2^64, key bits in pairs", "k_blind_rotate_g64_pair<true>"),
+    "q64_grouped": (4, "2^64, key bits in pairs", "k_blind_rotate_g64_pair<true, 2>"),
+    "q64_grouped3": (6, "2^64, key bits in triples", "k_blind_rotate_g64_pair<true, 2, false, 3>"),
     "prime": (2, "703687441727489 (NTT prime)", "k_blind_rotate_q"),
     "grouped": (3, "703687441727489 (NTT prime), key bits in pairs", "k_blind_rotate_q2_pair<false, true>"),
     "grouped3": (5, "703687441727489 (NTT prime), key bits in triples", "k_blind_rotate_q3<2>"),
@@ -94,11 +95,13 @@ def cpu_baseline(seconds_budget: float = 20.0, flavour: str = "prime"):
         pb = orc.prepare_bsk_qp_grouped(orc.gen_bsk_qp_grouped(lwe_sk, glwe_sk, seed_bytes(9)))
     elif flavour == "q64_grouped":
         pb = orc.prepare_bsk_grouped(orc.gen_bsk_grouped(lwe_sk, glwe_sk, seed_bytes(9)))
+    elif flavour == "q64_grouped3":
+        pb = orc.prepare_bsk_grouped(orc.gen_bsk_grouped(lwe_sk, glwe_sk, seed_bytes(9), 3), 3)
     elif flavour == "prime":
         pb = orc.prepare_bsk_qp(orc.gen_bsk_qp(lwe_sk, glwe_sk, seed_bytes(9)))
     else:
         pb = orc.prepare_bsk(bsk)
-    pbs_batch = orc.pbs_batch if flavour in ("q64", "q64_grouped") else orc.pbs_batch_qp
+    pbs_batch = orc.pbs_batch if flavour.startswith("q64") else orc.pbs_batch_qp
     r = Rng(seed_bytes(10))
     lut = orc.make_lut(lambda x: x)
     probe = np.stack([orc.encrypt_block(glwe_sk, int(r.u64() % 16), r) for _ in range(threads)])
@@ -283,19 +286,19 @@ def main(argv=None, backend=None):
         br_s = br_ms * 1e-3
         # priced with the products the kernel really executes (12 per point with the factored key image, 16 without)
         modmul = MODMUL_PER_PBS
-        if flavour == "grouped3":
+        if flavour in ("grouped3", "q64_grouped3"):
             modmul = MODMUL_PER_PBS_GROUPED3
         elif flavour in ("grouped", "q64_grouped"):
             modmul = MODMUL_PER_PBS_GROUPED_FACTORED if factored else MODMUL_PER_PBS_GROUPED
         achieved = B * modmul / br_s / 1e9
-        peak = PEAK_GBFLY_PER_PRIME / 2 if flavour in ("q64", "q64_grouped") else PEAK_GBFLY_PER_PRIME
+        peak = PEAK_GBFLY_PER_PRIME / 2 if flavour.startswith("q64") else PEAK_GBFLY_PER_PRIME
         algo_bytes = BSK_BYTES + KSK_BYTES + 2 * CT_BYTES * B
         pmc = measured_counters(flavour, B)
         traffic, traffic_source = pmc.get("bytes_per_launch_4096"), pmc.get("source")
         classic = B * MODMUL_PER_PBS / br_s / 1e9 / peak
         unit_note = (f"achieved = {B} bootstraps x modmul_per_pbs / blind-rotation launch time; modmul_per_pbs counts the modular "
                      "products this kernel's algorithm executes")
-        if flavour == "grouped3":
+        if flavour in ("grouped3", "q64_grouped3"):
             unit_note += (f": {MODMUL_PER_PBS_GROUPED3} = 306 steps x (4 transforms x 11264 butterflies + 24 products x 2048 points) "
                           f"with the key bits in triples, where the classic one-bit-per-step count ({MODMUL_PER_PBS}) would read "
                           f"frac = {classic:.3f}")
@@ -306,7 +309,7 @@ def main(argv=None, backend=None):
                           f"read frac = {classic:.3f}")
         unit_note += (f"; peak = {PEAK_GBFLY_PER_PRIME:.0f} G exact f64 butterflies/s per prime, calibrated register-resident at "
                       "2.39 GHz (profiles/r01/valu_rates_8wg_per_cu.txt)" + (", halved: two primes per product over 2^64"
-                                                                              if flavour in ("q64", "q64_grouped") else ""))
+                                                                              if flavour.startswith("q64") else ""))
         res = {
             "metric": "programmable bootstraps/sec (node)",
             "value": value,
@@ -360,7 +363,8 @@ def main(argv=None, backend=None):
             res["other_bootstrapping_keys"] = alts
             # the parameter set with every modulus as the reference names it (2^64): the one-bit key any
             # 2^64 engine can load, and this library's own key with the bits in pairs
-            for name, field in (("q64", "value_q64_key"), ("q64_grouped", "value_q64_grouped_key")):
+            for name, field in (("q64", "value_q64_key"), ("q64_grouped", "value_q64_grouped_key"),
+                                ("q64_grouped3", "value_q64_grouped3_key")):
                 leg = [a for a in alts if a["flavour"] == name]
                 if leg:
                     res[field] = leg[0]["value"]
@@ -368,11 +372,14 @@ def main(argv=None, backend=None):
             res["value_q64_key"] = value
         if flavour == "q64_grouped":
             res["value_q64_grouped_key"] = value
+        if flavour == "q64_grouped3":
+            res["value_q64_grouped3_key"] = value
         # `value` is on this library's fastest server key (config.bsk_modulus says which); the same workload with
         # every modulus exactly as the parameter set is published:
         res["value_param_set_as_published"] = {
             "one_bit_key_any_2^64_engine_can_load": res.get("value_q64_key"),
-            "own_key_with_the_key_bits_in_pairs": res.get("value_q64_grouped_key"), "unit": "PBS/s"}
+            "own_key_with_the_key_bits_in_pairs": res.get("value_q64_grouped_key"),
+            "own_key_with_the_key_bits_in_triples": res.get("value_q64_grouped3_key"), "unit": "PBS/s"}
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(flavour=flavour)
         print(json.dumps(res), flush=True)

@@ -41,7 +41,7 @@ def main(argv=None, backend=None):
     ap.add_argument("--bids", type=int, default=1000, help="total over all GPUs")
     ap.add_argument("--mul-batch", type=int, default=256,
                     help="random pairs, total over all GPUs (the reference's vectors are added)")
-    ap.add_argument("--bsk-modulus", choices=["q64", "prime", "grouped", "q64_grouped", "grouped3"], default="grouped3",
+    ap.add_argument("--bsk-modulus", choices=["q64", "prime", "grouped", "q64_grouped", "grouped3", "q64_grouped3"], default="grouped3",
                     help="bootstrapping key: over 2^64, over the NTT prime, or over the prime with the key bits in pairs")
     args = ap.parse_args(argv)
 
@@ -64,7 +64,7 @@ def main(argv=None, backend=None):
         else:
             dist.init_process_group(backend.collective, rank=rank, world_size=world)
     seed = bytes((11 * i + 5) & 0xFF for i in range(32))
-    ctx, keep = backend.context(dist, rank, world, dev, seed, {"q64": 1, "prime": 2, "grouped": 3, "q64_grouped": 4, "grouped3": 5}[args.bsk_modulus])
+    ctx, keep = backend.context(dist, rank, world, dev, seed, {"q64": 1, "prime": 2, "grouped": 3, "q64_grouped": 4, "grouped3": 5, "q64_grouped3": 6}[args.bsk_modulus])
 
     def timed(fn):
         """Wall time of fn over all ranks: barrier on both sides, maximum over ranks."""

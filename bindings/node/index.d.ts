@@ -14,7 +14,7 @@ export type Operator =
   | 'div' | 'rem' | 'cast';
 
 /** Parameter set ids of include/lfhe.h: bootstrapping key over 2^64, over the NTT prime, over the prime with key bits in pairs. */
-export const PARAMS: { readonly Q64: 1; readonly PRIME_BSK: 2; readonly PRIME_BSK_GROUPED: 3; readonly Q64_GROUPED: 4; readonly PRIME_BSK_GROUPED3: 5 };
+export const PARAMS: { readonly Q64: 1; readonly PRIME_BSK: 2; readonly PRIME_BSK_GROUPED: 3; readonly Q64_GROUPED: 4; readonly PRIME_BSK_GROUPED3: 5; readonly Q64_GROUPED3: 6 };
 export const KEY: { readonly CLIENT: 1; readonly SERVER: 2 };
 
 export interface NativeEngineOptions {

@@ -13,7 +13,7 @@ const path = require('path');
 const crypto = require('crypto');
 const native = require('./lfhe_napi.node');
 
-const PARAMS = { Q64: 1, PRIME_BSK: 2, PRIME_BSK_GROUPED: 3, Q64_GROUPED: 4, PRIME_BSK_GROUPED3: 5 };
+const PARAMS = { Q64: 1, PRIME_BSK: 2, PRIME_BSK_GROUPED: 3, Q64_GROUPED: 4, PRIME_BSK_GROUPED3: 5, Q64_GROUPED3: 6 };
 const KEY = { CLIENT: 1, SERVER: 2 };
 const COMPARISONS = new Set(['eq', 'ne', 'ge', 'gt', 'le', 'lt']);
 const WIDTHS = new Set([1, 8, 16, 32, 64, 128, 160, 256]);

@@ -131,7 +131,8 @@ int32_t lfhe_ctx_create(lfhe_ctx** out, uint32_t params_id, int32_t device, cons
         params_id != LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK &&
         params_id != LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK_GROUPED &&
         params_id != LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_GROUPED &&
-        params_id != LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK_GROUPED3)
+        params_id != LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK_GROUPED3 &&
+        params_id != LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_GROUPED3)
         return LFHE_ERR_UNSUPPORTED;
     lfhe_params p;
     lfhe_default_params(&p);
@@ -139,7 +140,9 @@ int32_t lfhe_ctx_create(lfhe_ctx** out, uint32_t params_id, int32_t device, cons
         params_id == LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK_GROUPED ||
         params_id == LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK_GROUPED3)
         p.bsk_modulus = LFHE_BSK_MODULUS_PRIME;
-    if (params_id == LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK_GROUPED3) p.bsk_grouping = 3;
+    if (params_id == LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK_GROUPED3 ||
+        params_id == LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_GROUPED3)
+        p.bsk_grouping = 3;
     if (params_id == LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK_GROUPED ||
         params_id == LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_GROUPED)
         p.bsk_grouping = 2;

@@ -26,8 +26,6 @@ Engine::Engine(int device, const EngineParams& p) : device_(device), prm_(p) {
     if (p.bsk_modulus != 0 && p.bsk_modulus != QP_U)
         throw std::runtime_error("unsupported bootstrapping-key modulus: 0 (2^64) or 703687441727489");
     if (p.bsk_grouping < 1 || p.bsk_grouping > 3) throw std::runtime_error("unsupported key grouping: 1, 2 or 3");
-    if (p.bsk_grouping == 3 && p.bsk_modulus != QP_U)
-        throw std::runtime_error("unsupported key grouping: three key bits per step need the prime bootstrapping-key modulus");
     if (p.ms_zeros_count && (p.ms_bound_log2 < 27 || p.ms_bound_log2 > 63 || !(p.ms_r_sigma_factor > 0) ||
                              !(p.ms_r_sigma_factor < 1024) || !(p.ms_input_variance >= 0) ||
                              !(p.ms_input_variance < 1e-3)))
@@ -56,7 +54,7 @@ Engine::Engine(int device, const EngineParams& p) : device_(device), prm_(p) {
     if (const char* e = std::getenv("LFHE_KS_MFMA_MIN")) ksm_min_ = std::atoi(e);     // 0: VALU key switch only
     if (!ksm_supported(N, (int)p.ks_level, (int)p.lwe_dim)) ksm_min_ = 0;
 
-    if (!single_modulus() && p.bsk_grouping == 2) {
+    if (!single_modulus() && p.bsk_grouping >= 2) {
         // lift guard of the grouped key over 2^64 (kernels.hip: k_blind_rotate_g64_pair): marks of one launch and
         // the count of ciphertexts that took the slow path, made here so that no bootstrap call allocates
         g64_guard_.capacity = 65536;
@@ -161,16 +159,18 @@ bool Engine::build_bsk_image(const u64* host_bsk, size_t total, double* dst) {
         // three key bits per step: every slab of eight groups is transformed into a staging buffer and
         // written out in the factored layout its kernel streams (kernels.hip: k_bsk_factor3).  A key with a
         // non-invertible word (one in 10^8) has no such image: the caller has to come with another key.
+        // With both primes (2^64) the staging rows hold both transforms and each prime is factored by itself.
         double* d_tmp = nullptr;
         int* d_flag = nullptr;
-        HC(hipMalloc(&d_tmp, slab * BSKQ_ROW * sizeof(double)));
+        HC(hipMalloc(&d_tmp, slab * row * sizeof(double)));
         HC(hipMalloc(&d_flag, sizeof(int)));
         HC(hipMemsetAsync(d_flag, 0, sizeof(int), stream_));
         for (size_t i0 = 0; i0 < total; i0 += slab) {
             const size_t cnt = (total - i0) < slab ? (total - i0) : slab;
             HC(hipMemcpyAsync(d_raw, host_bsk + i0 * 4 * N, cnt * 4 * N * sizeof(u64), hipMemcpyHostToDevice, stream_));
-            launch_bskq_prepare(T_, d_raw, d_tmp, cnt * 4, stream_);
-            launch_bsk_factor3(T_, d_tmp, dst + i0 * row, cnt / 8, d_flag, stream_);
+            if (single_modulus()) launch_bskq_prepare(T_, d_raw, d_tmp, cnt * 4, stream_);
+            else launch_ntt_forward(T_, d_raw, d_tmp, cnt * 4, 1, stream_);
+            launch_bsk_factor3(T_, d_tmp, dst + i0 * row, cnt / 8, d_flag, single_modulus() ? 1 : 2, stream_);
             HC(hipGetLastError());
             HC(hipStreamSynchronize(stream_));
         }
@@ -180,7 +180,7 @@ bool Engine::build_bsk_image(const u64* host_bsk, size_t total, double* dst) {
         HC(hipFree(d_flag));
         HC(hipFree(d_raw));
         if (flag) throw std::runtime_error("unsupported key: a word of the bootstrapping key is not invertible modulo the prime "
-                                           "(one key in 10^8); generate another key");
+                                           "(one key in 10^8, one in 5 * 10^7 over 2^64); generate another key");
         return true;
     }
     auto transform_all = [&]() {
@@ -528,7 +528,7 @@ void Engine::blind_rotate_with(const double* bsk, uint32_t n, const u64* lwe_sma
                                   stream_);
         else
             launch_blind_rotate(T_, bsk, in, (int)n, luts, li, gout, lout, cnt, omap,
-                                prm_.bsk_grouping == 2 && fact ? 3 : (int)prm_.bsk_grouping,
+                                prm_.bsk_grouping == 3 ? 4 : prm_.bsk_grouping == 2 && fact ? 3 : (int)prm_.bsk_grouping,
                                 pair_above_ != -2 ? pair_above_ : (cnt > 2 * (size_t)cu_count_ ? 0 : -1), g64_guard_, stream_);
         HC(hipGetLastError());
     }

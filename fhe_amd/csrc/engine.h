@@ -63,7 +63,7 @@ void launch_blind_rotate(const Tables& T, const double* bsk, const u64* lwe_smal
                          const BlockMap& omap, int grouping, int pair_above, const G64Guard& guard, hipStream_t st);
 void launch_bskq_prepare(const Tables& T, const u64* in, double* out, size_t polys, hipStream_t st);
 // three key bits per step: groups of eight transformed GGSWs (src) -> the factored image the kernel streams (dst)
-void launch_bsk_factor3(const Tables& T, const double* src, double* dst, size_t groups, int* degenerate, hipStream_t st);
+void launch_bsk_factor3(const Tables& T, const double* src, double* dst, size_t groups, int* degenerate, int primes, hipStream_t st);
 // grouped key image -> factored form, in place (row_words: BSKQ_ROW or BSK_ROW); *degenerate (device) is set
 // when a word has none
 void launch_bsk_factor(const Tables& T, double* img, size_t groups, size_t row_words, int* degenerate, hipStream_t st);

@@ -1057,32 +1057,35 @@ __device__ __forceinline__ double mod_inverse(double x, const Prime& P, u64 p);
 constexpr int BSK3_GROUP = 8 * BSKQ_ROW;    // doubles per group of eight GGSWs
 LFHE_HD unsigned bsk3_off(unsigned p, unsigned w, unsigned q, unsigned t) { return (((p * 4 + w) * 4 + q) * NT + t) * 2; }
 
-// eight GGSW rows in the transform layout of k_bskq_prepare (src: [m][q][c4][t][2]) -> the factored image
+// eight GGSW rows in the transform layout (src: [m][prime][q][c4][t][2], `src_row` doubles per GGSW: BSKQ_ROW
+// with the prime ring modulus, BSK_ROW with both primes) -> the factored image of prime r
+// (dst: [group][prime][p][w][q][t][2], `dst_group` doubles per group)
 __global__ void __launch_bounds__(256) k_bsk_factor3(Tables T, const double* __restrict__ src, double* __restrict__ dst,
-                                                     size_t groups, int* __restrict__ degenerate) {
+                                                     size_t groups, int* __restrict__ degenerate, unsigned r,
+                                                     size_t src_row, size_t dst_group) {
     const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;     // (group, q, position e)
     if (id >= groups * 4 * N) return;
     const size_t g = id / (4 * N);
     const unsigned q = (unsigned)(id / N % 4), e = (unsigned)(id % N);
     const unsigned t = e >> 3, pp = e & 7;
-    const Prime P = T.pr[0];
-    const double* in = src + g * BSK3_GROUP + bsk_off(0, q, pp >> 1, t) + (pp & 1);
+    const Prime P = T.pr[r];
+    const double* in = src + g * 8 * src_row + bsk_off(r, q, pp >> 1, t) + (pp & 1);
     double k[8];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) k[m] = mnorm(mnorm(in[(size_t)m * BSKQ_ROW], P), P);
+    for (int m = 0; m < 8; ++m) k[m] = mnorm(mnorm(in[(size_t)m * src_row], P), P);
     double out[8];
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const double k0 = k[4 * half], k1 = k[4 * half + 1], k2 = k[4 * half + 2], k3 = k[4 * half + 3];
         if (k3 == 0.0) { atomicOr(degenerate, 1); return; }
-        const double inv = mod_inverse(k3, P, P0_U);
+        const double inv = mod_inverse(k3, P, r ? P1_U : P0_U);
         const double a = mnorm(mmul(k2, inv, P), P), b = mnorm(mmul(k1, inv, P), P);
         const double c = mnorm(k0 - mmul(k1, a, P), P);
         // pairs in load order: (a1, b1), (d1, c1), (a0, b0), (d0, c0)
         const int base = half == 1 ? 0 : 4;
         out[base] = a; out[base + 1] = b; out[base + 2] = k3; out[base + 3] = c;
     }
-    double* o = dst + g * BSK3_GROUP;
+    double* o = dst + g * dst_group + (size_t)r * BSK3_GROUP;
 #pragma unroll
     for (unsigned w = 0; w < 4; ++w) {
         const unsigned at = bsk3_off(pp, w, q, t);
@@ -1091,9 +1094,13 @@ __global__ void __launch_bounds__(256) k_bsk_factor3(Tables T, const double* __r
     }
 }
 
-void launch_bsk_factor3(const Tables& T, const double* src, double* dst, size_t groups, int* degenerate, hipStream_t st) {
+// primes: 1 (image of the prime ring modulus) or 2 (both primes of the 2^64 arithmetic, src rows of BSK_ROW)
+void launch_bsk_factor3(const Tables& T, const double* src, double* dst, size_t groups, int* degenerate, int primes,
+                        hipStream_t st) {
     const size_t words = groups * 4 * N;
-    hipLaunchKernelGGL(k_bsk_factor3, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, T, src, dst, groups, degenerate);
+    for (int r = 0; r < primes; ++r)
+        hipLaunchKernelGGL(k_bsk_factor3, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, T, src, dst, groups, degenerate,
+                           (unsigned)r, (size_t)(primes == 2 ? BSK_ROW : BSKQ_ROW), (size_t)primes * BSK3_GROUP);
 }
 
 // NC ciphertexts per workgroup (2: throughput, as k_blind_rotate_q2_pair; 1: launches that would leave
@@ -1382,11 +1389,14 @@ constexpr size_t g64_lds_bytes(int nc) { return (size_t)nc * LDS_BYTES + G64_TW_
 // One prime's share of a step for the NC (two, or one for launches that do not fill the GPU) ciphertexts of a workgroup: digits in x (pass-1
 // ownership) -> residues of the external product in x (|x| < 2 p, pass-1 ownership).  Ends with the
 // workgroup barrier that frees the exchange buffers.
-// TERM: -1 the whole step's GGSW; 0..3 one of its four terms alone (the slow path, see below).
-template <int R, bool FACTORED, int NC, int TERM = -1>
+// TERM: -1 the whole step's GGSW; 0..2^BITS - 1 one of its terms alone (the slow path, see below).
+// BITS: key bits per step, 2 (rows: four GGSW rows of BSK_ROW words) or 3 (rows: the group's factored image
+// of both primes as k_bsk_factor3 lays it out; the point-wise stage is k_blind_rotate_q3's).
+template <int R, bool FACTORED, int NC, int TERM = -1, int BITS = 2>
 __device__ __forceinline__ void g64_prime_pass(double (&x)[NC][2][E], const Tables& T,
-                                               const double* __restrict__ rows, const unsigned (&am)[NC][2],
+                                               const double* __restrict__ rows, const unsigned (&am)[NC][BITS],
                                                unsigned t) {
+    static_assert(BITS == 2 || (BITS == 3 && FACTORED), "three key bits per step come with the factored image only");
     const Prime P = T.pr[R];
     const double* __restrict__ twf_small = lds_dyn + NC * LDS_WORDS + 2 * R * G2_TW_SMALL;
     const double* __restrict__ twi_small = twf_small + G2_TW_SMALL;
@@ -1448,16 +1458,21 @@ __device__ __forceinline__ void g64_prime_pass(double (&x)[NC][2][E], const Tabl
     asm volatile("" : "+v"(tt));
     {
         const unsigned ut = 2 * rev8(tt) + 1;
-        double base[NC][2];
+        double base[NC][BITS];
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
-            for (int m = 0; m < 2; ++m) base[c][m] = ldt(mono, (am[c][m] * ut) & (2 * N - 1));
+            for (int m = 0; m < BITS; ++m) base[c][m] = ldt(mono, (am[c][m] * ut) & (2 * N - 1));
         // key words of unit u = 4 c4 + m: GGSW m of the group, this prime, the four polynomials q,
         // positions 8 t + 2 c4 + {0, 1}; the next unit's loads are in flight while this one is multiplied
+        // (three bits: unit u = 4 p + w, position 8 t + p, word pair w of this prime's factored image)
+        const double* __restrict__ rows3 = rows + (BITS == 3 ? R * BSK3_GROUP : 0);
         double kc[4][2], kn[4][2];
 #pragma unroll
-        for (unsigned q = 0; q < 4; ++q) { const unsigned o = bsk_off(R, q, 0, tt); kc[q][0] = LFHE_LDK(rows, o); kc[q][1] = LFHE_LDK(rows, o + 1); }
+        for (unsigned q = 0; q < 4; ++q) {
+            const unsigned o = BITS == 3 ? bsk3_off(0, 0, q, tt) : bsk_off(R, q, 0, tt);
+            kc[q][0] = LFHE_LDK(rows3, o); kc[q][1] = LFHE_LDK(rows3, o + 1);
+        }
 #pragma unroll
         for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -1470,6 +1485,53 @@ __device__ __forceinline__ void g64_prime_pass(double (&x)[NC][2][E], const Tabl
         const double* __restrict__ w8 = mono + MONO_WORDS;
         auto chunk = [&](auto c4_tag) {
             constexpr int c4 = decltype(c4_tag)::value;
+            if constexpr (BITS == 3) {
+                double M[NC][3][2];
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) mono_pair<c4>(base[c][i], w8, am[c][i], P, M[c][i][0], M[c][i][1]);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int p = 2 * c4 + h;
+                    double B[NC][4], Tm[NC][4];
+#pragma unroll
+                    for (int wd = 0; wd < 4; ++wd) {
+                        const int u = 4 * p + wd;
+                        if (u < 31) {
+                            const unsigned pn = (unsigned)(u + 1) / 4, wn = (unsigned)(u + 1) % 4;
+#pragma unroll
+                            for (unsigned q = 0; q < 4; ++q) {
+                                const unsigned o = bsk3_off(pn, wn, q, tt);
+                                kn[q][0] = LFHE_LDK(rows3, o); kn[q][1] = LFHE_LDK(rows3, o + 1);
+                            }
+                        }
+#pragma unroll
+                        for (int c = 0; c < NC; ++c)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const double m1 = M[c][0][h], m2 = M[c][1][h], m3 = M[c][2][h];
+                                if constexpr (TERM < 0) {
+                                    if (wd == 0) Tm[c][q] = mmul(m1 + kc[q][0], m2 + kc[q][1], P);              // (m1 + a1)(m2 + b1)
+                                    else if (wd == 1) Tm[c][q] = mmul(mmul(Tm[c][q], kc[q][0], P) + kc[q][1], m3, P);   // m3 A1
+                                    else if (wd == 2) B[c][q] = mmul(m1 + kc[q][0], m2 + kc[q][1], P);          // (m1 + a0)(m2 + b0)
+                                    else B[c][q] = (mmul(B[c][q], kc[q][0], P) + kc[q][1]) + Tm[c][q];          // A0 + m3 A1, |B| < 1.8 p
+                                } else {
+                                    ggsw3_term_row<TERM>(wd, B[c][q], Tm[c][q], kc[q][0], kc[q][1], m1, m2, m3, P);
+                                }
+                            }
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { kc[q][0] = kn[q][0]; kc[q][1] = kn[q][1]; }
+                    }
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        const double d0 = x[c][0][p], d1 = x[c][1][p];
+                        x[c][0][p] = mmul(B[c][0], d0, P) + mmul(B[c][2], d1, P);
+                        x[c][1][p] = mmul(B[c][1], d0, P) + mmul(B[c][3], d1, P);
+                    }
+                }
+            } else {
             double B[NC][4][2], S[NC][4][2], M1[NC][2], M2[NC][2];
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
@@ -1509,6 +1571,7 @@ __device__ __forceinline__ void g64_prime_pass(double (&x)[NC][2][E], const Tabl
                     x[c][0][j] = mmul(B[c][0][h], d0, P) + mmul(B[c][2][h], d1, P);
                     x[c][1][j] = mmul(B[c][1][h], d0, P) + mmul(B[c][3][h], d1, P);
                 }
+            }
         };
         chunk(std::integral_constant<int, 0>{});
         chunk(std::integral_constant<int, 1>{});
@@ -1583,7 +1646,8 @@ __device__ __forceinline__ void g64_prime_pass(double (&x)[NC][2][E], const Tabl
 // exact without condition), summed in wrapping 64-bit words: the same bits as an exact evaluation of
 // the fast path's formula, at four times the transforms.  The order on the stream does the rest;
 // the host is not involved.  `fallbacks` counts the ciphertexts that took the slow path.
-template <bool FACTORED, int NC, bool SAFE = false>
+// BITS = 3: three key bits per step (eight terms; the group's image is k_bsk_factor3's for both primes).
+template <bool FACTORED, int NC, bool SAFE = false, int BITS = 2>
 __global__ void __launch_bounds__(NT, 2) k_blind_rotate_g64_pair(Tables T, const double* __restrict__ bsk,
                                                                 const u64* __restrict__ lwe_small, int n,
                                                                 const u64* __restrict__ luts,
@@ -1625,15 +1689,14 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_g64_pair(Tables T, const
     }
     __syncthreads();
 
-    const int groups = (n + 1) / 2;
+    const int groups = (n + BITS - 1) / BITS;
     for (int g = 0; g < groups; ++g) {
-        unsigned am[NC][2];
+        unsigned am[NC][BITS];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            am[c][0] = modswitch_2n(lwe[c][2 * g]);
-            am[c][1] = 2 * g + 1 < n ? modswitch_2n(lwe[c][2 * g + 1]) : 0u;
-        }
-        const double* __restrict__ rows = bsk + (size_t)4 * g * BSK_ROW;
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int i = 0; i < BITS; ++i) am[c][i] = BITS * g + i < n ? modswitch_2n(lwe[c][BITS * g + i]) : 0u;
+        const double* __restrict__ rows = bsk + (size_t)g * (BITS == 3 ? 2 * BSK3_GROUP : 4 * BSK_ROW);
         int dig[NC][2][E];
         double x[NC][2][E], y0[NC][2][E];
         auto digits_to_x = [&]() {
@@ -1660,10 +1723,10 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_g64_pair(Tables T, const
                 for (int j = 0; j < E; ++j) dig[c][q][j] = decomp23(acc[c][q][j]);
         if constexpr (!SAFE) {
             digits_to_x();
-            g64_prime_pass<0, FACTORED, NC>(x, T, rows, am, t);
+            g64_prime_pass<0, FACTORED, NC, -1, BITS>(x, T, rows, am, t);
             keep_prime0();
             digits_to_x();
-            g64_prime_pass<1, FACTORED, NC>(x, T, rows, am, t);
+            g64_prime_pass<1, FACTORED, NC, -1, BITS>(x, T, rows, am, t);
 #pragma unroll
             for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -1680,10 +1743,10 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_g64_pair(Tables T, const
             auto term = [&](auto term_tag) {
                 constexpr int TERM = decltype(term_tag)::value;
                 digits_to_x();
-                g64_prime_pass<0, FACTORED, NC, TERM>(x, T, rows, am, t);
+                g64_prime_pass<0, FACTORED, NC, TERM, BITS>(x, T, rows, am, t);
                 keep_prime0();
                 digits_to_x();
-                g64_prime_pass<1, FACTORED, NC, TERM>(x, T, rows, am, t);
+                g64_prime_pass<1, FACTORED, NC, TERM, BITS>(x, T, rows, am, t);
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -1693,6 +1756,12 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_g64_pair(Tables T, const
             term(std::integral_constant<int, 1>{});
             term(std::integral_constant<int, 2>{});
             term(std::integral_constant<int, 3>{});
+            if constexpr (BITS == 3) {
+                term(std::integral_constant<int, 4>{});
+                term(std::integral_constant<int, 5>{});
+                term(std::integral_constant<int, 6>{});
+                term(std::integral_constant<int, 7>{});
+            }
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -2125,6 +2194,8 @@ void blind_rotate_setup(int dev) {
     need(ask_lds(k_blind_rotate_g64_pair<true, 2>, g64_lds_bytes(2)), "k_blind_rotate_g64_pair", g64_lds_bytes(2));
     need(ask_lds(k_blind_rotate_g64_pair<true, 1, true>, g64_lds_bytes(1)), "k_blind_rotate_g64_pair (slow path)", g64_lds_bytes(1));
     need(ask_lds(k_blind_rotate_g64_pair<false, 1, true>, g64_lds_bytes(1)), "k_blind_rotate_g64_pair (slow path)", g64_lds_bytes(1));
+    need(ask_lds(k_blind_rotate_g64_pair<true, 2, false, 3>, g64_lds_bytes(2)), "k_blind_rotate_g64_pair (three key bits)", g64_lds_bytes(2));
+    need(ask_lds(k_blind_rotate_g64_pair<true, 1, true, 3>, g64_lds_bytes(1)), "k_blind_rotate_g64_pair (three key bits, slow path)", g64_lds_bytes(1));
     need(ask_lds(k_blind_rotate_q2_wide<false>, WIDE2_LDS_BYTES), "k_blind_rotate_q2_wide", WIDE2_LDS_BYTES);
     need(ask_lds(k_blind_rotate_q2_wide<true>, WIDE2_LDS_BYTES), "k_blind_rotate_q2_wide", WIDE2_LDS_BYTES);
     need(ask_lds(k_blind_rotate_q_wide, WIDE_LDS_BYTES), "k_blind_rotate_q_wide", WIDE_LDS_BYTES);
@@ -2357,7 +2428,7 @@ void launch_blind_rotate(const Tables& T, const double* bsk, const u64* lwe_smal
                          const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
                          const BlockMap& omap, int grouping, int pair_above, const G64Guard& guard, hipStream_t st) {
     if (grouping >= 2) {
-        // four GGSWs per pair of key bits (3: in factored form); two ciphertexts per workgroup, one when
+        // four GGSWs per pair of key bits (3: in factored form; 4: eight per triple, factored); two ciphertexts per workgroup, one when
         // the launch would leave CUs without a workgroup otherwise (pair_above: as for the prime modulus)
         if (!guard.fault || count > guard.capacity) throw std::logic_error("lift-guard flags missing or too few for this launch");
         if (hipMemsetAsync(guard.fault, 0, count * sizeof(int), st) != hipSuccess) throw std::runtime_error("hipMemsetAsync failed");
@@ -2367,10 +2438,12 @@ void launch_blind_rotate(const Tables& T, const double* bsk, const u64* lwe_smal
             hipLaunchKernelGGL(kernel, g, dim3(NT), g64_lds_bytes(nc), st, T, bsk, lwe_small, n, luts, lut_index, glwe_out,
                                lwe_out, omap, (unsigned)count, guard.fault, guard.k_guard, guard.fallbacks);
         };
-        if (grouping == 3) { if (pair) go(k_blind_rotate_g64_pair<true, 2>, 2, grid); else go(k_blind_rotate_g64_pair<true, 1>, 1, grid); }
+        if (grouping == 4) { if (pair) go(k_blind_rotate_g64_pair<true, 2, false, 3>, 2, grid); else go(k_blind_rotate_g64_pair<true, 1, false, 3>, 1, grid); }
+        else if (grouping == 3) { if (pair) go(k_blind_rotate_g64_pair<true, 2>, 2, grid); else go(k_blind_rotate_g64_pair<true, 1>, 1, grid); }
         else { if (pair) go(k_blind_rotate_g64_pair<false, 2>, 2, grid); else go(k_blind_rotate_g64_pair<false, 1>, 1, grid); }
         // the slow path for whatever the fast one marked: one workgroup per ciphertext, gone at once when unmarked
-        if (grouping == 3) go(k_blind_rotate_g64_pair<true, 1, true>, 1, dim3((unsigned)count));
+        if (grouping == 4) go(k_blind_rotate_g64_pair<true, 1, true, 3>, 1, dim3((unsigned)count));
+        else if (grouping == 3) go(k_blind_rotate_g64_pair<true, 1, true>, 1, dim3((unsigned)count));
         else go(k_blind_rotate_g64_pair<false, 1, true>, 1, dim3((unsigned)count));
         return;
     }

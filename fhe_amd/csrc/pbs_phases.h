@@ -264,6 +264,28 @@ LFHE_HD void ggsw_term_row(int m, double& B, double k, double m1, double m2, con
     }
 }
 
+// The same for three key bits per step: ONE of the eight terms K0, m1 K1, m2 K2, m1 m2 K3 (TERM 0..3) and
+// m3 K4, m3 m1 K5, m3 m2 K6, m3 m1 m2 K7 (TERM 4..7) of the step's GGSW entry, from the factored word pairs
+// in their load order w = 0..3 = (a1, b1), (d1, c1), (a0, b0), (d0, c0); the key words come back as
+// K3 = d, K2 = a d, K1 = b d, K0 = c + a b d per half.  T holds the partial value between the two pairs of
+// the term's half; B is complete after w = 3.  |B| < 1.1 p.
+template <int TERM>
+LFHE_HD void ggsw3_term_row(int w, double& B, double& T, double k0, double k1, double m1, double m2, double m3,
+                            const Prime& P) {
+    constexpr int HALF = TERM >> 2, SUB = TERM & 3;
+    const int first = HALF ? 0 : 2;
+    if (w == first) {           // (a, b)
+        T = SUB == 0 ? mmul(k0, k1, P) : SUB == 1 ? k1 : SUB == 2 ? k0 : mmul(m1, m2, P);
+    } else if (w == first + 1) {   // (d, c)
+        double v = mmul(T, k0, P);
+        if (SUB == 0) v += k1;
+        else if (SUB == 1) v = mmul(v, m1, P);
+        else if (SUB == 2) v = mmul(v, m2, P);
+        T = HALF ? mmul(v, m3, P) : v;
+    }
+    if (w == 3) B = T;
+}
+
 template <bool FACTORED = false>
 LFHE_HD void ep_group2_phase5(EpState& s, double* lds, unsigned t, const Tables& T,
                               const double* __restrict__ rows, unsigned a1, unsigned a2) {

@@ -19,6 +19,7 @@ PARAMS_PRIME_BSK = 2          # same set, bootstrapping key over the NTT prime
 PARAMS_PRIME_BSK_GROUPED = 3  # prime modulus, two key bits per blind-rotation step
 PARAMS_Q64_GROUPED = 4        # every modulus 2^64 as published, two key bits per blind-rotation step
 PARAMS_PRIME_BSK_GROUPED3 = 5  # prime modulus, three key bits per blind-rotation step
+PARAMS_Q64_GROUPED3 = 6        # every modulus 2^64, three key bits per blind-rotation step
 BSK_MODULUS_PRIME = 703687441727489
 
 OPS = {"add": 0, "sub": 1, "mul": 2, "eq": 3, "ne": 4, "ge": 5, "gt": 6, "le": 7, "lt": 8, "min": 9, "max": 10,

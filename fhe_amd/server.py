@@ -311,10 +311,10 @@ def main(argv=None):
     ap.add_argument("-threshold", "--threshold", action="store_true")
     ap.add_argument("-parties", "--parties", type=int, default=1)
     ap.add_argument("--device", type=int, default=0)
-    ap.add_argument("--bootstrapping-key", choices=["q64", "q64-grouped", "prime", "grouped", "grouped3"], default="grouped3",
-                    help="server-side bootstrapping key (include/lfhe.h parameter set ids 1, 4, 2, 3): over 2^64, over 2^64 "
-                         "with the key bits in pairs, over the NTT prime, or over the prime with the key bits in pairs "
-                         "or in triples (fastest); clients see no difference")
+    ap.add_argument("--bootstrapping-key", choices=["q64", "q64-grouped", "q64-grouped3", "prime", "grouped", "grouped3"], default="grouped3",
+                    help="server-side bootstrapping key (include/lfhe.h parameter set ids 1, 4, 6, 2, 3, 5): over 2^64, over "
+                         "2^64 with the key bits in pairs or in triples, over the NTT prime, or over the prime with the key "
+                         "bits in pairs or in triples (fastest); clients see no difference")
     ap.add_argument("--seed-hex", default=None,
                     help="64 hex digits the keys are derived from (reproducible set-ups only: whoever knows the "
                          "seed knows the secret key); default: operating-system entropy")
@@ -326,7 +326,7 @@ def main(argv=None):
             raise SystemExit("--seed-hex needs 64 hex digits")
     if args.threshold:
         raise SystemExit("threshold decryption is outside this backend's scope: run without -threshold")
-    params_id = {"q64": 1, "prime": 2, "grouped": 3, "q64-grouped": 4, "grouped3": 5}[args.bootstrapping_key]
+    params_id = {"q64": 1, "prime": 2, "grouped": 3, "q64-grouped": 4, "grouped3": 5, "q64-grouped3": 6}[args.bootstrapping_key]
     srv = serve(GpuBackend(seed=seed, device=args.device, params_id=params_id), args.addr, False, args.parties)
     print(f"fhe-server (gfx950) listening on {args.addr}")
     srv.serve_forever()

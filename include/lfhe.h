@@ -59,6 +59,11 @@ extern "C" {
  * (one per product of s_i or 1 - s_i over the triple), 306 blind-rotation steps instead of 459, a
  * server key of 2448 GGSWs (157 MB on the device).  Everything a client sees is that of the named set. */
 #define LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_PRIME_BSK_GROUPED3 5u
+/* the named set itself (every modulus 2^64) with the key bits taken three at a time: eight GGSWs over 2^64
+ * per triple of bits, a third of the transforms of set 1, a server key of 2448 GGSWs (321 MB on the device
+ * for both primes).  The lift window of set 4 applies with eight key words per sum (standard deviation
+ * 2^90.9, 107 standard deviations to the end of the window), behind the same guard and exact slow path. */
+#define LFHE_PARAMS_MESSAGE_2_CARRY_2_KS_PBS_TUNIFORM_2M128_GROUPED3 6u
 
 typedef struct lfhe_ctx lfhe_ctx;
 

@@ -122,7 +122,7 @@ def extract(glwe: np.ndarray, count: int) -> np.ndarray:
 
 class Decompressor:
     """Bootstrap of extracted blocks under a key for the compression secret (an Oracle of LWE
-    dimension KC * NC, key of the given flavour: 'q64', 'q64_grouped', 'prime', 'grouped' or 'grouped3')."""
+    dimension KC * NC, key of the given flavour: 'q64', 'q64_grouped', 'q64_grouped3', 'prime', 'grouped' or 'grouped3')."""
 
     def __init__(self, flavour: str, comp_sk: np.ndarray, glwe_sk: np.ndarray, seed: bytes):
         self.flavour = flavour
@@ -134,9 +134,10 @@ class Decompressor:
             self.bsk = np.zeros(L.orc_bsk_len(C.byref(self.orc._cp)), dtype=np.uint64)
             L.orc_gen_bsk(self.orc._ctx, comp_sk, glwe_sk, rng.ref, self.bsk)
             self.pb = self.orc.prepare_bsk(self.bsk)
-        elif flavour == "q64_grouped":
-            self.bsk = self.orc.gen_bsk_grouped(comp_sk, glwe_sk, seed)
-            self.pb = self.orc.prepare_bsk_grouped(self.bsk)
+        elif flavour in ("q64_grouped", "q64_grouped3"):
+            bits = 3 if flavour == "q64_grouped3" else 2
+            self.bsk = self.orc.gen_bsk_grouped(comp_sk, glwe_sk, seed, bits)
+            self.pb = self.orc.prepare_bsk_grouped(self.bsk, bits)
         elif flavour == "prime":
             self.bsk = self.orc.gen_bsk_qp(comp_sk, glwe_sk, seed)
             self.pb = self.orc.prepare_bsk_qp(self.bsk)
@@ -150,7 +151,7 @@ class Decompressor:
 
     def bootstrap(self, small: np.ndarray, lut: np.ndarray) -> np.ndarray:
         o = self.orc
-        if self.flavour in ("q64", "q64_grouped"):
+        if self.flavour.startswith("q64"):
             return o.sample_extract(o.blind_rotate(self.pb, small, lut))
         acc = o.blind_rotate_qp(self.pb, small, lut)
         q = o.qp

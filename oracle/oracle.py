@@ -140,6 +140,10 @@ def lib():
         "orc_bsk_grouped_count": (sz, [C.POINTER(_Params)]),
         "orc_gen_bsk_grouped": (None, [vp, _u64p, _u64p, C.POINTER(_Rng), _u64p]),
         "orc_bsk_grouped_prepare": (vp, [vp, _u64p]),
+        "orc_bsk_grouped_count_n": (sz, [C.POINTER(_Params), u32]),
+        "orc_gen_bsk_grouped_n": (None, [vp, _u64p, _u64p, C.POINTER(_Rng), u32, _u64p]),
+        "orc_bsk_grouped_prepare_n": (vp, [vp, _u64p, u32]),
+        "orc_group_step_n": (None, [vp, _u64p, u32, np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS"), _u64p]),
         "orc_group_step": (None, [vp, _u64p, u32, u32, _u64p]),
         "orc_blind_rotate_qp": (None, [vp, vp, _u64p, _u64p, _u64p]),
         "orc_pbs_qp": (None, [vp, _u64p, vp, _u64p, _u64p, _u64p]),
@@ -336,20 +340,23 @@ class Oracle:
     def prepare_bsk(self, bsk: np.ndarray):
         return _PreparedBsk(self, bsk)
 
-    # -- grouped key over 2^64: four GGSWs per pair of key bits; blind_rotate / pbs / pbs_batch take
-    # the prepared key like the one-bit key's
-    def gen_bsk_grouped(self, lwe_sk: np.ndarray, glwe_sk: np.ndarray, seed: bytes) -> np.ndarray:
-        count = lib().orc_bsk_grouped_count(C.byref(self._cp))
+    # -- grouped key over 2^64: 2^bits GGSWs per group of `bits` (2 or 3) key bits; blind_rotate / pbs /
+    # pbs_batch take the prepared key like the one-bit key's
+    def gen_bsk_grouped(self, lwe_sk: np.ndarray, glwe_sk: np.ndarray, seed: bytes, bits: int = 2) -> np.ndarray:
+        assert bits in (2, 3)
+        count = lib().orc_bsk_grouped_count_n(C.byref(self._cp), bits)
         bsk = np.zeros(count * self.ggsw_words(), dtype=np.uint64)
-        lib().orc_gen_bsk_grouped(self._ctx, lwe_sk, glwe_sk, Rng(seed, 8).ref, bsk)
+        lib().orc_gen_bsk_grouped_n(self._ctx, lwe_sk, glwe_sk, Rng(seed, 8 if bits == 2 else 10).ref, bits, bsk)
         return bsk
 
-    def prepare_bsk_grouped(self, bsk: np.ndarray):
-        return _PreparedBsk(self, bsk, grouped64=True)
+    def prepare_bsk_grouped(self, bsk: np.ndarray, bits: int = 2):
+        return _PreparedBsk(self, bsk, grouped64=True, bits=bits)
 
-    def group_step(self, ggsw4: np.ndarray, a0: int, a1: int, acc: np.ndarray) -> np.ndarray:
+    def group_step(self, ggsws: np.ndarray, exponents, acc: np.ndarray) -> np.ndarray:
+        """acc <- (sum over m of X^(sum of the exponents whose bit is set in m) GGSW_m) [.] acc over 2^64."""
         acc = np.array(acc, dtype=np.uint64, copy=True)
-        lib().orc_group_step(self._ctx, np.ascontiguousarray(ggsw4, dtype=np.uint64), a0, a1, acc)
+        a = np.array(exponents, dtype=np.uint32)
+        lib().orc_group_step_n(self._ctx, np.ascontiguousarray(ggsws, dtype=np.uint64), len(a), a, acc)
         return acc
 
     def blind_rotate(self, pbsk, lwe_small: np.ndarray, lut: np.ndarray) -> np.ndarray:
@@ -454,8 +461,8 @@ class _PreparedBsk:
         self._orc = orc
         prep = lib().orc_bsk_qp_prepare if prime else lib().orc_bsk_prepare
         if grouped64:
-            prep = lib().orc_bsk_grouped_prepare
-        if grouped:
+            self.h = lib().orc_bsk_grouped_prepare_n(orc._ctx, np.ascontiguousarray(bsk, dtype=np.uint64), bits)
+        elif grouped:
             self.h = lib().orc_bsk_qp_grouped_prepare_n(orc._ctx, np.ascontiguousarray(bsk, dtype=np.uint64), bits)
         else:
             self.h = prep(orc._ctx, np.ascontiguousarray(bsk, dtype=np.uint64))

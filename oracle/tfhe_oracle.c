@@ -704,78 +704,102 @@ void orc_bsk_prepared_free(orc_prepared_bsk* b) {
     free(b);
 }
 
-/* Grouped key over 2^64: the LWE key bits in pairs (s, s') = (s_2g, s_2g+1) (s' = 0 past the end
- * of an odd-length key); group g holds four GGSWs over the torus, of (1-s)(1-s'), s(1-s'), (1-s)s'
- * and s s'. */
-size_t orc_bsk_grouped_count(const orc_params* p) { return 4 * (((size_t)p->lwe_dim + 1) / 2); }
+/* Grouped key over 2^64: the LWE key bits `bits` at a time (2 or 3; bits past the end of the key count
+ * as 0); group g holds 2^bits GGSWs over the torus, GGSW m encrypting the product over the group's
+ * bits i of s_i (bit i of m set) or 1 - s_i: for pairs (1-s)(1-s'), s(1-s'), (1-s)s' and s s'. */
+size_t orc_bsk_grouped_count_n(const orc_params* p, uint32_t bits) {
+    return ((size_t)1 << bits) * (((size_t)p->lwe_dim + bits - 1) / bits);
+}
+size_t orc_bsk_grouped_count(const orc_params* p) { return orc_bsk_grouped_count_n(p, 2); }
 
-void orc_gen_bsk_grouped(const orc_ctx* c, const uint64_t* lwe_sk, const uint64_t* glwe_sk, orc_rng* r,
-                         uint64_t* bsk) {
+void orc_gen_bsk_grouped_n(const orc_ctx* c, const uint64_t* lwe_sk, const uint64_t* glwe_sk, orc_rng* r,
+                           uint32_t bits, uint64_t* bsk) {
     const orc_params* P = &c->prm;
     const u32 N = P->poly_size, k = P->glwe_dim;
     const size_t row_len = (size_t)(k + 1) * N;
-    const u32 groups = (P->lwe_dim + 1) / 2;
+    const u32 groups = (P->lwe_dim + bits - 1) / bits, terms = 1u << bits;
     u64* row = bsk;
-    for (u32 g = 0; g < groups; ++g) {
-        const u64 s0 = lwe_sk[2 * g], s1 = 2 * g + 1 < P->lwe_dim ? lwe_sk[2 * g + 1] : 0;
-        const u64 msg[4] = {(1 - s0) & (1 - s1), s0 & (1 - s1), (1 - s0) & s1, s0 & s1};
-        for (u32 m = 0; m < 4; ++m)
+    for (u32 g = 0; g < groups; ++g)
+        for (u32 m = 0; m < terms; ++m) {
+            u64 msg = 1;
+            for (u32 i = 0; i < bits; ++i) {
+                const u64 s = bits * g + i < P->lwe_dim ? lwe_sk[bits * g + i] : 0;
+                msg &= (m >> i & 1) ? s : 1 - s;
+            }
             for (u32 lv = 0; lv < P->pbs_level; ++lv)
                 for (u32 rr = 0; rr <= k; ++rr, row += row_len) {
                     orc_glwe_encrypt(c, glwe_sk, NULL, r, row);
-                    row[(size_t)rr * N] += msg[m] << (64 - P->pbs_base_log * (lv + 1));
+                    row[(size_t)rr * N] += msg << (64 - P->pbs_base_log * (lv + 1));
                 }
-    }
+        }
 }
 
-orc_prepared_bsk* orc_bsk_grouped_prepare(const orc_ctx* c, const uint64_t* bsk) {
+void orc_gen_bsk_grouped(const orc_ctx* c, const uint64_t* lwe_sk, const uint64_t* glwe_sk, orc_rng* r,
+                         uint64_t* bsk) {
+    orc_gen_bsk_grouped_n(c, lwe_sk, glwe_sk, r, 2, bsk);
+}
+
+orc_prepared_bsk* orc_bsk_grouped_prepare_n(const orc_ctx* c, const uint64_t* bsk, uint32_t bits) {
     const orc_params* P = &c->prm;
     const size_t polys = (size_t)P->pbs_level * (P->glwe_dim + 1) * (P->glwe_dim + 1);
-    const size_t count = orc_bsk_grouped_count(P);
+    const size_t count = orc_bsk_grouped_count_n(P, bits);
     orc_prepared_bsk* b = (orc_prepared_bsk*)malloc(sizeof *b);
     b->per_ggsw = polys * P->poly_size;
-    b->grouping = 2;
+    b->grouping = bits;
     b->raw = 1;
     b->hat = (u64*)malloc(sizeof(u64) * b->per_ggsw * count);
     memcpy(b->hat, bsk, sizeof(u64) * b->per_ggsw * count);
     return b;
 }
 
-/* One step with two mask elements over 2^64:  acc <- B [.] acc  with
- *     B = G0 + X^a G1 + X^a' G2 + X^(a+a') G3,
- * an encryption of X^(a s + a' s').  B is formed here in the coefficient domain with wrapping words
- * (only its value modulo 2^64 enters the result), then the ordinary external product runs over the
- * two 62-bit primes, whose product leaves no doubt about the lift. */
-void orc_group_step(const orc_ctx* c, const uint64_t* ggsw4, uint32_t a0, uint32_t a1, uint64_t* acc) {
+orc_prepared_bsk* orc_bsk_grouped_prepare(const orc_ctx* c, const uint64_t* bsk) {
+    return orc_bsk_grouped_prepare_n(c, bsk, 2);
+}
+
+/* One step with `bits` mask elements over 2^64:  acc <- B [.] acc  with
+ *     B = sum over m of X^(sum of the exponents a_i whose bit i is set in m) G_m
+ * (for pairs G0 + X^a G1 + X^a' G2 + X^(a+a') G3), an encryption of X^(sum a_i s_i).  B is formed here in
+ * the coefficient domain with wrapping words (only its value modulo 2^64 enters the result), then the
+ * ordinary external product runs over the two 62-bit primes, whose product leaves no doubt about the lift. */
+void orc_group_step_n(const orc_ctx* c, const uint64_t* ggsws, uint32_t bits, const uint32_t* a, uint64_t* acc) {
     const orc_params* P = &c->prm;
-    const u32 N = P->poly_size, k1 = P->glwe_dim + 1;
+    const u32 N = P->poly_size, k1 = P->glwe_dim + 1, terms = 1u << bits;
     const size_t polys = (size_t)P->pbs_level * k1 * k1, per = polys * N;
-    const u32 a[4] = {0, a0, a1, (a0 + a1) % (2 * N)};
     u64* B = (u64*)calloc(per + N + (size_t)k1 * N, sizeof(u64));
     u64 *rot = B + per, *out = rot + N;
-    for (u32 m = 0; m < 4; ++m)
+    for (u32 m = 0; m < terms; ++m) {
+        u32 e = 0;
+        for (u32 i = 0; i < bits; ++i)
+            if (m >> i & 1) e = (e + a[i]) % (2 * N);
         for (size_t q = 0; q < polys; ++q) {
-            orc_monomial_mul(rot, ggsw4 + (size_t)m * per + q * N, a[m], N);
+            orc_monomial_mul(rot, ggsws + (size_t)m * per + q * N, e, N);
             for (u32 j = 0; j < N; ++j) B[q * N + j] += rot[j];
         }
+    }
     orc_external_product(c, B, acc, out);
     memcpy(acc, out, sizeof(u64) * (size_t)k1 * N);
     free(B);
+}
+
+void orc_group_step(const orc_ctx* c, const uint64_t* ggsw4, uint32_t a0, uint32_t a1, uint64_t* acc) {
+    const u32 a[2] = {a0, a1};
+    orc_group_step_n(c, ggsw4, 2, a, acc);
 }
 
 static void blind_rotate_grouped(const orc_ctx* c, const orc_prepared_bsk* pb, const u64* lwe_small,
                                  const u64* lut, u64* acc) {
     const orc_params* P = &c->prm;
     const u32 N = P->poly_size, k1 = P->glwe_dim + 1, n = P->lwe_dim;
-    const u32 log2n = c->logN + 1, groups = (n + 1) / 2;
+    const u32 bits = pb->grouping, log2n = c->logN + 1, groups = (n + bits - 1) / bits;
     const u32 bt = orc_modswitch(lwe_small[n], log2n);
     for (u32 q = 0; q < k1; ++q)
         orc_monomial_mul(acc + (size_t)q * N, lut + (size_t)q * N, (2 * N - bt) % (2 * N), N);
     for (u32 g = 0; g < groups; ++g) {
-        const u32 a0 = orc_modswitch(lwe_small[2 * g], log2n);
-        const u32 a1 = 2 * g + 1 < n ? orc_modswitch(lwe_small[2 * g + 1], log2n) : 0;
-        /* every step runs, also the one whose exponents are both zero */
-        orc_group_step(c, pb->hat + (size_t)4 * g * pb->per_ggsw, a0, a1, acc);
+        u32 a[3] = {0, 0, 0};
+        for (u32 i = 0; i < bits; ++i)
+            if (bits * g + i < n) a[i] = orc_modswitch(lwe_small[bits * g + i], log2n);
+        /* every step runs, also the one whose exponents are all zero */
+        orc_group_step_n(c, pb->hat + ((size_t)g << bits) * pb->per_ggsw, bits, a, acc);
     }
 }
 

@@ -212,6 +212,13 @@ void orc_gen_bsk_grouped(const orc_ctx* c, const uint64_t* lwe_sk, const uint64_
                          uint64_t* bsk);
 orc_prepared_bsk* orc_bsk_grouped_prepare(const orc_ctx* c, const uint64_t* bsk);
 void orc_group_step(const orc_ctx* c, const uint64_t* ggsw4, uint32_t a0, uint32_t a1, uint64_t* acc);
+/* the same with `bits` (2 or 3) key bits per step: 2^bits GGSWs over the torus per group, ordered as in
+ * the grouped key over q' below; orc_group_step_n takes the `bits` exponents at a */
+size_t orc_bsk_grouped_count_n(const orc_params* p, uint32_t bits);
+void orc_gen_bsk_grouped_n(const orc_ctx* c, const uint64_t* lwe_sk, const uint64_t* glwe_sk, orc_rng* r,
+                           uint32_t bits, uint64_t* bsk);
+orc_prepared_bsk* orc_bsk_grouped_prepare_n(const orc_ctx* c, const uint64_t* bsk, uint32_t bits);
+void orc_group_step_n(const orc_ctx* c, const uint64_t* ggsws, uint32_t bits, const uint32_t* a, uint64_t* acc);
 
 size_t orc_bsk_qp_grouped_count(const orc_params* p);   /* GGSWs in the grouped key */
 void orc_gen_bsk_qp_grouped(const orc_ctx* c, const uint64_t* lwe_sk, const uint64_t* glwe_sk, orc_rng* r,

@@ -6,7 +6,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[1, 3, 4, 5], ids=["bsk_q64", "bsk_prime_grouped", "bsk_q64_grouped", "bsk_prime_grouped3"])
+@pytest.fixture(scope="module", params=[1, 3, 4, 5, 6], ids=["bsk_q64", "bsk_prime_grouped", "bsk_q64_grouped", "bsk_prime_grouped3", "bsk_q64_grouped3"])
 def ctx(request):
     from fhe_amd.native import Context
     c = Context(seed=bytes(range(32)), params_id=request.param)
@@ -67,7 +67,7 @@ def oracle_keys():
     return orc, lwe_sk, glwe_sk, bsk, ksk, comp_sk, pksk
 
 
-@pytest.mark.parametrize("flavour,params_id", [("q64", 1), ("prime", 2), ("grouped", 3), ("q64_grouped", 4), ("grouped3", 5)])
+@pytest.mark.parametrize("flavour,params_id", [("q64", 1), ("prime", 2), ("grouped", 3), ("q64_grouped", 4), ("grouped3", 5), ("q64_grouped3", 6)])
 def test_compression_bit_exact_against_the_oracle(oracle_keys, flavour, params_id):
     """Same keys on both sides (made by the oracle, imported raw): the compressed list is the
     oracle's byte for byte, and every decompressed block is the oracle's bootstrap of the extracted
@@ -80,8 +80,8 @@ def test_compression_bit_exact_against_the_oracle(oracle_keys, flavour, params_i
     dec = OC.Decompressor(flavour, comp_sk, glwe_sk, seed_bytes(42))
     if flavour == "q64":
         main_bsk = bsk
-    elif flavour == "q64_grouped":
-        main_bsk = orc.gen_bsk_grouped(lwe_sk, glwe_sk, seed_bytes(40))
+    elif flavour in ("q64_grouped", "q64_grouped3"):
+        main_bsk = orc.gen_bsk_grouped(lwe_sk, glwe_sk, seed_bytes(40), 3 if flavour == "q64_grouped3" else 2)
     elif flavour == "prime":
         main_bsk = orc.gen_bsk_qp(lwe_sk, glwe_sk, seed_bytes(40))
     else:

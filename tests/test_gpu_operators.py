@@ -19,8 +19,8 @@ GPU_OPS = {"add", "sub", "mul", "eq", "ne", "ge", "gt", "le", "lt", "min", "max"
 SPECIALISED = {"shl", "shr", "rotl", "rotr", "div", "rem"}
 
 
-@pytest.fixture(scope="module", params=[1, 2, 3, 4, 5],
-                ids=["bsk_q64", "bsk_prime", "bsk_prime_grouped", "bsk_q64_grouped", "bsk_prime_grouped3"])
+@pytest.fixture(scope="module", params=[1, 2, 3, 4, 5, 6],
+                ids=["bsk_q64", "bsk_prime", "bsk_prime_grouped", "bsk_q64_grouped", "bsk_prime_grouped3", "bsk_q64_grouped3"])
 def ctx(request):
     """Library-generated keys, once per ring modulus of the bootstrapping key."""
     from fhe_amd.native import Context

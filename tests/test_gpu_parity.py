@@ -15,18 +15,18 @@ N = 2048
 M64 = (1 << 64) - 1
 
 
-def _mk(n, ks_base_log=4, ks_level=4, seed=1, ms_zeros=0, grouped=False, factored=True):
+def _mk(n, ks_base_log=4, ks_level=4, seed=1, ms_zeros=0, grouped=False, factored=True, bits=2):
     """Oracle and library context over the same keys.  ms_zeros > 0 adds that many encryptions of
     zero and switches the modulus-switch noise reduction on in both.  grouped: the bootstrapping key
-    with four GGSWs over 2^64 per pair of key bits."""
+    with 2^bits GGSWs over 2^64 per group of `bits` key bits."""
     from fhe_amd.native import Context, Params, default_params
     op = OParams(lwe_dim=n, ks_base_log=ks_base_log, ks_level=ks_level)
     orc = Oracle(op)
     keys = orc.gen_keys(seed_bytes(seed))
     p = Params(**{k: getattr(op, k) for k in op.__dataclass_fields__})
     if grouped:
-        keys = (keys[0], keys[1], orc.gen_bsk_grouped(keys[0], keys[1], seed_bytes(seed)), keys[3])
-        p.bsk_grouping = 2
+        keys = (keys[0], keys[1], orc.gen_bsk_grouped(keys[0], keys[1], seed_bytes(seed), bits), keys[3])
+        p.bsk_grouping = bits
     zeros = None
     if ms_zeros:
         d = default_params()
@@ -560,23 +560,24 @@ def test_padding_bit_tables_full_parameters():
         ctx.close()
 
 
-@pytest.mark.parametrize("factored", [True, False], ids=["factored", "plain"])
-@pytest.mark.parametrize("n", [12, 13])
-def test_grouped_key_over_the_torus_bit_exact(n, factored):
-    """Two key bits per step, every modulus 2^64 (two-prime transform and lift per step, two
+@pytest.mark.parametrize("n,factored,bits", [(12, True, 2), (13, True, 2), (12, False, 2), (13, False, 2),
+                                              (12, True, 3), (13, True, 3), (14, True, 3)],
+                         ids=["12-factored", "13-factored", "12-plain", "13-plain", "12-triples", "13-triples", "14-triples"])
+def test_grouped_key_over_the_torus_bit_exact(n, factored, bits):
+    """Two or three key bits per step, every modulus 2^64 (two-prime transform and lift per step, two
     ciphertexts per workgroup): accumulators and bootstrapped ciphertexts equal the oracle's bit for
-    bit, for an even and an odd key length, odd and even batches, all-zero masks, masks whose pairs
-    cancel (a + a' = 2N) and accumulators whose digits are all extreme."""
+    bit, for key lengths with and without a ragged last group, odd and even batches, all-zero masks,
+    masks whose pairs cancel (a + a' = 2N) and accumulators whose digits are all extreme."""
     from fhe_amd.native import LfheError
-    orc, keys, ctx = _mk(n, seed=9, grouped=True, factored=factored)
+    orc, keys, ctx = _mk(n, seed=9, grouped=True, factored=factored, bits=bits)
     try:
         lwe_sk, glwe_sk, bskg, ksk = keys
-        pb = orc.prepare_bsk_grouped(bskg)
+        pb = orc.prepare_bsk_grouped(bskg, bits)
         r = Rng(seed_bytes(33))
         W = orc.ggsw_words()
         glwe = np.stack([r.u64s(2 * N) for _ in range(3)])
         glwe[2][:] = 1 << 63
-        gi = np.array([0, 5, 4 * ((n + 1) // 2) - 1], dtype=np.uint32)
+        gi = np.array([0, 5, (1 << bits) * ((n + bits - 1) // bits) - 1], dtype=np.uint32)
         if factored:    # the image holds (K2/K3, K1/K3, K3, K0 - K1 K2/K3) per group: its rows are no GGSWs
             with pytest.raises(LfheError):
                 ctx.external_product(gi, glwe)
@@ -607,14 +608,15 @@ def test_grouped_key_over_the_torus_bit_exact(n, factored):
         ctx.close()
 
 
-def test_grouped_key_over_the_torus_full_parameters():
+@pytest.mark.parametrize("bits", [2, 3], ids=["pairs", "triples"])
+def test_grouped_key_over_the_torus_full_parameters(bits):
     """n = 918, noise reduction on, grouped key over 2^64: outputs decrypt to f(m), a subsample is
     bit-identical to the oracle (the two 49-bit primes of the kernel against the two 62-bit primes of
     the oracle: the lift of every step stayed inside its window), noise far below half a message step."""
-    orc, keys, ctx = _mk(918, seed=10, ms_zeros=1449, grouped=True)
+    orc, keys, ctx = _mk(918, seed=10, ms_zeros=1449, grouped=True, bits=bits)
     try:
         lwe_sk, glwe_sk, bskg, ksk = keys
-        pb = orc.prepare_bsk_grouped(bskg)
+        pb = orc.prepare_bsk_grouped(bskg, bits)
         r = Rng(seed_bytes(34))
         f = [lambda x: x, lambda x: (x * x + 3) % 16]
         luts_o = [orc.make_lut(g) for g in f]
@@ -641,23 +643,23 @@ def test_grouped_key_over_the_torus_full_parameters():
         ctx.close()
 
 
-@pytest.mark.parametrize("factored", [True, False], ids=["factored", "plain"])
-def test_lift_guard_of_the_grouped_key_over_the_torus(factored):
+@pytest.mark.parametrize("factored,bits", [(True, 2), (False, 2), (True, 3)], ids=["factored", "plain", "triples"])
+def test_lift_guard_of_the_grouped_key_over_the_torus(factored, bits):
     """Every lift of the grouped key over 2^64 is checked against a guard band at the end of its window;
     a ciphertext that reaches the band is bootstrapped again, on the device, with the step taken apart
-    into four unconditionally exact products.  Never taken at the shipped band (130 standard
+    into its four (eight with three key bits per step) unconditionally exact products.  Never taken at the shipped band (130 standard
     deviations out); with the band forced down to the middle of the window every ciphertext takes the
     slow path -- and must come back with exactly the oracle's bits, like the fast path."""
     import os
-    orc, keys, ctx = _mk(13, seed=9, grouped=True, factored=factored)
+    orc, keys, ctx = _mk(13, seed=9, grouped=True, factored=factored, bits=bits)
     os.environ["LFHE_G64_GUARD_FRAC"] = "1e-4"
     try:
-        _, _, forced = _mk(13, seed=9, grouped=True, factored=factored)
+        _, _, forced = _mk(13, seed=9, grouped=True, factored=factored, bits=bits)
     finally:
         del os.environ["LFHE_G64_GUARD_FRAC"]
     try:
         lwe_sk, glwe_sk, bskg, ksk = keys
-        pb = orc.prepare_bsk_grouped(bskg)
+        pb = orc.prepare_bsk_grouped(bskg, bits)
         r = Rng(seed_bytes(35))
         f = [lambda x: x, lambda x: (5 * x + 2) % 16]
         luts_o = [orc.make_lut(g) for g in f]
@@ -684,7 +686,7 @@ def test_lift_guard_of_the_grouped_key_over_the_torus(factored):
         forced.close()
 
 
-@pytest.mark.parametrize("params_id", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("params_id", [1, 2, 3, 4, 5, 6])
 def test_library_keygen_round_trip(params_id):
     """Keys made by the library itself (both bootstrapping-key moduli): encrypt -> bootstrap ->
     decrypt, and the oracle decrypts library ciphertexts with the exported secret key."""
@@ -709,8 +711,8 @@ def test_library_keygen_round_trip(params_id):
         ctx.close()
 
 
-@pytest.mark.parametrize("params_id", [1, 2, 3, 4, 5],
-                         ids=["bsk_q64", "bsk_prime", "bsk_prime_grouped", "bsk_q64_grouped", "bsk_prime_grouped3"])
+@pytest.mark.parametrize("params_id", [1, 2, 3, 4, 5, 6],
+                         ids=["bsk_q64", "bsk_prime", "bsk_prime_grouped", "bsk_q64_grouped", "bsk_prime_grouped3", "bsk_q64_grouped3"])
 def test_full_size_batch_properties(params_id):
     """The benchmark's configuration (4096 blocks, 16 distinct tables) through size-independent
     properties: every output decrypts to f(m); a second pass gives the same bits (no dependence on
@@ -748,15 +750,15 @@ def test_full_size_batch_properties(params_id):
         # made (exported, handed to the oracle as raw words)
         from fhe_amd.native import KEY_SERVER
         words = np.frombuffer(ctx.export_keys(KEY_SERVER), dtype=np.uint8)
-        n_ggsw = {1: 918, 2: 918, 3: 1836, 4: 1836, 5: 2448}[params_id]
+        n_ggsw = {1: 918, 2: 918, 3: 1836, 4: 1836, 5: 2448, 6: 2448}[params_id]
         nb, nk, nz = n_ggsw * 4 * N, N * 4 * 919, 1449 * 919
         raw = np.frombuffer(words[-(nb + nk + nz) * 8:].tobytes(), dtype=np.uint64)
         bsk_raw, ksk_raw, zeros_raw = raw[:nb].copy(), raw[nb:nb + nk].copy(), raw[nb + nk:].reshape(1449, 919).copy()
         orc = Oracle()
         orc.set_ms(zeros_raw)
         prep = {1: orc.prepare_bsk, 2: orc.prepare_bsk_qp, 3: orc.prepare_bsk_qp_grouped, 4: orc.prepare_bsk_grouped,
-                5: lambda k: orc.prepare_bsk_qp_grouped(k, 3)}[params_id]
-        batch = orc.pbs_batch if params_id in (1, 4) else orc.pbs_batch_qp
+                5: lambda k: orc.prepare_bsk_qp_grouped(k, 3), 6: lambda k: orc.prepare_bsk_grouped(k, 3)}[params_id]
+        batch = orc.pbs_batch if params_id in (1, 4, 6) else orc.pbs_batch_qp
         pick = np.arange(0, B, 31)[:128]
         luts_o = np.stack([np.concatenate([np.zeros(N, dtype=np.uint64), l]) for l in luts])
         assert np.array_equal(out[pick], batch(ksk_raw, prep(bsk_raw), blocks[pick], luts_o, idx[pick], nthreads=16))

@@ -7,8 +7,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("params_id", [1, 2, 3, 4, 5],
-                         ids=["bsk_q64", "bsk_prime", "bsk_prime_grouped", "bsk_q64_grouped", "bsk_prime_grouped3"])
+@pytest.mark.parametrize("params_id", [1, 2, 3, 4, 5, 6],
+                         ids=["bsk_q64", "bsk_prime", "bsk_prime_grouped", "bsk_q64_grouped", "bsk_prime_grouped3", "bsk_q64_grouped3"])
 def test_attached_key_images_bootstrap_like_the_originals(params_id):
     import ctypes as C
     from fhe_amd.native import Context, KEY_CLIENT

@@ -307,17 +307,17 @@ def test_compression_oracle_round_trip():
     assert orc.decrypt_block(glwe_sk, out) == msgs[3]
 
 
-@pytest.mark.parametrize("n", [10, 11])
-def test_grouped_key_blind_rotation_over_the_torus(n):
-    """Two key bits per step with every modulus 2^64: the bootstrap evaluates the table; the
+@pytest.mark.parametrize("n,bits", [(10, 2), (11, 2), (10, 3), (11, 3), (12, 3)])
+def test_grouped_key_blind_rotation_over_the_torus(n, bits):
+    """Two or three key bits per step with every modulus 2^64: the bootstrap evaluates the table; the
     accumulator carries the same plaintext polynomial as the one-bit rotation's (glwe_phase differs by
-    noise only); one step equals the two one-bit steps it replaces up to noise."""
+    noise only); one step equals the one-bit steps it replaces up to noise."""
     orc = Oracle(Params(lwe_dim=n))
     lwe_sk, glwe_sk, bsk, ksk = orc.gen_keys(seed_bytes(31))
-    bskg = orc.gen_bsk_grouped(lwe_sk, glwe_sk, seed_bytes(31))
+    bskg = orc.gen_bsk_grouped(lwe_sk, glwe_sk, seed_bytes(31), bits)
     W = orc.ggsw_words()
-    assert bskg.size == 4 * ((n + 1) // 2) * W
-    pb, pb1 = orc.prepare_bsk_grouped(bskg), orc.prepare_bsk(bsk)
+    assert bskg.size == (1 << bits) * ((n + bits - 1) // bits) * W
+    pb, pb1 = orc.prepare_bsk_grouped(bskg, bits), orc.prepare_bsk(bsk)
     r = Rng(seed_bytes(32))
     f = lambda x: (7 * x + 2) % 16
     lut = orc.make_lut(f)
@@ -333,10 +333,12 @@ def test_grouped_key_blind_rotation_over_the_torus(n):
             a2, a1 = orc.blind_rotate(pb, small, lut), orc.blind_rotate(pb1, small, lut)
             assert close(orc.glwe_phase(glwe_sk, a2), orc.glwe_phase(glwe_sk, a1), 1 << 52)
             assert not np.array_equal(a2, a1)
-    # one grouped step against the two CMux steps of the same pair of key bits
+    # one grouped step against the CMux steps of the same key bits
     acc = orc.glwe_encrypt(glwe_sk, r.u64s(orc.N) & np.uint64(~((1 << 50) - 1) & (2**64 - 1)), r)
-    a0, a1 = 1234, 3071
-    two = orc.cmux_rotate(bsk[W:2 * W], a1, orc.cmux_rotate(bsk[:W], a0, acc))
-    one = orc.group_step(bskg[:4 * W], a0, a1, acc)
+    exps = [1234, 3071, 4095][:bits]
+    two = acc
+    for i, e in enumerate(exps):
+        two = orc.cmux_rotate(bsk[i * W:(i + 1) * W], e, two)
+    one = orc.group_step(bskg[:(1 << bits) * W], exps, acc)
     assert close(orc.glwe_phase(glwe_sk, one), orc.glwe_phase(glwe_sk, two), 1 << 48)
 

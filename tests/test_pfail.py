@@ -20,6 +20,7 @@ DOCUMENTED = {
     "grouped": (1.38, -129.2),
     "q64_grouped": (1.38, -129.1),
     "grouped3": (1.46, -128.9),
+    "q64_grouped3": (1.43, -129.1),
 }
 
 

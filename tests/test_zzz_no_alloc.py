@@ -20,8 +20,8 @@ def _blocks(ctx, count, salt):
                            for v in vals])[:count]
 
 
-@pytest.mark.parametrize("params_id", [5, 3, 1, 2, 4],
-                         ids=["bsk_prime_grouped3", "bsk_prime_grouped", "bsk_q64", "bsk_prime", "bsk_q64_grouped"])
+@pytest.mark.parametrize("params_id", [5, 3, 1, 2, 4, 6],
+                         ids=["bsk_prime_grouped3", "bsk_prime_grouped", "bsk_q64", "bsk_prime", "bsk_q64_grouped", "bsk_q64_grouped3"])
 def test_no_alloc_entry_point_matches_the_allocating_one(params_id):
     import torch
     from fhe_amd.native import Context, LfheError

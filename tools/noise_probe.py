@@ -27,7 +27,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-FLAVOURS = (("q64", 1), ("prime", 2), ("grouped", 3), ("q64_grouped", 4), ("grouped3", 5))
+FLAVOURS = (("q64", 1), ("prime", 2), ("grouped", 3), ("q64_grouped", 4), ("grouped3", 5), ("q64_grouped3", 6))
 CHUNK = 16384
 KEEP = 32768      # candidate records kept per key
 
