@@ -196,6 +196,7 @@ static napi_value js_create(napi_env env, napi_callback_info info) {
         return throw_msg(env, buf);
     }
     lfhe_ctx** slot = (lfhe_ctx**)malloc(sizeof *slot);
+    if (!slot) { p_lfhe_ctx_destroy(c); return throw_msg(env, "out of memory"); }
     *slot = c;
     napi_value ext;
     napi_create_external(env, slot, finalize_ctx, NULL, &ext);
@@ -246,6 +247,7 @@ static napi_value blob_out(napi_env env, lfhe_ctx* c, blob_fn fn, uint32_t which
     int32_t rc = fn(c, which, NULL, &n);
     if (rc != LFHE_OK) return fail(env, c, rc, what);
     uint8_t* tmp = (uint8_t*)malloc(n ? n : 1);
+    if (!tmp) return throw_msg(env, "out of memory");
     rc = fn(c, which, tmp, &n);
     napi_value out = rc == LFHE_OK ? make_buffer(env, tmp, n) : fail(env, c, rc, what);
     free(tmp);
@@ -304,6 +306,7 @@ static napi_value js_encrypt(napi_env env, napi_callback_info info) {
     int32_t rc = p_lfhe_ciphertext_size(c, bits, &n);
     if (rc != LFHE_OK) return throw_msg(env, "Encryption failed: unsupported bit width");
     uint8_t* tmp = (uint8_t*)malloc(n);
+    if (!tmp) return throw_msg(env, "out of memory");
     rc = mode ? p_lfhe_trivial_encrypt(c, v, bits, tmp, &n) : p_lfhe_encrypt(c, v, bits, tmp, &n);
     napi_value out = rc == LFHE_OK ? make_buffer(env, tmp, n) : fail(env, c, rc, "Encryption");
     free(tmp);
@@ -324,6 +327,7 @@ static napi_value js_encrypt_public(napi_env env, napi_callback_info info) {
     uint64_t n = 0;
     if (p_lfhe_ciphertext_size(c, bits, &n) != LFHE_OK) return throw_msg(env, "Encryption failed: unsupported bit width");
     uint8_t* tmp = (uint8_t*)malloc(n);
+    if (!tmp) return throw_msg(env, "out of memory");
     const int32_t rc = p_lfhe_encrypt_public(c, pk, pl, v, bits, tmp, &n);
     napi_value out = rc == LFHE_OK ? make_buffer(env, tmp, n) : fail(env, c, rc, "Encryption");
     free(tmp);
@@ -382,6 +386,7 @@ static napi_value js_evaluate(napi_env env, napi_callback_info info) {
     int32_t rc = p_lfhe_evaluate(c, op, bits, l, ll, r, rl, scalar, cd, cl, NULL, &n);
     if (rc != LFHE_OK) return fail(env, c, rc, "Evaluation");
     uint8_t* tmp = (uint8_t*)malloc(n);
+    if (!tmp) return throw_msg(env, "out of memory");
     rc = p_lfhe_evaluate(c, op, bits, l, ll, r, rl, scalar, cd, cl, tmp, &n);
     napi_value out = rc == LFHE_OK ? make_buffer(env, tmp, n) : fail(env, c, rc, "Evaluation");
     free(tmp);
@@ -413,6 +418,7 @@ static napi_value js_evaluate_batch(napi_env env, napi_callback_info info) {
     if (ll != (size_t)count * in_sz || (r && rl != (size_t)count * (scalar ? 32 : rhs_sz)) || (cd && cl != (size_t)count * cond_sz))
         return throw_msg(env, "operand arrays do not hold `count` ciphertexts of the stated width");
     uint8_t* tmp = (uint8_t*)malloc((size_t)count * out_sz + 1);
+    if (!tmp) return throw_msg(env, "out of memory");
     const int32_t rc = p_lfhe_evaluate_batch(c, op, bits, count, l, r, scalar, cd, tmp);
     napi_value out = rc == LFHE_OK ? make_buffer(env, tmp, (size_t)count * out_sz) : fail(env, c, rc, "Evaluation");
     free(tmp);
@@ -695,6 +701,7 @@ static napi_value js_rand(napi_env env, napi_callback_info info) {
     uint64_t n = 0;
     if (p_lfhe_ciphertext_size(c, bits, &n) != LFHE_OK) return throw_msg(env, "unsupported bit width");
     uint8_t* tmp = (uint8_t*)malloc(n);
+    if (!tmp) return throw_msg(env, "out of memory");
     const int32_t rc = p_lfhe_rand(c, bits, seed, rbits, tmp, &n);
     napi_value out = rc == LFHE_OK ? make_buffer(env, tmp, n) : fail(env, c, rc, "lfhe_rand");
     free(tmp);
@@ -751,6 +758,7 @@ static napi_value js_cast_from_pke(napi_env env, napi_callback_info info) {
     if (!get_bytes(env, argv[1], &ct, &n)) return NULL;
     uint64_t on = n;
     uint8_t* tmp = (uint8_t*)malloc(n ? n : 1);
+    if (!tmp) return throw_msg(env, "out of memory");
     const int32_t rc = p_lfhe_cast_from_pke(c, ct, n, tmp, &on);
     napi_value out = rc == LFHE_OK ? make_buffer(env, tmp, on) : fail(env, c, rc, "lfhe_cast_from_pke");
     free(tmp);
@@ -809,6 +817,7 @@ static napi_value blob_call(napi_env env, napi_callback_info info, recode_fn fn,
     int32_t rc = fn(c, in, n, NULL, &on);
     if (rc != LFHE_OK) return fail(env, c, rc, what);
     uint8_t* tmp = (uint8_t*)malloc(on ? on : 1);
+    if (!tmp) return throw_msg(env, "out of memory");
     rc = fn(c, in, n, tmp, &on);
     napi_value out = rc == LFHE_OK ? make_buffer(env, tmp, on) : fail(env, c, rc, what);
     free(tmp);
