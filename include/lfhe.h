@@ -283,7 +283,8 @@ int32_t lfhe_evaluate_fused(lfhe_ctx* ctx, const lfhe_step* steps, uint32_t nste
  * lfhe_evaluate_batch_handles: lfhe_evaluate_batch with every ciphertext operand given as a handle
  * (arrays of n x 32 bytes; a clear right operand stays n x 32 bytes of values) and the results
  * entered under out_handles; an unknown handle or a stored width that does not match is LFHE_ERR_ARG
- * and nothing is stored.  lfhe_evaluate_fused_handles: the same for lfhe_evaluate_fused
+ * and nothing is stored (a batch too large for one arena of device memory runs in parts, lfhe_arena_chunk
+ * instances at a time, and a failure in a later part leaves the results of the parts before it stored).  lfhe_evaluate_fused_handles: the same for lfhe_evaluate_fused
  * (input_handles[i] / out_handles[o]: n handles each).  Results are bit-identical to the host-buffer
  * entry points. */
 int32_t lfhe_store_put(lfhe_ctx* ctx, const uint8_t handle[32], const uint8_t* ct, uint64_t ct_len);

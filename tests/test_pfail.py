@@ -11,7 +11,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-# what include/lfhe.h, INTEGRATION.md and DESIGN.md state per flavour: variance of a bootstrap's output
+# what include/lfhe.h and the project's documentation state per flavour: variance of a bootstrap's output
 # relative to the one-bit key over 2^64, and log2 p_fail of a candidate the noise reduction accepts
 # at its bound (the worst case it lets through) at noise level 5
 DOCUMENTED = {
