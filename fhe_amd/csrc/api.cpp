@@ -194,6 +194,7 @@ int32_t lfhe_health(lfhe_ctx* ctx, char* out, uint64_t* out_len) {
 
 // ---- keys --------------------------------------------------------------------------------------
 static void upload_server_keys(lfhe_ctx* c) {
+    c->have_server = false;
     c->eng->load_bsk(c->bsk.data());
     c->eng->load_ksk(c->ksk.data(), c->ms_zeros.empty() ? nullptr : c->ms_zeros.data());
     c->have_server = true;

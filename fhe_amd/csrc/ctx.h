@@ -47,7 +47,8 @@ int32_t guarded(lfhe_ctx* ctx, F&& fn) {
         return LFHE_ERR_STATE;
     } catch (const std::exception& e) {
         ctx->err = e.what();
-        return LFHE_ERR_DEVICE;
+        // "unsupported ...": something this library does not do (a key without a device image), not a device fault
+        return ctx->err.compare(0, 11, "unsupported") == 0 ? LFHE_ERR_UNSUPPORTED : LFHE_ERR_DEVICE;
     }
 }
 }  // namespace lfhe

@@ -133,7 +133,14 @@ void Engine::load_bsk(const u64* host_bsk) {
         HC(hipMalloc(&d_bsk_, bsk_dev_bytes()));
         own_keys_ = true;
     }
-    bsk_factored_ = build_bsk_image(host_bsk, bsk_ggsw_count(), d_bsk_);
+    try {
+        bsk_factored_ = build_bsk_image(host_bsk, bsk_ggsw_count(), d_bsk_);
+    } catch (...) {
+        // a refused key leaves a half-written image behind: the engine is without keys until the next load
+        (void)hipFree(d_bsk_);
+        d_bsk_ = nullptr;
+        throw;
+    }
     publish_key_flags();
 }
 
@@ -231,7 +238,13 @@ void Engine::load_compression_keys(const CompShape& shape, const u64* host_pksk,
     HC(hipFree(d_raw));
     const size_t row = single_modulus() ? BSKQ_ROW : BSK_ROW;
     if (!d_decomp_bsk_) HC(hipMalloc(&d_decomp_bsk_, decomp_bsk_ggsw_count() * row * sizeof(double)));
-    decomp_factored_ = build_bsk_image(host_decomp_bsk, decomp_bsk_ggsw_count(), d_decomp_bsk_);
+    try {
+        decomp_factored_ = build_bsk_image(host_decomp_bsk, decomp_bsk_ggsw_count(), d_decomp_bsk_);
+    } catch (...) {
+        (void)hipFree(d_decomp_bsk_);      // as in load_bsk: no compression keys until the next load
+        d_decomp_bsk_ = nullptr;
+        throw;
+    }
 }
 
 void Engine::compress(const u64* blocks, size_t count, uint16_t* out, u64 scale) {

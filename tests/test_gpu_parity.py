@@ -467,6 +467,40 @@ def test_grouped_key_with_a_non_invertible_word_keeps_the_plain_image():
         ctx.close()
 
 
+@pytest.mark.parametrize("modulus", ["prime", "q64"])
+def test_three_bit_key_with_a_non_invertible_word_is_refused(modulus):
+    """Three key bits per step exist only with the factored image: a key in which a word of the fourth or
+    eighth GGSW of a group has no inverse (here: a whole GGSW of zeros) is refused at load with
+    LFHE_ERR_UNSUPPORTED, and the context goes on working with a good key afterwards."""
+    from fhe_amd.native import LfheError
+    if modulus == "prime":
+        orc, keys, ctx = _mk_prime(12, seed=11, grouped=True, bits=3)
+    else:
+        orc, keys, ctx = _mk(12, seed=11, grouped=True, bits=3)
+    try:
+        lwe_sk, glwe_sk, bskg, ksk = keys
+        W = orc.ggsw_words()
+        for which in (3, 15):                        # K3 of the first group, K7 of the second
+            broken = bskg.copy()
+            broken[which * W:(which + 1) * W] = 0
+            with pytest.raises(LfheError) as e:
+                ctx.import_server_keys_raw(broken, ksk, None)
+            assert "LFHE_ERR_UNSUPPORTED" in str(e.value) and "another key" in str(e.value)
+            with pytest.raises(LfheError):           # the refused key left the context without server keys
+                ctx.blind_rotate(np.zeros((1, orc.n + 1), dtype=np.uint64), ctx.make_lut(lambda x: x)[None], None)
+        ctx.import_server_keys_raw(bskg, ksk, None)
+        pb = orc.prepare_bsk_qp_grouped(bskg, 3) if modulus == "prime" else orc.prepare_bsk_grouped(bskg, 3)
+        rotate = orc.blind_rotate_qp if modulus == "prime" else orc.blind_rotate
+        r = Rng(seed_bytes(36))
+        lut_o, lut_g = orc.make_lut(lambda x: (5 * x + 2) % 16), ctx.make_lut(lambda x: (5 * x + 2) % 16)
+        smalls = np.stack([r.u64s(orc.n + 1) for _ in range(3)])
+        got = ctx.blind_rotate(smalls, lut_g[None], None)
+        for c in range(3):
+            assert np.array_equal(got[c].reshape(-1), rotate(pb, smalls[c], lut_o)), c
+    finally:
+        ctx.close()
+
+
 def test_grouped_key_pbs_full_parameters():
     """n = 918, noise reduction on, grouped key: outputs decrypt to f(m), a subsample is
     bit-identical to the oracle, the output noise stays far below half a message step."""

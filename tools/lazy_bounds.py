@@ -115,6 +115,11 @@ def check_header(path):
     m = prod(0.5)
     Bf = prod(prod2(m + NORM, m + NORM)) + NORM
     assert Bf < 1.1 and Bf < B and 2 * prod2(Bf, f[-1]) * 2 < LIMIT
+    # three key bits per step: B = A0 + m3 A1 with both halves factored; A1 = d1 (m1 + a1)(m2 + b1) + c1 meets
+    # m3 un-normalised, A0 = d0 (m1 + a0)(m2 + b0) + c0 is added as it is -- still below the plain pairs' entry
+    half = prod2(m + NORM, m + NORM)
+    B3 = (prod(half) + NORM) + prod2(prod(half) + NORM, m)
+    assert B3 < 1.8 and B3 < B
     return max(w, wg), max(x), n
 
 
