@@ -499,6 +499,9 @@ static size_t launch_chunk(size_t count, size_t ops, size_t slots) {
 int Engine::pair_threshold(size_t count) const {
     if (pair_above_ != -2) return pair_above_;   // forced by LFHE_PAIR_ABOVE (-1: never)
     const size_t cu = (size_t)cu_count_;
+    // three key bits per step (ms, one / two per workgroup): 512: 5.45 / 5.24, 640: 7.96 / 9.04, 768: 8.18 / 9.06,
+    // 896: 10.51 / 9.33, 1024: 10.69 / 9.68 -- one per workgroup only between two and three and a quarter per CU
+    if (prm_.bsk_grouping == 3) return (count <= 2 * cu || 4 * count > 13 * cu) ? 0 : -1;
     return (count <= 2 * cu || 2 * count > 7 * cu) ? 0 : -1;
 }
 
