@@ -61,6 +61,12 @@ export class NativeEngine {
   castFromPke(ciphertext: Bytes): Buffer;
   /** words: mask (2048) then one body word per list ciphertext; packed defaults to true */
   expandCompactList(words: BigUint64Array, widths: BitWidth[], packed?: boolean): Buffer[];
+  /** Ciphertexts resident on the GPU under 32-byte handles; results of evaluateBatchHandles stay there. */
+  storePut(handle: Bytes, ciphertext: Bytes): void;
+  storeGet(handle: Bytes): Buffer;
+  storeDrop(handle: Bytes): void;
+  storeStat(handle?: Bytes | null): { entries: number; deviceBytes: number; bitWidth: number };
+  evaluateBatchHandles(op: Operator, bitWidth: BitWidth, leftHandles: Bytes[], rights: Array<Bytes | ClearValue> | null, condHandles: Bytes[] | null, outHandles: Bytes[]): void;
   compressionKeygen(): void;
   compress(ciphertexts: Bytes[]): Buffer;
   decompress(blob: Bytes): Buffer;

@@ -168,6 +168,28 @@ class NativeEngine {
     return out;
   }
 
+  // ---- ciphertexts resident on the GPU under 32-byte handles (the executor events' bytes32 handles):
+  // operands and results of a chain of operations stay in device memory, only storePut / storeGet cross PCIe
+  storePut(handle, ciphertext) { native.storePut(this.handle, Buffer.from(handle), Buffer.from(ciphertext)); }
+  storeGet(handle) { return native.storeGet(this.handle, Buffer.from(handle)); }
+  storeDrop(handle) { native.storeDrop(this.handle, Buffer.from(handle)); }
+  /** { entries, deviceBytes, bitWidth } -- bitWidth of `handle` (0: no such entry) when one is given. */
+  storeStat(handle) { return native.storeStat(this.handle, handle ? Buffer.from(handle) : null); }
+
+  /** evaluateBatch on stored ciphertexts: arrays of 32-byte handles in (rights: handles or clear values), results entered under outHandles. */
+  evaluateBatchHandles(op, bitWidth, leftHandles, rights, condHandles, outHandles) {
+    const code = native.opFromName(op);
+    if (code < 0) throw new Error(`unknown operation ${op}`);
+    const n = leftHandles.length;
+    if (n === 0) return;
+    if (outHandles.length !== n) throw new RangeError('one result handle per instance');
+    const scalar = rights && rights.length && (typeof rights[0] !== 'object');
+    const cat = (hs) => Buffer.concat(hs.map((h) => Buffer.from(h)));
+    native.evaluateBatchHandles(this.handle, code, bitWidth, n, cat(leftHandles),
+      rights ? Buffer.concat(rights.map((r) => (scalar ? toLE32(r) : Buffer.from(r)))) : null, !!scalar,
+      condHandles ? cat(condHandles) : null, cat(outHandles));
+  }
+
   /** Oblivious pseudo-random ciphertext (FheRand / FheRandBounded): uniform below 2^randomBits. */
   rand(bitWidth, seed16, randomBits) {
     return native.rand(this.handle, bitWidth, Buffer.from(seed16), randomBits || bitWidth);

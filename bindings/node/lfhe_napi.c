@@ -63,6 +63,12 @@ FN(int32_t, lfhe_expand_compact_list, (lfhe_ctx*, const uint64_t*, const uint64_
 FN(int32_t, lfhe_compression_keygen, (lfhe_ctx*))
 FN(int32_t, lfhe_compress, (lfhe_ctx*, const uint8_t*, uint64_t, uint8_t*, uint64_t*))
 FN(int32_t, lfhe_decompress, (lfhe_ctx*, const uint8_t*, uint64_t, uint8_t*, uint64_t*))
+FN(int32_t, lfhe_store_put, (lfhe_ctx*, const uint8_t*, const uint8_t*, uint64_t))
+FN(int32_t, lfhe_store_get, (lfhe_ctx*, const uint8_t*, uint8_t*, uint64_t*))
+FN(int32_t, lfhe_store_drop, (lfhe_ctx*, const uint8_t*))
+FN(int32_t, lfhe_store_stat, (const lfhe_ctx*, const uint8_t*, uint64_t*, uint64_t*, uint32_t*))
+FN(int32_t, lfhe_evaluate_batch_handles, (lfhe_ctx*, uint32_t, uint32_t, uint64_t, const uint8_t*, const uint8_t*, int32_t,
+                                          const uint8_t*, const uint8_t*))
 #undef FN
 
 static napi_value throw_msg(napi_env env, const char* msg) {
@@ -92,6 +98,7 @@ static int resolve_all(napi_env env, const char* path) {
     GET(lfhe_op_from_name) GET(lfhe_evaluate) GET(lfhe_evaluate_batch) GET(lfhe_pbs_count)
     GET(lfhe_rand) GET(lfhe_keygen_server) GET(lfhe_client_keys_import_raw) GET(lfhe_pke_key_set) GET(lfhe_cast_from_pke)
     GET(lfhe_compression_keygen) GET(lfhe_compress) GET(lfhe_decompress) GET(lfhe_expand_compact_list)
+    GET(lfhe_store_put) GET(lfhe_store_get) GET(lfhe_store_drop) GET(lfhe_store_stat) GET(lfhe_evaluate_batch_handles)
 #undef GET
     return 1;
 }
@@ -845,6 +852,117 @@ static napi_value js_pbs_count(napi_env env, napi_callback_info info) {
     return v;
 }
 
+/* ---- ciphertexts resident on the GPU, addressed by 32-byte handles (the executor events' bytes32) ---- */
+static int get_handle(napi_env env, napi_value v, const uint8_t** h) {
+    size_t n = 0;
+    if (!get_bytes(env, v, h, &n)) return 0;
+    if (!*h || n != 32) { throw_msg(env, "a handle is 32 bytes"); return 0; }
+    return 1;
+}
+
+/* storePut(ctx, handle, ciphertext) */
+static napi_value js_store_put(napi_env env, napi_callback_info info) {
+    NEED_LIB();
+    napi_value argv[3];
+    if (!get_args(env, info, 3, argv)) return NULL;
+    lfhe_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return NULL;
+    const uint8_t *h, *ct; size_t n;
+    if (!get_handle(env, argv[1], &h) || !get_bytes(env, argv[2], &ct, &n)) return NULL;
+    const int32_t rc = p_lfhe_store_put(c, h, ct, n);
+    if (rc != LFHE_OK) return fail(env, c, rc, "lfhe_store_put");
+    napi_value u;
+    napi_get_undefined(env, &u);
+    return u;
+}
+
+/* storeGet(ctx, handle) -> Buffer */
+static napi_value js_store_get(napi_env env, napi_callback_info info) {
+    NEED_LIB();
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return NULL;
+    lfhe_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return NULL;
+    const uint8_t* h;
+    if (!get_handle(env, argv[1], &h)) return NULL;
+    uint64_t n = 0;
+    int32_t rc = p_lfhe_store_get(c, h, NULL, &n);
+    if (rc != LFHE_OK) return fail(env, c, rc, "lfhe_store_get");
+    uint8_t* tmp = (uint8_t*)malloc(n ? n : 1);
+    if (!tmp) return throw_msg(env, "out of memory");
+    rc = p_lfhe_store_get(c, h, tmp, &n);
+    napi_value out = rc == LFHE_OK ? make_buffer(env, tmp, n) : fail(env, c, rc, "lfhe_store_get");
+    free(tmp);
+    return out;
+}
+
+/* storeDrop(ctx, handle) */
+static napi_value js_store_drop(napi_env env, napi_callback_info info) {
+    NEED_LIB();
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return NULL;
+    lfhe_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return NULL;
+    const uint8_t* h;
+    if (!get_handle(env, argv[1], &h)) return NULL;
+    const int32_t rc = p_lfhe_store_drop(c, h);
+    if (rc != LFHE_OK) return fail(env, c, rc, "lfhe_store_drop");
+    napi_value u;
+    napi_get_undefined(env, &u);
+    return u;
+}
+
+/* storeStat(ctx, handle|null) -> { entries, deviceBytes, bitWidth (0: no such handle) } */
+static napi_value js_store_stat(napi_env env, napi_callback_info info) {
+    NEED_LIB();
+    napi_value argv[2];
+    if (!get_args(env, info, 2, argv)) return NULL;
+    lfhe_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return NULL;
+    const uint8_t* h = NULL; size_t hn = 0;
+    if (!get_bytes(env, argv[1], &h, &hn)) return NULL;
+    if (h && hn != 32) return throw_msg(env, "a handle is 32 bytes");
+    uint64_t entries = 0, bytes = 0;
+    uint32_t width = 0;
+    const int32_t rc = p_lfhe_store_stat(c, h, &entries, &bytes, &width);
+    if (rc != LFHE_OK && !(h && rc == LFHE_ERR_ARG)) return fail(env, c, rc, "lfhe_store_stat");
+    if (rc != LFHE_OK) width = 0;
+    napi_value o, v;
+    napi_create_object(env, &o);
+    napi_create_double(env, (double)entries, &v); napi_set_named_property(env, o, "entries", v);
+    napi_create_double(env, (double)bytes, &v); napi_set_named_property(env, o, "deviceBytes", v);
+    napi_create_uint32(env, width, &v); napi_set_named_property(env, o, "bitWidth", v);
+    return o;
+}
+
+/* evaluateBatchHandles(ctx, op, bits, count, lhsHandles, rhs|null, rhsIsScalar, condHandles|null, outHandles):
+ * count x 32 bytes each (a clear right operand: count x 32 bytes of little-endian values); results stay on the GPU */
+static napi_value js_evaluate_batch_handles(napi_env env, napi_callback_info info) {
+    NEED_LIB();
+    napi_value argv[9];
+    if (!get_args(env, info, 9, argv)) return NULL;
+    lfhe_ctx* c = get_ctx(env, argv[0]);
+    if (!c) return NULL;
+    uint32_t op, bits, count;
+    napi_get_value_uint32(env, argv[1], &op);
+    napi_get_value_uint32(env, argv[2], &bits);
+    napi_get_value_uint32(env, argv[3], &count);
+    const uint8_t *l, *r, *cd, *o; size_t ll, rl, cl, ol;
+    if (!get_bytes(env, argv[4], &l, &ll) || !get_bytes(env, argv[5], &r, &rl) || !get_bytes(env, argv[7], &cd, &cl) ||
+        !get_bytes(env, argv[8], &o, &ol))
+        return NULL;
+    bool scalar = false;
+    napi_get_value_bool(env, argv[6], &scalar);
+    const size_t want = (size_t)count * 32;
+    if (ll != want || ol != want || (r && rl != want) || (cd && cl != want))
+        return throw_msg(env, "handle arrays hold `count` entries of 32 bytes each");
+    const int32_t rc = p_lfhe_evaluate_batch_handles(c, op, bits, count, l, r, scalar, cd, o);
+    if (rc != LFHE_OK) return fail(env, c, rc, "Evaluation");
+    napi_value u;
+    napi_get_undefined(env, &u);
+    return u;
+}
+
 /* Every synchronous export enters the library under the same mutex as the async workers. */
 typedef struct { const char* name; napi_callback fn; int locked; } export_entry;
 
@@ -870,7 +988,9 @@ static napi_value init(napi_env env, napi_value exports) {
         {"rand", js_rand, 1}, {"importClientKeys", js_import_client, 1}, {"keygenServer", js_keygen_server, 1},
         {"setPkeKey", js_set_pke_key, 1}, {"castFromPke", js_cast_from_pke, 1},
         {"compressionKeygen", js_compression_keygen, 1}, {"compress", js_compress, 1}, {"decompress", js_decompress, 1},
-        {"expandCompactList", js_expand_compact_list, 1}};
+        {"expandCompactList", js_expand_compact_list, 1}, {"storePut", js_store_put, 1}, {"storeGet", js_store_get, 1},
+        {"storeDrop", js_store_drop, 1}, {"storeStat", js_store_stat, 1},
+        {"evaluateBatchHandles", js_evaluate_batch_handles, 1}};
     for (size_t i = 0; i < sizeof tab / sizeof tab[0]; ++i) {
         napi_value f;
         if (tab[i].locked) napi_create_function(env, tab[i].name, NAPI_AUTO_LENGTH, locked_call, (void*)&tab[i], &f);

@@ -53,6 +53,22 @@ const { LuxFHEClient, NativeEngine } = require('./index.js');
   // a failing request rejects its own promise only
   const mixed = await Promise.all([sdk.evaluate('add', a, b, 8), sdk.evaluate('add', a, Buffer.alloc(a.length), 8).then(() => 'resolved', () => 'rejected')]);
   res.mixed = [String(await sdk.decrypt(mixed[0])), mixed[1]];
+  // ciphertexts resident on the GPU under bytes32 handles (the executor events' way,
+  // tests/fhevm-suite/e2e/test/utils.ts:182-214): a chain le -> select -> sub stays on the device
+  const H = (k) => Buffer.alloc(32, k);
+  engine.storePut(H(1), a);
+  engine.storePut(H(2), b);
+  engine.evaluateBatchHandles('le', 8, [H(2)], [H(1)], null, [H(3)]);            // 17 <= 42
+  engine.evaluateBatchHandles('select', 8, [H(2)], [H(1)], [H(3)], [H(4)]);       // true ? 17 : 42
+  engine.evaluateBatchHandles('sub', 8, [H(1)], [H(4)], null, [H(5)]);            // 42 - 17
+  engine.evaluateBatchHandles('add', 8, [H(5)], [100], null, [H(5)]);             // clear operand, result replaces its operand
+  const stat = engine.storeStat(H(5));
+  res.store = { chain: String(engine.decrypt(engine.storeGet(H(5)))), cond: String(engine.decrypt(engine.storeGet(H(3)))),
+    entries: stat.entries, bitWidth: stat.bitWidth, condWidth: engine.storeStat(H(3)).bitWidth };
+  engine.storeDrop(H(4));
+  res.store.afterDrop = engine.storeStat(null).entries;
+  res.store.dropped = engine.storeStat(H(4)).bitWidth;
+  try { engine.evaluateBatchHandles('add', 8, [H(4)], [H(1)], null, [H(6)]); res.store.unknown = 'accepted'; } catch (e) { res.store.unknown = 'rejected'; }
   // compression for storage: both operands into one blob and back
   engine.compressionKeygen();
   const blob = engine.compress([a, b]);
@@ -80,6 +96,8 @@ const { LuxFHEClient, NativeEngine } = require('./index.js');
     res.concurrent.ok && res.concurrent.all_ms < 2 * res.concurrent.single_ms && res.concurrent.ticks > 2 &&
     res.concurrentMul.ok && res.concurrentMul.all_ms < 13 * res.concurrentMul.single_ms &&
     res.mixed[0] === '59' && res.mixed[1] === 'rejected' &&
+    res.store.chain === '125' && res.store.cond === '1' && res.store.entries === 5 && res.store.bitWidth === 8 &&
+    res.store.condWidth === 1 && res.store.afterDrop === 4 && res.store.dropped === 0 && res.store.unknown === 'rejected' &&
     res.restored[0] === '42' && res.restored[1] === '17' && back.length === a.length + b.length && blob.length < a.length / 8;
   engine.close();
   process.exit(ok ? 0 : 1);

@@ -26,7 +26,8 @@ def test_addon_loads_and_exports_the_engine_calls():
     assert out.returncode == 0, out.stderr
     d = json.loads(out.stdout)
     for fn in ("open", "createContext", "keygen", "publicKey", "encrypt", "decrypt", "evaluate", "evaluateBatch", "evaluateAsync",
-               "compressionKeygen", "compress", "decompress"):
+               "compressionKeygen", "compress", "decompress", "storePut", "storeGet", "storeDrop", "storeStat",
+               "evaluateBatchHandles"):
         assert fn in d["fns"]
     # the reference SDK's method names (packages/luxfhejs/src/index.ts:56-122)
     for m in ("initialize", "getPublicKey", "encrypt_uint8", "encrypt_uint16", "encrypt_uint32", "encrypt_uint64",
@@ -82,5 +83,8 @@ def test_plumbing_case_through_node():
     m = d["concurrentMul"]          # 16 x 1814 bootstraps cannot hide in one product's launches: batch rate instead
     assert m["ok"] and m["all_ms"] < 13 * m["single_ms"], m      # sixteen one after the other would be 16 x
     assert d["mixed"] == ["59", "rejected"]
+    # le -> select -> sub -> add on ciphertexts that stay on the GPU under 32-byte handles
+    assert d["store"] == {"chain": "125", "cond": "1", "entries": 5, "bitWidth": 8, "condWidth": 1, "afterDrop": 4,
+                          "dropped": 0, "unknown": "rejected"}, d["store"]
     print(f"node: one euint16 add {c['single_ms']:.1f} ms, sixteen concurrent {c['all_ms']:.1f} ms; "
           f"one euint64 mul {m['single_ms']:.1f} ms, sixteen concurrent {m['all_ms']:.1f} ms")
