@@ -545,7 +545,8 @@ void Engine::blind_rotate_with(const double* bsk, uint32_t n, const u64* lwe_sma
         else
             launch_blind_rotate(T_, bsk, in, (int)n, luts, li, gout, lout, cnt, omap,
                                 prm_.bsk_grouping == 3 ? 4 : prm_.bsk_grouping == 2 && fact ? 3 : (int)prm_.bsk_grouping,
-                                pair_above_ != -2 ? pair_above_ : (cnt > 2 * (size_t)cu_count_ ? 0 : -1), g64_guard_, stream_);
+                                pair_above_ != -2 ? pair_above_ : (cnt > 2 * (size_t)cu_count_ ? 0 : -1),
+                                prm_.bsk_grouping >= 2 ? wide_below_ : 0, g64_guard_, stream_);
         HC(hipGetLastError());
     }
 }

@@ -60,7 +60,7 @@ struct G64Guard {
 };
 void launch_blind_rotate(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
                          const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
-                         const BlockMap& omap, int grouping, int pair_above, const G64Guard& guard, hipStream_t st);
+                         const BlockMap& omap, int grouping, int pair_above, int wide_below, const G64Guard& guard, hipStream_t st);
 void launch_bskq_prepare(const Tables& T, const u64* in, double* out, size_t polys, hipStream_t st);
 // three key bits per step: groups of eight transformed GGSWs (src) -> the factored image the kernel streams (dst)
 void launch_bsk_factor3(const Tables& T, const double* src, double* dst, size_t groups, int* degenerate, int primes, hipStream_t st);

@@ -1392,22 +1392,27 @@ constexpr size_t g64_lds_bytes(int nc) { return (size_t)nc * LDS_BYTES + G64_TW_
 // TERM: -1 the whole step's GGSW; 0..2^BITS - 1 one of its terms alone (the slow path, see below).
 // BITS: key bits per step, 2 (rows: four GGSW rows of BSK_ROW words) or 3 (rows: the group's factored image
 // of both primes as k_bsk_factor3 lays it out; the point-wise stage is k_blind_rotate_q3's).
+// R < 0: the prime is picked at run time (r_rt, the same for every lane of a wavefront) -- the 512-thread kernel,
+// whose halves each take one prime, with exchange buffers (lds_base) of their own.
 template <int R, bool FACTORED, int NC, int TERM = -1, int BITS = 2>
 __device__ __forceinline__ void g64_prime_pass(double (&x)[NC][2][E], const Tables& T,
                                                const double* __restrict__ rows, const unsigned (&am)[NC][BITS],
-                                               unsigned t) {
+                                               unsigned t, double* __restrict__ lds_base = lds_dyn,
+                                               const double* __restrict__ tw_small = lds_dyn + NC * LDS_WORDS,
+                                               unsigned r_rt = 0) {
     static_assert(BITS == 2 || (BITS == 3 && FACTORED), "three key bits per step come with the factored image only");
-    const Prime P = T.pr[R];
-    const double* __restrict__ twf_small = lds_dyn + NC * LDS_WORDS + 2 * R * G2_TW_SMALL;
+    const unsigned r = R >= 0 ? (unsigned)R : r_rt;
+    const Prime P = r ? T.pr[1] : T.pr[0];
+    const double* __restrict__ twf_small = tw_small + 2 * r * G2_TW_SMALL;
     const double* __restrict__ twi_small = twf_small + G2_TW_SMALL;
-    auto buf = [&](int c, int q) { return lds_dyn + (2 * c + q) * POLY_STRIDE; };
+    auto buf = [&](int c, int q) { return lds_base + (2 * c + q) * POLY_STRIDE; };
     // addresses are recomputed per phase instead of living in registers across the step loop
     unsigned tt = t, zero = 0;
     asm volatile("" : "+v"(tt));
     asm volatile("" : "+s"(zero));
-    const double* __restrict__ mono = (R == 0 ? T.mono : T.mono1) + zero;
-    const double* __restrict__ twf = T.tw_fwd[R] + zero;
-    const double* __restrict__ twi = T.tw_inv[R] + zero;
+    const double* __restrict__ mono = (r == 0 ? T.mono : T.mono1) + zero;
+    const double* __restrict__ twf = (r ? T.tw_fwd[1] : T.tw_fwd[0]) + zero;
+    const double* __restrict__ twi = (r ? T.tw_inv[1] : T.tw_inv[0]) + zero;
     double w[7];
     // ---- forward transform of the digits, four polynomials per pass
     load_tw8(twf_small, 1, w);
@@ -1466,11 +1471,11 @@ __device__ __forceinline__ void g64_prime_pass(double (&x)[NC][2][E], const Tabl
         // key words of unit u = 4 c4 + m: GGSW m of the group, this prime, the four polynomials q,
         // positions 8 t + 2 c4 + {0, 1}; the next unit's loads are in flight while this one is multiplied
         // (three bits: unit u = 4 p + w, position 8 t + p, word pair w of this prime's factored image)
-        const double* __restrict__ rows3 = rows + (BITS == 3 ? R * BSK3_GROUP : 0);
+        const double* __restrict__ rows3 = rows + (BITS == 3 ? r * BSK3_GROUP : 0);
         double kc[4][2], kn[4][2];
 #pragma unroll
         for (unsigned q = 0; q < 4; ++q) {
-            const unsigned o = BITS == 3 ? bsk3_off(0, 0, q, tt) : bsk_off(R, q, 0, tt);
+            const unsigned o = BITS == 3 ? bsk3_off(0, 0, q, tt) : bsk_off(r, q, 0, tt);
             kc[q][0] = LFHE_LDK(rows3, o); kc[q][1] = LFHE_LDK(rows3, o + 1);
         }
 #pragma unroll
@@ -1545,7 +1550,7 @@ __device__ __forceinline__ void g64_prime_pass(double (&x)[NC][2][E], const Tabl
                     const unsigned c4n = (unsigned)(u + 1) / 4, mn = (unsigned)(u + 1) % 4;
 #pragma unroll
                     for (unsigned q = 0; q < 4; ++q) {
-                        const unsigned o = mn * (unsigned)BSK_ROW + bsk_off(R, q, c4n, tt);
+                        const unsigned o = mn * (unsigned)BSK_ROW + bsk_off(r, q, c4n, tt);
                         kn[q][0] = LFHE_LDK(rows, o); kn[q][1] = LFHE_LDK(rows, o + 1);
                     }
                 }
@@ -1788,6 +1793,100 @@ __global__ void __launch_bounds__(NT, 2) k_blind_rotate_g64_pair(Tables T, const
                 const unsigned e = own1(t, j);
                 if (e == 0) { o[0] = acc[c][0][j]; o[N] = acc[c][1][j]; }
                 else o[N - e] = (u64)0 - acc[c][0][j];
+            }
+        }
+    }
+}
+
+// The grouped key over 2^64 for launches of up to one ciphertext per CU: 512 threads per ciphertext, one half
+// per PRIME.  The two primes' shares of a step are independent until the lift, so each half runs the whole
+// one-prime pass (digits -> transform -> the step's GGSW -> inverse) with exchange buffers of its own, at the
+// same time as the other; then thread t of either half hands its 16 residues to thread t of the other through
+// the (now idle) exchange buffers and both lift all 16 coefficients -- the same words in both halves, so the
+// accumulator, the digits and the guard's verdict never have to be exchanged.  Bit-identical to
+// k_blind_rotate_g64_pair; a ciphertext the guard marks goes to that kernel's slow path like any other.
+constexpr size_t G64_WIDE_LDS_BYTES = 2 * LDS_BYTES + G64_TW_WORDS * sizeof(double);
+
+template <bool FACTORED, int BITS>
+__global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_g64_wide(Tables T, const double* __restrict__ bsk,
+                                                                     const u64* __restrict__ lwe_small, int n,
+                                                                     const u64* __restrict__ luts,
+                                                                     const u32* __restrict__ lut_index,
+                                                                     u64* __restrict__ glwe_out,
+                                                                     u64* __restrict__ lwe_out, BlockMap omap,
+                                                                     int* __restrict__ fault, double k_guard) {
+    const unsigned h = threadIdx.x >> 8;   // prime of this half (the same for every lane of a wavefront)
+    const unsigned t = threadIdx.x & (NT - 1);
+    const size_t ct = blockIdx.x;
+    const u64* __restrict__ lwe = lwe_small + ct * (size_t)(n + 1);
+    const u64* __restrict__ lut = luts + (size_t)(lut_index ? lut_index[omap.ops ? ct % omap.ops : ct] : 0) * N;
+    double* __restrict__ mine = lds_dyn + h * LDS_WORDS;
+    const double* __restrict__ theirs = lds_dyn + (1 - h) * LDS_WORDS;
+    const double* __restrict__ tw_small = lds_dyn + 2 * LDS_WORDS;
+    u64 acc[1][2][E];
+    bool near_edge = false;
+    {
+        const unsigned bt = modswitch_2n(lwe[n]);
+        const unsigned a = (2 * N - bt) & (2 * N - 1);  // multiply by X^-b~
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            bool neg;
+            const u64 v = lut[rot_index(own1(t, j), a, neg)];
+            acc[0][0][j] = 0;
+            acc[0][1][j] = neg ? (u64)0 - v : v;
+        }
+    }
+    for (unsigned i = threadIdx.x; i < (unsigned)G64_TW_WORDS; i += 2 * NT) {
+        const unsigned r = i / (2 * G2_TW_SMALL), k = i % (2 * G2_TW_SMALL);
+        lds_dyn[2 * LDS_WORDS + i] = k < (unsigned)G2_TW_SMALL ? T.tw_fwd[r][k] : T.tw_inv[r][k - G2_TW_SMALL];
+    }
+    __syncthreads();
+
+    const int groups = (n + BITS - 1) / BITS;
+    for (int g = 0; g < groups; ++g) {
+        unsigned am[1][BITS];
+#pragma unroll
+        for (int i = 0; i < BITS; ++i) am[0][i] = BITS * g + i < n ? modswitch_2n(lwe[BITS * g + i]) : 0u;
+        const double* __restrict__ rows = bsk + (size_t)g * (BITS == 3 ? 2 * BSK3_GROUP : 4 * BSK_ROW);
+        double x[1][2][E];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < E; ++j) x[0][q][j] = (double)decomp23(acc[0][q][j]);
+        g64_prime_pass<-1, FACTORED, 1, -1, BITS>(x, T, rows, am, t, mine, tw_small, h);   // ends with a workgroup barrier
+        // residues of this half's prime to the partner thread: word (q, j) of thread t at [q][j][t]
+        unsigned tt = t;
+        asm volatile("" : "+v"(tt));
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < E; ++j) mine[q * POLY_STRIDE + j * NT + tt] = x[0][q][j];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const double other = theirs[q * POLY_STRIDE + j * NT + tt];
+                const double y0 = h ? other : x[0][q][j], y1 = h ? x[0][q][j] : other;
+                acc[0][q][j] = crt_wrap_checked(y0, y1, T.p0inv_mod_p1, T.pr[1], k_guard, near_edge);
+            }
+        __syncthreads();   // the partner has read before the next step's first pass writes the buffers
+    }
+    if (h == 0) {
+        if (near_edge) fault[ct] = 1;   // any thread that saw a lift near the edge marks the ciphertext (plain vector store)
+        if (glwe_out) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < E; ++j) glwe_out[(ct * 2 + q) * N + own1(t, j)] = acc[0][q][j];
+        }
+        if (lwe_out) {  // sample extraction of coefficient 0
+            u64* o = lwe_out + omap.block(ct) * (size_t)(N + 1);
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const unsigned e = own1(t, j);
+                if (e == 0) { o[0] = acc[0][0][j]; o[N] = acc[0][1][j]; }
+                else o[N - e] = (u64)0 - acc[0][0][j];
             }
         }
     }
@@ -2196,6 +2295,9 @@ void blind_rotate_setup(int dev) {
     need(ask_lds(k_blind_rotate_g64_pair<false, 1, true>, g64_lds_bytes(1)), "k_blind_rotate_g64_pair (slow path)", g64_lds_bytes(1));
     need(ask_lds(k_blind_rotate_g64_pair<true, 2, false, 3>, g64_lds_bytes(2)), "k_blind_rotate_g64_pair (three key bits)", g64_lds_bytes(2));
     need(ask_lds(k_blind_rotate_g64_pair<true, 1, true, 3>, g64_lds_bytes(1)), "k_blind_rotate_g64_pair (three key bits, slow path)", g64_lds_bytes(1));
+    need(ask_lds(k_blind_rotate_g64_wide<true, 3>, G64_WIDE_LDS_BYTES), "k_blind_rotate_g64_wide", G64_WIDE_LDS_BYTES);
+    need(ask_lds(k_blind_rotate_g64_wide<true, 2>, G64_WIDE_LDS_BYTES), "k_blind_rotate_g64_wide", G64_WIDE_LDS_BYTES);
+    need(ask_lds(k_blind_rotate_g64_wide<false, 2>, G64_WIDE_LDS_BYTES), "k_blind_rotate_g64_wide", G64_WIDE_LDS_BYTES);
     need(ask_lds(k_blind_rotate_q2_wide<false>, WIDE2_LDS_BYTES), "k_blind_rotate_q2_wide", WIDE2_LDS_BYTES);
     need(ask_lds(k_blind_rotate_q2_wide<true>, WIDE2_LDS_BYTES), "k_blind_rotate_q2_wide", WIDE2_LDS_BYTES);
     need(ask_lds(k_blind_rotate_q_wide, WIDE_LDS_BYTES), "k_blind_rotate_q_wide", WIDE_LDS_BYTES);
@@ -2426,7 +2528,8 @@ void launch_external_product(const Tables& T, const double* bsk, const u32* idx,
 }
 void launch_blind_rotate(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
                          const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
-                         const BlockMap& omap, int grouping, int pair_above, const G64Guard& guard, hipStream_t st) {
+                         const BlockMap& omap, int grouping, int pair_above, int wide_below, const G64Guard& guard,
+                         hipStream_t st) {
     if (grouping >= 2) {
         // four GGSWs per pair of key bits (3: in factored form; 4: eight per triple, factored); two ciphertexts per workgroup, one when
         // the launch would leave CUs without a workgroup otherwise (pair_above: as for the prime modulus)
@@ -2438,7 +2541,16 @@ void launch_blind_rotate(const Tables& T, const double* bsk, const u64* lwe_smal
             hipLaunchKernelGGL(kernel, g, dim3(NT), g64_lds_bytes(nc), st, T, bsk, lwe_small, n, luts, lut_index, glwe_out,
                                lwe_out, omap, (unsigned)count, guard.fault, guard.k_guard, guard.fallbacks);
         };
-        if (grouping == 4) { if (pair) go(k_blind_rotate_g64_pair<true, 2, false, 3>, 2, grid); else go(k_blind_rotate_g64_pair<true, 1, false, 3>, 1, grid); }
+        if (count <= (size_t)wide_below) {   // up to one ciphertext per CU: 512 threads each, one half per prime
+            auto wide = [&](auto kernel) {
+                hipLaunchKernelGGL(kernel, dim3((unsigned)count), dim3(2 * NT), G64_WIDE_LDS_BYTES, st, T, bsk, lwe_small, n, luts,
+                                   lut_index, glwe_out, lwe_out, omap, guard.fault, guard.k_guard);
+            };
+            if (grouping == 4) wide(k_blind_rotate_g64_wide<true, 3>);
+            else if (grouping == 3) wide(k_blind_rotate_g64_wide<true, 2>);
+            else wide(k_blind_rotate_g64_wide<false, 2>);
+        }
+        else if (grouping == 4) { if (pair) go(k_blind_rotate_g64_pair<true, 2, false, 3>, 2, grid); else go(k_blind_rotate_g64_pair<true, 1, false, 3>, 1, grid); }
         else if (grouping == 3) { if (pair) go(k_blind_rotate_g64_pair<true, 2>, 2, grid); else go(k_blind_rotate_g64_pair<true, 1>, 1, grid); }
         else { if (pair) go(k_blind_rotate_g64_pair<false, 2>, 2, grid); else go(k_blind_rotate_g64_pair<false, 1>, 1, grid); }
         // the slow path for whatever the fast one marked: one workgroup per ciphertext, gone at once when unmarked

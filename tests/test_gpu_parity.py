@@ -15,10 +15,11 @@ N = 2048
 M64 = (1 << 64) - 1
 
 
-def _mk(n, ks_base_log=4, ks_level=4, seed=1, ms_zeros=0, grouped=False, factored=True, bits=2):
+def _mk(n, ks_base_log=4, ks_level=4, seed=1, ms_zeros=0, grouped=False, factored=True, bits=2, wide=True):
     """Oracle and library context over the same keys.  ms_zeros > 0 adds that many encryptions of
     zero and switches the modulus-switch noise reduction on in both.  grouped: the bootstrapping key
-    with 2^bits GGSWs over 2^64 per group of `bits` key bits."""
+    with 2^bits GGSWs over 2^64 per group of `bits` key bits.  wide=False keeps launches of up to one
+    ciphertext per CU on the 256-thread kernel (by default a grouped key takes the 512-thread one there)."""
     from fhe_amd.native import Context, Params, default_params
     op = OParams(lwe_dim=n, ks_base_log=ks_base_log, ks_level=ks_level)
     orc = Oracle(op)
@@ -35,8 +36,14 @@ def _mk(n, ks_base_log=4, ks_level=4, seed=1, ms_zeros=0, grouped=False, factore
         zeros = orc.gen_ms_zeros(keys[0], seed_bytes(seed), ms_zeros)
         orc.set_ms(zeros)
         orc.zeros = zeros
-    ctx = Context(seed=seed_bytes(100 + seed), params=p)
     import os
+    os.environ.pop("LFHE_WIDE_BELOW", None)
+    if not wide:
+        os.environ["LFHE_WIDE_BELOW"] = "0"
+    try:
+        ctx = Context(seed=seed_bytes(100 + seed), params=p)
+    finally:
+        os.environ.pop("LFHE_WIDE_BELOW", None)
     if not factored:                      # keep the grouped key's image as generated (the fall-back path)
         os.environ["LFHE_BSK_FACTORED"] = "0"
     try:
@@ -594,16 +601,17 @@ def test_padding_bit_tables_full_parameters():
         ctx.close()
 
 
+@pytest.mark.parametrize("wide", [True, False], ids=["512-thread", "256-thread"])
 @pytest.mark.parametrize("n,factored,bits", [(12, True, 2), (13, True, 2), (12, False, 2), (13, False, 2),
                                               (12, True, 3), (13, True, 3), (14, True, 3)],
                          ids=["12-factored", "13-factored", "12-plain", "13-plain", "12-triples", "13-triples", "14-triples"])
-def test_grouped_key_over_the_torus_bit_exact(n, factored, bits):
+def test_grouped_key_over_the_torus_bit_exact(n, factored, bits, wide):
     """Two or three key bits per step, every modulus 2^64 (two-prime transform and lift per step, two
     ciphertexts per workgroup): accumulators and bootstrapped ciphertexts equal the oracle's bit for
     bit, for key lengths with and without a ragged last group, odd and even batches, all-zero masks,
     masks whose pairs cancel (a + a' = 2N) and accumulators whose digits are all extreme."""
     from fhe_amd.native import LfheError
-    orc, keys, ctx = _mk(n, seed=9, grouped=True, factored=factored, bits=bits)
+    orc, keys, ctx = _mk(n, seed=9, grouped=True, factored=factored, bits=bits, wide=wide)
     try:
         lwe_sk, glwe_sk, bskg, ksk = keys
         pb = orc.prepare_bsk_grouped(bskg, bits)
@@ -677,18 +685,19 @@ def test_grouped_key_over_the_torus_full_parameters(bits):
         ctx.close()
 
 
+@pytest.mark.parametrize("wide", [True, False], ids=["512-thread", "256-thread"])
 @pytest.mark.parametrize("factored,bits", [(True, 2), (False, 2), (True, 3)], ids=["factored", "plain", "triples"])
-def test_lift_guard_of_the_grouped_key_over_the_torus(factored, bits):
+def test_lift_guard_of_the_grouped_key_over_the_torus(factored, bits, wide):
     """Every lift of the grouped key over 2^64 is checked against a guard band at the end of its window;
     a ciphertext that reaches the band is bootstrapped again, on the device, with the step taken apart
     into its four (eight with three key bits per step) unconditionally exact products.  Never taken at the shipped band (130 standard
     deviations out); with the band forced down to the middle of the window every ciphertext takes the
     slow path -- and must come back with exactly the oracle's bits, like the fast path."""
     import os
-    orc, keys, ctx = _mk(13, seed=9, grouped=True, factored=factored, bits=bits)
+    orc, keys, ctx = _mk(13, seed=9, grouped=True, factored=factored, bits=bits, wide=wide)
     os.environ["LFHE_G64_GUARD_FRAC"] = "1e-4"
     try:
-        _, _, forced = _mk(13, seed=9, grouped=True, factored=factored, bits=bits)
+        _, _, forced = _mk(13, seed=9, grouped=True, factored=factored, bits=bits, wide=wide)
     finally:
         del os.environ["LFHE_G64_GUARD_FRAC"]
     try:
