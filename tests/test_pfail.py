@@ -61,6 +61,18 @@ def test_documented_figures_follow_from_the_probe(analysis):
     assert 1.30 < analysis["keys"]["grouped"]["v_br_ratio_to_q64"] < 1.45
 
 
+def test_measured_bootstrap_noise_agrees_with_its_formula(analysis):
+    """Output variance of a bootstrap by formula (key noise of every GGSW of a step + decomposition
+    rounding, tools/pfail.py) against the GPU measurement, for one, two and three key bits per step and
+    both moduli: within 0.06 in the exponent (2^98.00, 2^98.48, 2^98.55)."""
+    import pfail
+    assert pfail.blind_rotation_variance_log2(1) == pytest.approx(97.995, abs=0.01)
+    assert pfail.blind_rotation_variance_log2(2) == pytest.approx(98.48, abs=0.01)
+    assert pfail.blind_rotation_variance_log2(3) == pytest.approx(98.547, abs=0.01)
+    for name, k in analysis["keys"].items():
+        assert abs(k["v_br_log2"] - k["v_br_log2_formula"]) < 0.06, (name, k["v_br_log2"], k["v_br_log2_formula"])
+
+
 def test_pfail_formula_against_a_closed_form():
     import numpy as np
     import pfail

@@ -58,6 +58,24 @@ def ks_variance_log2(pub) -> float:
     return math.log2(N * l * d2 * var_key + N / 2 * cut * cut / 12)
 
 
+def blind_rotation_variance_log2(bits: int, n: int = 918, N: int = 2048, base_log: int = 23, glwe_noise_log2: int = 17) -> float:
+    """Formula value of a bootstrap's output variance (2^64 torus scale) for `bits` key bits per step,
+    one decomposition level, k = 1.  Per external product: the key noise of every GGSW in the step
+    ((k+1) N digits of variance (B^2 + 2) / 12 times Var TUniform) and what the decomposition rounds
+    away ((q / B)^2 / 12 per coefficient, seen through the key: 1 + N / 2).  One bit per step (the CMux
+    acc + G [.] ((X^a - 1) acc)): n products of one GGSW, the rounding counted where the key bit is 1
+    (half of them).  Grouped, accumulator replaced by the product: ceil(n / bits) products of 2^bits
+    GGSWs, the rounding in every one."""
+    var_key = (2.0 ** (2 * glwe_noise_log2 + 1) + 1) / 6
+    B = 2.0 ** base_log
+    key = 2 * N * (B * B + 2) / 12 * var_key
+    rounding = (2.0 ** (64 - base_log)) ** 2 / 12 * (1 + N / 2)
+    if bits == 1:
+        return math.log2(n * (key + rounding / 2))
+    steps = -(-n // bits)
+    return math.log2(steps * ((1 << bits) * key + rounding))
+
+
 def log2_pfail(v_in_log2: float, mean58: np.ndarray, sd58: np.ndarray, in_mean58: float = 0.0) -> float:
     """mean and sd of the rounding error in units of 2^58; v_in (variance about the mean) on the 2^64
     torus scale; in_mean58: mean of the input noise in units of 2^58 (for one key the key-switch noise
@@ -84,6 +102,7 @@ def analyse(probe_path: str = DEFAULT_PROBE) -> dict:
         out["keys"][name] = {
             "samples": rec["bootstraps"],
             "v_br_log2": v_br, "v_br_ratio_to_q64": 2.0 ** (v_br - 2 * ref),
+            "v_br_log2_formula": blind_rotation_variance_log2(3 if name.endswith("3") else 2 if "grouped" in name else 1),
             "v_ks_log2_measured": v_ks,
             "v_in_level5_log2": v_in,
             "v_in_over_published": 2.0 ** (v_in - pub["input_variance_log2"]),
