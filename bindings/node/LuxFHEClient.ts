@@ -100,13 +100,14 @@ export class NativeTransport implements EngineTransport {
       publicKey(): Uint8Array;
       encrypt(value: bigint, bitWidth: number): Uint8Array;
       decrypt(ciphertext: Uint8Array): bigint;
-      evaluate(
+      // runs off the event loop; concurrent calls of one shape share their bootstrap launches
+      evaluateAsync(
         op: string,
         bitWidth: number,
         left: Uint8Array,
         right?: Uint8Array | bigint | null,
         cond?: Uint8Array | null
-      ): Uint8Array;
+      ): Promise<Uint8Array>;
     }
   ) {}
 
@@ -126,7 +127,7 @@ export class NativeTransport implements EngineTransport {
     right?: Uint8Array | bigint | null,
     cond?: Uint8Array | null
   ): Promise<Uint8Array> {
-    return new Uint8Array(this.engine.evaluate(op, bitWidth, left, right, cond));
+    return new Uint8Array(await this.engine.evaluateAsync(op, bitWidth, left, right, cond));
   }
 }
 
