@@ -64,6 +64,15 @@ Engine::Engine(int device, const EngineParams& p) : device_(device), prm_(p) {
         double frac = 0.875;      // of the half-window p1 / 2
         if (const char* e = std::getenv("LFHE_G64_GUARD_FRAC")) frac = std::atof(e);   // tests force the slow path with a small one
         g64_guard_.k_guard = frac * 0.5 * P1;
+        // launches of at most one ciphertext per two CUs spread each ciphertext's two primes over two CUs
+        size_t split = (size_t)cu_count_ / 2;
+        if (const char* e = std::getenv("LFHE_G64_SPLIT_BELOW")) split = (size_t)std::max(0, std::atoi(e));   // 0: never
+        if (const char* e = std::getenv("LFHE_G64_SPLIT_POLL")) g64_guard_.poll_limit = (unsigned)std::max(0, std::atoi(e));   // tests: 0 makes every workgroup give up
+        if (split) {
+            HC(hipMalloc(&g64_guard_.xchg, g64_split_payload_bytes(split)));
+            HC(hipMalloc(&g64_guard_.xchg_flags, g64_split_flag_bytes(split)));
+            g64_guard_.split_below = split;
+        }
     }
 
     HostTables H;
@@ -110,6 +119,8 @@ Engine::~Engine() {
     (void)hipFree(d_decomp_bsk_);
     (void)hipFree(g64_guard_.fault);
     (void)hipFree(g64_guard_.fallbacks);
+    (void)hipFree(g64_guard_.xchg);
+    (void)hipFree(g64_guard_.xchg_flags);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 

@@ -57,7 +57,15 @@ struct G64Guard {
     size_t capacity = 0;
     double k_guard = 0;
     unsigned long long* fallbacks = nullptr;
+    // two CUs per ciphertext for launches of at most split_below ciphertexts (kernels.hip: k_blind_rotate_g64_split):
+    // hand-over buffers and step counters in device memory, how often a workgroup polls before it gives up
+    double* xchg = nullptr;
+    unsigned* xchg_flags = nullptr;
+    size_t split_below = 0;
+    unsigned poll_limit = 1u << 18;
 };
+size_t g64_split_payload_bytes(size_t cts);
+size_t g64_split_flag_bytes(size_t cts);
 void launch_blind_rotate(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
                          const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
                          const BlockMap& omap, int grouping, int pair_above, int wide_below, const G64Guard& guard, hipStream_t st);

@@ -1892,6 +1892,177 @@ __global__ void __launch_bounds__(2 * NT, 1) k_blind_rotate_g64_wide(Tables T, c
     }
 }
 
+// The grouped key over 2^64 for launches of at most one ciphertext per TWO CUs: the primes of a ciphertext on two
+// compute units of one XCD.  Each of the two workgroups (256 threads; blocks b and b + 8 land on the same XCD)
+// runs the one-prime pass of a step with the CU to itself and hands its 4096 residues to the other through the
+// XCD's L2 once per step: write-through stores, drained per wave, a workgroup barrier, one lane raises the
+// workgroup's step counter and polls the partner's, a barrier, loads that bypass the L1.  Payload slots alternate
+// with the step, so a workgroup that is one step ahead does not overwrite what its partner still reads (it cannot
+// be two ahead: it waits for the partner's counter of the step, raised after the partner has read the step before).
+// Both workgroups lift all coefficients and so hold the same accumulator.  The poll is bounded: a workgroup whose
+// partner does not show up (not resident because something else holds the CUs) marks the ciphertext in the guard's
+// flags and leaves, its partner does the same in its turn, and the slow path that follows every launch of this key
+// bootstraps the ciphertext -- no wave ever waits without end.  Bit-identical to the other kernels of the key.
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+constexpr int G64_SPLIT_WORDS = 2 * N;                      // residues one workgroup hands over per step (both polynomials)
+constexpr size_t g64_split_payload_words(size_t cts) { return cts * 2 * 2 * (size_t)G64_SPLIT_WORDS; }   // [ct][half][slot]
+constexpr size_t g64_split_flag_words(size_t cts) { return cts * 2 * 32; }                                // one 128-byte line each
+
+__device__ __forceinline__ void st8_l2(v2d_t* p, const v2d_t (&v)[8]) {
+    // eight 16-byte write-through stores (lane-contiguous, NT lanes apart), drained once before the wave goes on
+    v2d_t *p1 = p + NT, *p2 = p + 2 * NT, *p3 = p + 3 * NT, *p4 = p + 4 * NT, *p5 = p + 5 * NT, *p6 = p + 6 * NT, *p7 = p + 7 * NT;
+    asm volatile("global_store_dwordx4 %0, %8, off sc1\n"
+                 "global_store_dwordx4 %1, %9, off sc1\n"
+                 "global_store_dwordx4 %2, %10, off sc1\n"
+                 "global_store_dwordx4 %3, %11, off sc1\n"
+                 "global_store_dwordx4 %4, %12, off sc1\n"
+                 "global_store_dwordx4 %5, %13, off sc1\n"
+                 "global_store_dwordx4 %6, %14, off sc1\n"
+                 "global_store_dwordx4 %7, %15, off sc1\n"
+                 "s_waitcnt vmcnt(0)"
+                 :: "v"(p), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7),
+                    "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]) : "memory");
+}
+__device__ __forceinline__ void ld8_l2(const v2d_t* p, v2d_t (&v)[8]) {
+    const v2d_t *p1 = p + NT, *p2 = p + 2 * NT, *p3 = p + 3 * NT, *p4 = p + 4 * NT, *p5 = p + 5 * NT, *p6 = p + 6 * NT, *p7 = p + 7 * NT;
+    asm volatile("global_load_dwordx4 %0, %8, off sc1\n"
+                 "global_load_dwordx4 %1, %9, off sc1\n"
+                 "global_load_dwordx4 %2, %10, off sc1\n"
+                 "global_load_dwordx4 %3, %11, off sc1\n"
+                 "global_load_dwordx4 %4, %12, off sc1\n"
+                 "global_load_dwordx4 %5, %13, off sc1\n"
+                 "global_load_dwordx4 %6, %14, off sc1\n"
+                 "global_load_dwordx4 %7, %15, off sc1\n"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                 : "v"(p), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7) : "memory");
+}
+__device__ __forceinline__ void flag_store_l2(unsigned* p, unsigned v) {
+    asm volatile("global_store_dword %0, %1, off sc1\ns_waitcnt vmcnt(0)" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ unsigned flag_load_l2(const unsigned* p) {
+    unsigned v;
+    asm volatile("global_load_dword %0, %1, off sc1\ns_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+template <bool FACTORED, int BITS>
+__global__ void __launch_bounds__(NT, 2) k_blind_rotate_g64_split(Tables T, const double* __restrict__ bsk,
+                                                                 const u64* __restrict__ lwe_small, int n,
+                                                                 const u64* __restrict__ luts,
+                                                                 const u32* __restrict__ lut_index,
+                                                                 u64* __restrict__ glwe_out,
+                                                                 u64* __restrict__ lwe_out, BlockMap omap, unsigned count,
+                                                                 int* __restrict__ fault, double k_guard,
+                                                                 double* __restrict__ payload, unsigned* __restrict__ flags,
+                                                                 unsigned poll_limit) {
+    const unsigned b = blockIdx.x;
+    const unsigned h = (b >> 3) & 1u;                      // prime of this workgroup
+    const size_t ct = (size_t)(b >> 4) * 8 + (b & 7u);     // blocks b and b + 8: one ciphertext, one XCD
+    if (ct >= count) return;                               // the same for the whole workgroup and for its partner
+    const unsigned t = threadIdx.x;
+    const u64* __restrict__ lwe = lwe_small + ct * (size_t)(n + 1);
+    const u64* __restrict__ lut = luts + (size_t)(lut_index ? lut_index[omap.ops ? ct % omap.ops : ct] : 0) * N;
+    v2d_t* mine = reinterpret_cast<v2d_t*>(payload + (ct * 2 + h) * 2 * (size_t)G64_SPLIT_WORDS);
+    const v2d_t* theirs = reinterpret_cast<const v2d_t*>(payload + (ct * 2 + (1 - h)) * 2 * (size_t)G64_SPLIT_WORDS);
+    unsigned* my_flag = flags + (ct * 2 + h) * 32;
+    const unsigned* their_flag = flags + (ct * 2 + (1 - h)) * 32;
+    __shared__ unsigned s_dead;
+    if (t == 0) s_dead = 0;
+    u64 acc[1][2][E];
+    bool near_edge = false;
+    {
+        const unsigned bt = modswitch_2n(lwe[n]);
+        const unsigned a = (2 * N - bt) & (2 * N - 1);  // multiply by X^-b~
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            bool neg;
+            const u64 v = lut[rot_index(own1(t, j), a, neg)];
+            acc[0][0][j] = 0;
+            acc[0][1][j] = neg ? (u64)0 - v : v;
+        }
+    }
+    for (unsigned i = t; i < (unsigned)G64_TW_WORDS; i += NT) {
+        const unsigned r = i / (2 * G2_TW_SMALL), k = i % (2 * G2_TW_SMALL);
+        lds_dyn[LDS_WORDS + i] = k < (unsigned)G2_TW_SMALL ? T.tw_fwd[r][k] : T.tw_inv[r][k - G2_TW_SMALL];
+    }
+    __syncthreads();
+
+    const int groups = (n + BITS - 1) / BITS;
+    for (int g = 0; g < groups; ++g) {
+        unsigned am[1][BITS];
+#pragma unroll
+        for (int i = 0; i < BITS; ++i) am[0][i] = BITS * g + i < n ? modswitch_2n(lwe[BITS * g + i]) : 0u;
+        const double* __restrict__ rows = bsk + (size_t)g * (BITS == 3 ? 2 * BSK3_GROUP : 4 * BSK_ROW);
+        double x[1][2][E];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < E; ++j) x[0][q][j] = (double)decomp23(acc[0][q][j]);
+        g64_prime_pass<-1, FACTORED, 1, -1, BITS>(x, T, rows, am, t, lds_dyn, lds_dyn + LDS_WORDS, h);
+        // hand-over: 16-byte word k = 4 q + j / 2 of thread t at [slot][k][t]
+        const unsigned step = (unsigned)g + 1u;
+        const unsigned slot = step & 1u;
+        unsigned tt = t;
+        asm volatile("" : "+v"(tt));
+        {
+            v2d_t v[8];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { v[4 * q + k].x = x[0][q][2 * k]; v[4 * q + k].y = x[0][q][2 * k + 1]; }
+            st8_l2(mine + (size_t)slot * (G64_SPLIT_WORDS / 2) + tt, v);   // returns when this wave's stores have left
+        }
+        __syncthreads();                                   // ... and every wave's have
+        if (t == 0) {
+            flag_store_l2(my_flag, step);
+            unsigned tries = 0;
+            while (flag_load_l2(their_flag) < step) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++tries > poll_limit) { s_dead = 1; break; }
+            }
+        }
+        __syncthreads();                                   // the poll has matched before anyone loads
+        if (s_dead) {                                      // the same for every thread: the slow path takes this ciphertext
+            if (t == 0) fault[ct] = 1;
+            return;
+        }
+        {
+            v2d_t u[8];
+            ld8_l2(theirs + (size_t)slot * (G64_SPLIT_WORDS / 2) + tt, u);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int j = 2 * k + e;
+                        const double other = e ? u[4 * q + k].y : u[4 * q + k].x;
+                        const double y0 = h ? other : x[0][q][j], y1 = h ? x[0][q][j] : other;
+                        acc[0][q][j] = crt_wrap_checked(y0, y1, T.p0inv_mod_p1, T.pr[1], k_guard, near_edge);
+                    }
+        }
+    }
+    if (h == 0) {
+        if (near_edge) fault[ct] = 1;   // any thread that saw a lift near the edge marks the ciphertext (plain vector store)
+        if (glwe_out) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < E; ++j) glwe_out[(ct * 2 + q) * N + own1(t, j)] = acc[0][q][j];
+        }
+        if (lwe_out) {  // sample extraction of coefficient 0
+            u64* o = lwe_out + omap.block(ct) * (size_t)(N + 1);
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const unsigned e = own1(t, j);
+                if (e == 0) { o[0] = acc[0][0][j]; o[N] = acc[0][1][j]; }
+                else o[N - e] = (u64)0 - acc[0][0][j];
+            }
+        }
+    }
+}
+
 // The grouped blind rotation for launches too small to fill the GPU: 512 threads per ciphertext, one
 // half per polynomial as in k_blind_rotate_q_wide.  Each half forms the two entries of the step's
 // GGSW that feed its own output polynomial.  Results are bit-identical to k_blind_rotate_q2.
@@ -2295,6 +2466,9 @@ void blind_rotate_setup(int dev) {
     need(ask_lds(k_blind_rotate_g64_pair<false, 1, true>, g64_lds_bytes(1)), "k_blind_rotate_g64_pair (slow path)", g64_lds_bytes(1));
     need(ask_lds(k_blind_rotate_g64_pair<true, 2, false, 3>, g64_lds_bytes(2)), "k_blind_rotate_g64_pair (three key bits)", g64_lds_bytes(2));
     need(ask_lds(k_blind_rotate_g64_pair<true, 1, true, 3>, g64_lds_bytes(1)), "k_blind_rotate_g64_pair (three key bits, slow path)", g64_lds_bytes(1));
+    need(ask_lds(k_blind_rotate_g64_split<true, 3>, g64_lds_bytes(1)), "k_blind_rotate_g64_split", g64_lds_bytes(1));
+    need(ask_lds(k_blind_rotate_g64_split<true, 2>, g64_lds_bytes(1)), "k_blind_rotate_g64_split", g64_lds_bytes(1));
+    need(ask_lds(k_blind_rotate_g64_split<false, 2>, g64_lds_bytes(1)), "k_blind_rotate_g64_split", g64_lds_bytes(1));
     need(ask_lds(k_blind_rotate_g64_wide<true, 3>, G64_WIDE_LDS_BYTES), "k_blind_rotate_g64_wide", G64_WIDE_LDS_BYTES);
     need(ask_lds(k_blind_rotate_g64_wide<true, 2>, G64_WIDE_LDS_BYTES), "k_blind_rotate_g64_wide", G64_WIDE_LDS_BYTES);
     need(ask_lds(k_blind_rotate_g64_wide<false, 2>, G64_WIDE_LDS_BYTES), "k_blind_rotate_g64_wide", G64_WIDE_LDS_BYTES);
@@ -2526,6 +2700,9 @@ void launch_external_product(const Tables& T, const double* bsk, const u32* idx,
                              size_t count, hipStream_t st) {
     hipLaunchKernelGGL(k_external_product, dim3((unsigned)count), dim3(NT), LDS_BYTES, st, T, bsk, idx, glwe, out);
 }
+size_t g64_split_payload_bytes(size_t cts) { return g64_split_payload_words(cts) * sizeof(double); }
+size_t g64_split_flag_bytes(size_t cts) { return g64_split_flag_words(cts) * sizeof(unsigned); }
+
 void launch_blind_rotate(const Tables& T, const double* bsk, const u64* lwe_small, int n, const u64* luts,
                          const u32* lut_index, u64* glwe_out, u64* lwe_out, size_t count,
                          const BlockMap& omap, int grouping, int pair_above, int wide_below, const G64Guard& guard,
@@ -2541,7 +2718,19 @@ void launch_blind_rotate(const Tables& T, const double* bsk, const u64* lwe_smal
             hipLaunchKernelGGL(kernel, g, dim3(NT), g64_lds_bytes(nc), st, T, bsk, lwe_small, n, luts, lut_index, glwe_out,
                                lwe_out, omap, (unsigned)count, guard.fault, guard.k_guard, guard.fallbacks);
         };
-        if (count <= (size_t)wide_below) {   // up to one ciphertext per CU: 512 threads each, one half per prime
+        if (guard.xchg && count <= guard.split_below) {   // up to one ciphertext per two CUs: one CU per prime
+            if (hipMemsetAsync(guard.xchg_flags, 0, g64_split_flag_words(count) * sizeof(unsigned), st) != hipSuccess)
+                throw std::runtime_error("hipMemsetAsync failed");
+            auto split = [&](auto kernel) {
+                hipLaunchKernelGGL(kernel, dim3((unsigned)(16 * ((count + 7) / 8))), dim3(NT), g64_lds_bytes(1), st, T, bsk, lwe_small,
+                                   n, luts, lut_index, glwe_out, lwe_out, omap, (unsigned)count, guard.fault, guard.k_guard,
+                                   guard.xchg, guard.xchg_flags, guard.poll_limit);
+            };
+            if (grouping == 4) split(k_blind_rotate_g64_split<true, 3>);
+            else if (grouping == 3) split(k_blind_rotate_g64_split<true, 2>);
+            else split(k_blind_rotate_g64_split<false, 2>);
+        }
+        else if (count <= (size_t)wide_below) {   // up to one ciphertext per CU: 512 threads each, one half per prime
             auto wide = [&](auto kernel) {
                 hipLaunchKernelGGL(kernel, dim3((unsigned)count), dim3(2 * NT), G64_WIDE_LDS_BYTES, st, T, bsk, lwe_small, n, luts,
                                    lut_index, glwe_out, lwe_out, omap, guard.fault, guard.k_guard);

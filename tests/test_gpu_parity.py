@@ -15,11 +15,13 @@ N = 2048
 M64 = (1 << 64) - 1
 
 
-def _mk(n, ks_base_log=4, ks_level=4, seed=1, ms_zeros=0, grouped=False, factored=True, bits=2, wide=True):
+def _mk(n, ks_base_log=4, ks_level=4, seed=1, ms_zeros=0, grouped=False, factored=True, bits=2, shape="split", env=None):
     """Oracle and library context over the same keys.  ms_zeros > 0 adds that many encryptions of
     zero and switches the modulus-switch noise reduction on in both.  grouped: the bootstrapping key
-    with 2^bits GGSWs over 2^64 per group of `bits` key bits.  wide=False keeps launches of up to one
-    ciphertext per CU on the 256-thread kernel (by default a grouped key takes the 512-thread one there)."""
+    with 2^bits GGSWs over 2^64 per group of `bits` key bits.  shape: which kernel small launches of a grouped
+    key take -- "split" (the default: up to one ciphertext per two CUs on two CUs each, up to one per CU on 512
+    threads), "wide" (512 threads, never two CUs) or "narrow" (the 256-thread kernel at every size).  env: further
+    environment variables for the time the context is created."""
     from fhe_amd.native import Context, Params, default_params
     op = OParams(lwe_dim=n, ks_base_log=ks_base_log, ks_level=ks_level)
     orc = Oracle(op)
@@ -37,13 +39,19 @@ def _mk(n, ks_base_log=4, ks_level=4, seed=1, ms_zeros=0, grouped=False, factore
         orc.set_ms(zeros)
         orc.zeros = zeros
     import os
-    os.environ.pop("LFHE_WIDE_BELOW", None)
-    if not wide:
-        os.environ["LFHE_WIDE_BELOW"] = "0"
+    setup = dict(env or {})
+    if shape in ("wide", "narrow"):
+        setup["LFHE_G64_SPLIT_BELOW"] = "0"
+    if shape == "narrow":
+        setup["LFHE_WIDE_BELOW"] = "0"
+    for k in ("LFHE_WIDE_BELOW", "LFHE_G64_SPLIT_BELOW", "LFHE_G64_SPLIT_POLL"):
+        os.environ.pop(k, None)
+    os.environ.update(setup)
     try:
         ctx = Context(seed=seed_bytes(100 + seed), params=p)
     finally:
-        os.environ.pop("LFHE_WIDE_BELOW", None)
+        for k in setup:
+            os.environ.pop(k, None)
     if not factored:                      # keep the grouped key's image as generated (the fall-back path)
         os.environ["LFHE_BSK_FACTORED"] = "0"
     try:
@@ -601,17 +609,17 @@ def test_padding_bit_tables_full_parameters():
         ctx.close()
 
 
-@pytest.mark.parametrize("wide", [True, False], ids=["512-thread", "256-thread"])
+@pytest.mark.parametrize("shape", ["split", "wide", "narrow"], ids=["two-CUs", "512-thread", "256-thread"])
 @pytest.mark.parametrize("n,factored,bits", [(12, True, 2), (13, True, 2), (12, False, 2), (13, False, 2),
                                               (12, True, 3), (13, True, 3), (14, True, 3)],
                          ids=["12-factored", "13-factored", "12-plain", "13-plain", "12-triples", "13-triples", "14-triples"])
-def test_grouped_key_over_the_torus_bit_exact(n, factored, bits, wide):
+def test_grouped_key_over_the_torus_bit_exact(n, factored, bits, shape):
     """Two or three key bits per step, every modulus 2^64 (two-prime transform and lift per step, two
     ciphertexts per workgroup): accumulators and bootstrapped ciphertexts equal the oracle's bit for
     bit, for key lengths with and without a ragged last group, odd and even batches, all-zero masks,
     masks whose pairs cancel (a + a' = 2N) and accumulators whose digits are all extreme."""
     from fhe_amd.native import LfheError
-    orc, keys, ctx = _mk(n, seed=9, grouped=True, factored=factored, bits=bits, wide=wide)
+    orc, keys, ctx = _mk(n, seed=9, grouped=True, factored=factored, bits=bits, shape=shape)
     try:
         lwe_sk, glwe_sk, bskg, ksk = keys
         pb = orc.prepare_bsk_grouped(bskg, bits)
@@ -685,21 +693,17 @@ def test_grouped_key_over_the_torus_full_parameters(bits):
         ctx.close()
 
 
-@pytest.mark.parametrize("wide", [True, False], ids=["512-thread", "256-thread"])
+@pytest.mark.parametrize("shape", ["split", "wide", "narrow"], ids=["two-CUs", "512-thread", "256-thread"])
 @pytest.mark.parametrize("factored,bits", [(True, 2), (False, 2), (True, 3)], ids=["factored", "plain", "triples"])
-def test_lift_guard_of_the_grouped_key_over_the_torus(factored, bits, wide):
+def test_lift_guard_of_the_grouped_key_over_the_torus(factored, bits, shape):
     """Every lift of the grouped key over 2^64 is checked against a guard band at the end of its window;
     a ciphertext that reaches the band is bootstrapped again, on the device, with the step taken apart
     into its four (eight with three key bits per step) unconditionally exact products.  Never taken at the shipped band (130 standard
     deviations out); with the band forced down to the middle of the window every ciphertext takes the
     slow path -- and must come back with exactly the oracle's bits, like the fast path."""
     import os
-    orc, keys, ctx = _mk(13, seed=9, grouped=True, factored=factored, bits=bits, wide=wide)
-    os.environ["LFHE_G64_GUARD_FRAC"] = "1e-4"
-    try:
-        _, _, forced = _mk(13, seed=9, grouped=True, factored=factored, bits=bits, wide=wide)
-    finally:
-        del os.environ["LFHE_G64_GUARD_FRAC"]
+    orc, keys, ctx = _mk(13, seed=9, grouped=True, factored=factored, bits=bits, shape=shape)
+    _, _, forced = _mk(13, seed=9, grouped=True, factored=factored, bits=bits, shape=shape, env={"LFHE_G64_GUARD_FRAC": "1e-4"})
     try:
         lwe_sk, glwe_sk, bskg, ksk = keys
         pb = orc.prepare_bsk_grouped(bskg, bits)
@@ -727,6 +731,29 @@ def test_lift_guard_of_the_grouped_key_over_the_torus(factored, bits, wide):
     finally:
         ctx.close()
         forced.close()
+
+
+@pytest.mark.parametrize("bits", [2, 3], ids=["pairs", "triples"])
+def test_two_cu_kernel_gives_up_and_the_slow_path_takes_over(bits):
+    """The two workgroups of a ciphertext wait for each other a bounded number of polls.  With the bound
+    forced to zero a workgroup gives up at the first poll that does not find its partner's counter raised,
+    marks its ciphertext and leaves (its partner follows); the slow path behind the launch bootstraps every
+    marked ciphertext: the oracle's bits either way, fallbacks counted, and the context goes on working."""
+    orc, keys, ctx = _mk(13, seed=9, grouped=True, bits=bits, env={"LFHE_G64_SPLIT_POLL": "0"})
+    try:
+        lwe_sk, glwe_sk, bskg, ksk = keys
+        pb = orc.prepare_bsk_grouped(bskg, bits)
+        r = Rng(seed_bytes(37))
+        lut_o, lut_g = orc.make_lut(lambda x: (3 * x + 1) % 16), ctx.make_lut(lambda x: (3 * x + 1) % 16)
+        smalls = np.stack([r.u64s(orc.n + 1) for _ in range(11)])
+        want = np.stack([orc.blind_rotate(pb, smalls[c], lut_o).reshape(2, N) for c in range(11)])
+        assert np.array_equal(ctx.blind_rotate(smalls, lut_g[None], None), want)
+        first = ctx.lift_fallbacks()
+        assert 3 <= first <= 11          # a pair that happens to run in step never finds its partner missing
+        assert np.array_equal(ctx.blind_rotate(smalls[:5], lut_g[None], None), want[:5])
+        assert first < ctx.lift_fallbacks() <= first + 5
+    finally:
+        ctx.close()
 
 
 @pytest.mark.parametrize("params_id", [1, 2, 3, 4, 5, 6])

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Which workgroup shape serves which launch size (key bits in triples): blind rotation of B ciphertexts with two
-ciphertexts per workgroup, one per workgroup, and 512 threads per ciphertext, back to back.
+ciphertexts per workgroup, one per workgroup, and 512 threads per ciphertext, back to back (the library's own choice
+also has two CUs per ciphertext for the keys over 2^64, up to one ciphertext per two CUs).
   tools/launch_size_probe.py [params id = 5] [sizes ...]      (needs a GPU)"""
 import os
 import sys
@@ -16,13 +17,13 @@ def main():
     pid = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     sizes = [int(a) for a in sys.argv[2:]] or [128, 256, 288, 320, 384, 448, 512, 640, 768, 896, 1024, 1536, 2048]
     dev = torch.device("cuda", 0)
-    variants = (("two per workgroup", {"LFHE_PAIR_ABOVE": "0", "LFHE_WIDE_BELOW": "0"}),
-                ("one per workgroup", {"LFHE_PAIR_ABOVE": "-1", "LFHE_WIDE_BELOW": "0"}),
-                ("512 threads each", {"LFHE_WIDE_BELOW": "1000000"}),
+    variants = (("two per workgroup", {"LFHE_PAIR_ABOVE": "0", "LFHE_WIDE_BELOW": "0", "LFHE_G64_SPLIT_BELOW": "0"}),
+                ("one per workgroup", {"LFHE_PAIR_ABOVE": "-1", "LFHE_WIDE_BELOW": "0", "LFHE_G64_SPLIT_BELOW": "0"}),
+                ("512 threads each", {"LFHE_WIDE_BELOW": "1000000", "LFHE_G64_SPLIT_BELOW": "0"}),
                 ("library's choice", {}))
     rows = {}
     for name, env in variants:
-        for k in ("LFHE_PAIR_ABOVE", "LFHE_WIDE_BELOW"):
+        for k in ("LFHE_PAIR_ABOVE", "LFHE_WIDE_BELOW", "LFHE_G64_SPLIT_BELOW"):
             os.environ.pop(k, None)
         os.environ.update(env)
         ctx = Context(seed=bytes(range(32)), params_id=pid)
