@@ -69,8 +69,8 @@ def main():
             wrong += sum(g != x for g, x in zip(got, xs))      # c ? (c ? a : b) : (c ? b : a) = a
             done += batch
         print(f"round {it + 1} of {rounds}: {done} evaluations, {wrong} wrong", file=sys.stderr, flush=True)
-    print(json.dumps({"params_id": pid, "evaluations": done, "wrong": wrong, "bootstraps": ctx.pbs_count() - p0,
-                      "seconds": round(time.time() - t0, 1)}), flush=True)
+    print(json.dumps({"params_id": pid, "batch": batch, "evaluations": done, "wrong": wrong, "bootstraps": ctx.pbs_count() - p0,
+                      "slow_path_bootstraps": ctx.lift_fallbacks(), "seconds": round(time.time() - t0, 1)}), flush=True)
     ctx.close()
     if wrong:
         raise SystemExit("wrong results")
