@@ -227,6 +227,7 @@ def test_bench_control_flow_two_ranks_gloo():
     assert {a["flavour"] for a in d["other_bootstrapping_keys"]} == {"q64", "q64_grouped", "q64_grouped3", "prime", "grouped"} and "value_q64_key" in d and "value_q64_grouped_key" in d
     assert d["value_param_set_as_published"]["own_key_with_the_key_bits_in_pairs"] == d["value_q64_grouped_key"]
     assert d["value_param_set_as_published"]["own_key_with_the_key_bits_in_triples"] == d["value_q64_grouped3_key"]
+    assert d["value_param_set_as_published"]["euint64_mul_latency_ms_with_the_key_bits_in_triples"] > 0
     assert d["mul_pbs"] > 0 and "cpu_baseline" not in d and d["roofline"]["traffic"] is None
     codes, out, errs = _run_driver("bench", 2, flags + ["--no-alt", "--no-operators"], corrupt_rank=1)
     assert all(c != 0 for c in codes), (codes, errs)
