@@ -59,9 +59,24 @@ def _build_locked(force, verbose, out, flags, tag, newest_header, hipcc) -> str:
             return obj
         tmp = f"{obj}.{os.getpid()}.tmp"
         cmd = [hipcc] + flags + ["-x", "hip", "-c", path, "-o", tmp]
+        report = src.endswith(".hip")
+        if report:   # registers, scratch and occupancy per kernel, kept next to the object (tests read them)
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
+        if report:
+            done = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+            remarks = [l for l in done.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" in l]
+            rest = [l for l in done.stderr.splitlines() if "-Rpass-analysis=kernel-resource-usage" not in l]
+            if rest:
+                print("\n".join(rest), file=sys.stderr)
+            if done.returncode:
+                raise subprocess.CalledProcessError(done.returncode, cmd)
+            with open(f"{obj}.resources.{os.getpid()}.tmp", "w") as f:
+                f.write("\n".join(remarks) + "\n")
+            os.replace(f"{obj}.resources.{os.getpid()}.tmp", obj + ".resources.txt")
+        else:
+            subprocess.check_call(cmd)
         os.replace(tmp, obj)      # a reader never sees a half-written object
         return obj
 

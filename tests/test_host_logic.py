@@ -299,3 +299,36 @@ def test_typescript_surface_matches_the_binding_and_the_reference_class():
         declared = set(re.findall(r"^\s+(?:readonly )?(\w+)[(:]", block(cls), re.M))
         assert set(names) - {"constructor"} <= declared, (cls, set(names) - declared)
         assert declared - set(names) <= {"engine", "constructor"}, (cls, declared - set(names))
+
+
+def test_blind_rotation_kernels_keep_their_registers():
+    """The blind-rotation kernels the library launches hold their state in registers: no scratch (spills turn
+    the FP64-bound kernels memory-bound), at most 256 VGPRs, two waves per SIMD.  Read from the compiler's
+    resource remarks that the build keeps next to the objects (the slow path of the lift guard, which never
+    runs, is allowed to spill)."""
+    import re
+    path = os.path.join(ROOT, "fhe_amd", "_build", "kernels.hip.o.resources.txt")
+    src = os.path.join(ROOT, "fhe_amd", "csrc", "kernels.hip")
+    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        pytest.skip("no resource remarks for the current kernels.hip (python fhe_amd/build.py writes them)")
+    kernels, name = {}, None
+    for line in open(path):
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            kernels[name] = {}
+            continue
+        m = re.search(r" (VGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): (\d+)", line)
+        if m and name:
+            kernels[name][m.group(1).split(" ")[0]] = int(m.group(2))
+    hot = {k: v for k, v in kernels.items() if "k_blind_rotate" in k}
+    assert len(hot) >= 20, sorted(kernels)
+    # mangled template arguments of k_blind_rotate_g64_pair<FACTORED, NC, SAFE, BITS>: ...Lb<F>ELi<NC>ELb<SAFE>ELi<BITS>E
+    slow_path = [k for k in hot if re.search(r"g64_pairILb[01]ELi1ELb1E", k)]
+    assert len(slow_path) == 3
+    for k, v in hot.items():
+        assert v["VGPRs"] <= 256, (k, v)
+        if k in slow_path:
+            continue
+        assert v["ScratchSize"] == 0, (k, v)
+        assert v["Occupancy"] >= 2 or "wide" in k, (k, v)      # the 512-thread kernels: one workgroup of eight waves per CU
