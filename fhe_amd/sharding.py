@@ -79,6 +79,11 @@ def replicated_context(dist, rank: int, world: int, device, seed: bytes, params_
         blob = ctx.export_keys(KEY_CLIENT)
     if world > 1 or (always_broadcast and dist is not None):
         images = key_image_tensors(ctx, device, owner=rank == 0)
+        if rank == 0 and device.type == "cuda":
+            # The collective gets memory torch allocated itself on every rank: the owner's images are copied out
+            # of the library's memory first (a device-to-device copy of a few hundred megabytes, once per key set),
+            # so that the communication library never has to register or export memory another runtime allocated.
+            images = [t.clone() for t in images]
         # The images were written on the library's own non-blocking stream, which no torch stream is
         # ordered against.  Every key load ends in a host-side wait on that stream, so they are complete
         # here; the two waits below make that ordering explicit at the hand-over instead of leaving it to
